@@ -1,0 +1,137 @@
+"""Small offline fixtures shared by the golden generator, the oracle tests and the GPU parity tests.
+
+Three models cover the three layer flavours of the hot path:
+``mlp`` (2-D activations, one layer without bias), ``conv`` (Conv2d incl. stride, padding, a grouped
+layer, bias / no-bias, followed by a Linear) and ``seq`` (``[b, T, d]`` Linear stack with a padding
+mask).  Every fixture has more fitted rows than factor dimensions so the covariances are full rank
+(or have a simple null vector) and the eigenbasis -- hence Lambda and the scores -- is well defined
+up to sign.
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, Dict, List, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+Batch = Tuple[torch.Tensor, ...]
+
+
+class _SeqModel(nn.Module):
+    def __init__(self, vocab: int = 20, width: int = 8) -> None:
+        super().__init__()
+        self.embed = nn.Embedding(vocab, width)
+        self.fc1 = nn.Linear(width, 12)
+        self.fc2 = nn.Linear(12, width, bias=False)
+        self.head = nn.Linear(width, vocab)
+
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        h = self.embed(ids)
+        h = h + self.fc2(torch.tanh(self.fc1(h)))
+        return self.head(h)
+
+
+def make_model(kind: str, seed: int = 0) -> nn.Module:
+    torch.manual_seed(seed)
+    if kind == "mlp":
+        return nn.Sequential(
+            nn.Linear(12, 16), nn.ReLU(), nn.Linear(16, 16, bias=False), nn.ReLU(), nn.Linear(16, 3)
+        )
+    if kind == "conv":
+        return nn.Sequential(
+            nn.Conv2d(3, 4, 3, padding=1, bias=False), nn.ReLU(),
+            nn.Conv2d(4, 8, 5, stride=2, padding=2, bias=True), nn.ReLU(),
+            nn.Conv2d(8, 6, 3, padding=1, groups=2, bias=True), nn.ReLU(),
+            nn.Flatten(), nn.Linear(6 * 4 * 4, 3),
+        )
+    if kind == "seq":
+        return _SeqModel()
+    raise KeyError(kind)
+
+
+def make_data(kind: str, n: int, seed: int) -> Batch:
+    gen = torch.Generator().manual_seed(seed)
+    if kind == "mlp":
+        return (torch.randn(n, 12, generator=gen), torch.randint(0, 3, (n,), generator=gen))
+    if kind == "conv":
+        return (torch.randn(n, 3, 8, 8, generator=gen), torch.randint(0, 3, (n,), generator=gen))
+    if kind == "seq":
+        t = 6
+        ids = torch.randint(0, 20, (n, t), generator=gen)
+        lengths = torch.randint(2, t + 1, (n,), generator=gen)
+        mask = (torch.arange(t)[None, :] < lengths[:, None]).to(torch.int64)
+        labels = torch.randint(0, 20, (n, t), generator=gen)
+        labels = torch.where(mask.bool(), labels, torch.full_like(labels, -100))
+        return (ids, mask, labels)
+    raise KeyError(kind)
+
+
+def _inputs_to(model: nn.Module, x: torch.Tensor) -> torch.Tensor:
+    if x.is_floating_point():
+        return x.to(dtype=next(model.parameters()).dtype)
+    return x
+
+
+def train_loss(kind: str) -> Callable[[nn.Module, Batch], torch.Tensor]:
+    """Summed cross-entropy with the true labels (empirical Fisher; deterministic)."""
+
+    def loss(model: nn.Module, batch: Batch) -> torch.Tensor:
+        if kind == "seq":
+            ids, _mask, labels = batch
+            logits = model(ids)
+            return F.cross_entropy(logits.reshape(-1, logits.shape[-1]), labels.reshape(-1),
+                                   reduction="sum", ignore_index=-100)
+        x, y = batch
+        return F.cross_entropy(model(_inputs_to(model, x)), y, reduction="sum")
+
+    return loss
+
+
+def measurement(kind: str) -> Callable[[nn.Module, Batch], torch.Tensor]:
+    """A measurement that differs from the loss: summed correct-class margin."""
+
+    def measure(model: nn.Module, batch: Batch) -> torch.Tensor:
+        if kind == "seq":
+            ids, mask, labels = batch
+            logits = model(ids)
+            safe = labels.clamp(min=0)
+            picked = logits.gather(-1, safe[..., None])[..., 0]
+            margins = picked - torch.logsumexp(logits, dim=-1) * 0.5
+            return (margins * mask.to(margins.dtype)).sum()
+        x, y = batch
+        logits = model(_inputs_to(model, x))
+        picked = logits.gather(-1, y[:, None])[:, 0]
+        return (picked - 0.5 * torch.logsumexp(logits, dim=-1)).sum()
+
+    return measure
+
+
+def attention_mask(kind: str) -> Optional[Callable[[Batch], Optional[torch.Tensor]]]:
+    if kind == "seq":
+        return lambda batch: batch[1]
+    return None
+
+
+def batches(data: Batch, batch_size: int) -> List[Batch]:
+    n = data[0].shape[0]
+    return [tuple(t[i:i + batch_size] for t in data) for i in range(0, n, batch_size)]
+
+
+@dataclass
+class Fixture:
+    kind: str
+    n_train: int
+    n_query: int
+    factor_batch: int
+    train_batch: int
+    query_batch: int
+
+
+FIXTURES: Dict[str, Fixture] = {
+    "mlp": Fixture("mlp", 48, 6, 16, 12, 3),
+    "conv": Fixture("conv", 40, 6, 8, 10, 3),
+    "seq": Fixture("seq", 48, 6, 16, 12, 3),
+}

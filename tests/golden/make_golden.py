@@ -1,0 +1,105 @@
+"""Golden-vector generator: runs the REAL reference (kronfluence v1.0.1) on CPU, here only.
+
+Usage (build container; the reference is mounted read-only at /root/reference):
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tests/golden/make_golden.py
+
+For each fixture in ``tests/fixtures.py`` and for the fp64 ("pytest" preset) and fp32 (reference
+defaults) dtypes it drives ``prepare_model`` / ``Analyzer.fit_all_factors`` /
+``Analyzer.compute_pairwise_scores`` of the reference and stores, as
+``tests/golden/<fixture>_<dtype>.safetensors``:
+
+  * ``cov/<factor>/<module>``   activation/gradient covariance + the two counters  (A6)
+  * ``eig/<factor>/<module>``   eigenvalues and eigenvectors                        (E1)
+  * ``lam/<factor>/<module>``   Lambda matrix + counter                             (L4)
+  * ``scores/damp1e-8`` and ``scores/dampNone``  pairwise ``all_modules`` scores   (S3)
+
+The two missing third-party imports (``opt_einsum``, ``einconv``) are satisfied by the
+no-arithmetic stand-ins in ``tests/golden/_shims``.  Nothing from the
+reference is copied into the repository: only inputs-free output tensors are committed (the
+inputs are regenerated from seeds by ``tests/fixtures.py``).
+"""
+
+import os
+import sys
+import tempfile
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "_shims"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.dirname(HERE))  # tests/
+sys.dont_write_bytecode = True
+
+import torch  # noqa: E402
+from safetensors.torch import save_file  # noqa: E402
+from torch.utils import data  # noqa: E402
+
+from kronfluence.analyzer import Analyzer, prepare_model  # noqa: E402
+from kronfluence.arguments import FactorArguments, ScoreArguments  # noqa: E402
+from kronfluence.task import Task  # noqa: E402
+
+import fixtures as fx  # noqa: E402
+
+
+def make_task(kind: str) -> Task:
+    loss, measure, mask = fx.train_loss(kind), fx.measurement(kind), fx.attention_mask(kind)
+
+    class GoldenTask(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            assert not sample
+            return loss(model, tuple(batch))
+
+        def compute_measurement(self, batch, model):
+            return measure(model, tuple(batch))
+
+        def get_attention_mask(self, batch):
+            return None if mask is None else mask(tuple(batch))
+
+    return GoldenTask()
+
+
+def run(kind: str, dtype: torch.dtype, out_path: str) -> None:
+    spec = fx.FIXTURES[kind]
+    model = fx.make_model(kind).to(dtype=dtype)
+    train = data.TensorDataset(*fx.make_data(kind, spec.n_train, seed=1))
+    query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
+    task = make_task(kind)
+    model = prepare_model(model, task)
+    with tempfile.TemporaryDirectory() as tmp:
+        analyzer = Analyzer("golden", model, task, cpu=True, disable_tqdm=True, output_dir=tmp)
+        fargs = FactorArguments(
+            use_empirical_fisher=True,
+            activation_covariance_dtype=dtype, gradient_covariance_dtype=dtype,
+            per_sample_gradient_dtype=dtype, lambda_dtype=dtype,
+        )
+        analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch, factor_args=fargs,
+                                 overwrite_output_dir=True)
+        factors = analyzer.load_all_factors("f")
+        # covariance factors are not part of load_all_factors for ekfac
+        cov = analyzer.load_covariance_matrices("f")
+        out = {}
+        for name, per_module in cov.items():
+            for module, tensor in per_module.items():
+                out[f"cov/{name}/{module}"] = tensor.contiguous()
+        for name, per_module in factors.items():
+            group = "lam" if "lambda" in name else "eig"
+            for module, tensor in per_module.items():
+                out[f"{group}/{name}/{module}"] = tensor.contiguous()
+        for tag, damping in (("damp1e-8", 1e-8), ("dampNone", None)):
+            sargs = ScoreArguments(damping_factor=damping, per_sample_gradient_dtype=dtype,
+                                   precondition_dtype=dtype, score_dtype=dtype)
+            analyzer.compute_pairwise_scores(
+                f"s_{tag}", "f", query, train,
+                per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch,
+                score_args=sargs, overwrite_output_dir=True,
+            )
+            out[f"scores/{tag}"] = analyzer.load_pairwise_scores(f"s_{tag}")["all_modules"].contiguous()
+    save_file(out, out_path)
+    print(f"{out_path}: {len(out)} tensors, scores {tuple(out['scores/damp1e-8'].shape)}")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    for kind in fx.FIXTURES:
+        for tag, dtype in (("fp64", torch.float64), ("fp32", torch.float32)):
+            run(kind, dtype, os.path.join(HERE, f"{kind}_{tag}.safetensors"))
