@@ -1,0 +1,199 @@
+/*
+ * kronfluence_hip.h -- C ABI of the MI355X (gfx950) EK-FAC hot-path library, libkronfluence_hip.so.
+ *
+ * This is the drop-in boundary one level below kronfluence's Python plugin interfaces
+ * (TrackedModule operator API, Tracker hook API, FactorConfig strategy API).
+ * Every entry point replaces the dense-math torch call sites of one reference routine; the
+ * reference file:line each one stands in for is cited at its declaration (paths relative to the
+ * reference checkout).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / hip types in signatures ("stream" is a hipStream_t
+ *     passed as void*; NULL = the default stream);
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch's allocator in the shipped host
+ *     code); the library never allocates, frees or retains caller memory;
+ *   - every call is asynchronous on `stream`, never synchronises it (kf_eigh_f64 is the one
+ *     documented exception) and is re-entrant;
+ *   - return value: KF_OK (0) or a negative kf_status; never throws;
+ *   - accumulators ("+=" outputs) are fp32 regardless of the input dtype; the host casts on export;
+ *   - matrices are row-major; "ld*" = elements between consecutive rows.
+ */
+#ifndef KRONFLUENCE_HIP_H
+#define KRONFLUENCE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum kf_status {
+    KF_OK = 0,
+    KF_ERR_INVALID_ARGUMENT = -1,
+    KF_ERR_UNSUPPORTED_DTYPE = -2,
+    KF_ERR_LAUNCH_FAILED = -3,
+    KF_ERR_WORKSPACE_TOO_SMALL = -4,
+    KF_ERR_NOT_CONVERGED = -5,
+    KF_ERR_NO_DEVICE = -6
+} kf_status;
+
+typedef enum kf_dtype {
+    KF_F32 = 0,
+    KF_BF16 = 1,
+    KF_F16 = 2,
+    KF_F64 = 3,
+    KF_I64 = 4, /* mask dtypes only */
+    KF_I32 = 5,
+    KF_U8 = 6 /* torch.bool / torch.uint8 */
+} kf_dtype;
+
+/* ABI version: bumped on any signature change. */
+int kf_abi_version(void);
+const char* kf_status_string(int status);
+/* Number of visible HIP devices, or a negative kf_status.  The only call that is legal without a GPU. */
+int kf_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 1 -- covariance accumulation
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * C[d,d] += alpha * X'^T X'        (d = d_in + append_ones)
+ *
+ * X' is the "flattened activation" of module/linear.py:30-46 built on the fly from the hooked
+ * tensor: row n of X' is mask[n] * [X[n, 0..d_in), 1] (the ones column only if append_ones; the
+ * mask multiplies the ones column too, exactly as linear.py:39-43).  With mask == NULL and
+ * append_ones == 0 it is the gradient update of module/tracker/factor.py:93 (alpha =
+ * gradient_scale^2, factor.py:90-92); the reference never masks gradients (linear.py:48-54).
+ * Replaces: module/tracker/factor.py:58 (addmm_), :93 (addmm_), module/linear.py:33-43 (mask,
+ * ones column, cat).
+ *
+ * Row n lives at X + (n / rows_inner) * outer_stride + (n % rows_inner) * row_stride, element c of
+ * it col_stride further on (strides in elements).  A [n,d] matrix is rows_inner = n_rows,
+ * row_stride = ld, col_stride = 1; an NCHW output gradient [b,O,P] seen as rows (b,p) x cols o
+ * (module/conv2d.py:130-132) is rows_inner = P, outer_stride = O*P, row_stride = 1, col_stride = P.
+ *
+ * count (nullable, device int64[1]) += sum(mask) if mask else n_rows  (linear.py:45,
+ * factor.py:57).  Both triangles of C are updated, C stays symmetric.
+ */
+int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_rows, int64_t d_in,
+                  int64_t rows_inner, int64_t outer_stride, int64_t row_stride, int64_t col_stride,
+                  const void* mask, int mask_dtype, int append_ones, float alpha, int64_t* count,
+                  void* stream);
+
+/*
+ * out[b, P, I'] = unfold(group_mean(x))  (+ ones column), I' = C/groups*k1*k2 + append_ones,
+ * P = O1*O2.  Replaces module/conv2d.py:15-64 (extract_patches: rearrange, reduce "mean",
+ * F.unfold, transpose) and :120-127 (ones column).  x is NCHW contiguous.
+ */
+int kf_im2col(void* out, int out_dtype, const void* x, int in_dtype, int64_t b, int64_t C, int64_t H,
+              int64_t W, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2, int groups,
+              int append_ones, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Generic strided batched GEMM on the MFMA engine (building block of stages 2 and 3)
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * Operand view: element (z, r, k) = p[z*batch_stride + r*row_stride + k*k_stride] for r < rows,
+ * k < depth; if ones_row (resp. ones_k) the index r == rows (resp. k == depth) exists and reads
+ * 1.0 -- the un-masked bias column of module/linear.py:56-61 without a torch.cat.
+ */
+typedef struct kf_view {
+    const void* p;
+    int dtype;
+    int64_t batch_stride, row_stride, k_stride;
+    int64_t rows, depth;
+    int ones_row, ones_k;
+    int square; /* read x*x instead of x */
+} kf_view;
+
+/*
+ * C[z, m, n] = alpha * sum_k A(z,m,k) * B(z,n,k) * (mul ? mul[m*ld_mul + n] : 1) + beta * C[z,m,n]
+ * for z < batch.  C is fp32, z-th matrix at C + z*c_batch_stride.  c_batch_stride == 0 with
+ * batch > 1 sums the batch into one matrix (atomically).  Replaces torch.matmul at
+ * module/tracker/factor.py:205-226 and factor/config.py:350-352, torch.einsum at
+ * module/linear.py:72 and module/conv2d.py:176.
+ */
+int kf_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view* A, const kf_view* B,
+            int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 2 -- eigendecomposition and Lambda
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * Symmetric eigendecomposition in fp64 of  S = 0.5*(cov + cov^T) / count.
+ * Replaces factor/eigen.py:193-205 (to(fp64), div_, symmetrise, torch.linalg.eigh -> LAPACK
+ * syevd).  evals[d] ascending, evecs[d,d] row-major with eigenvectors in COLUMNS (torch
+ * convention), both fp64; the host casts back to the covariance dtype (eigen.py:214-219).
+ * cov is fp32 or fp64 [d,d]; count is a host value.  workspace: device, at least
+ * kf_eigh_workspace_bytes(d) bytes.  max_sweeps <= 0 selects the default (30).
+ * One-sided (Hestenes) Jacobi with a round-robin pair schedule; this call synchronises `stream`
+ * once per sweep to read the convergence flag.
+ */
+int64_t kf_eigh_workspace_bytes(int64_t d);
+int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double* evals, double* evecs,
+                void* workspace, int64_t workspace_bytes, int max_sweeps, int* sweeps_done,
+                void* stream);
+
+/*
+ * Lambda[O,I'] += sum_b ( sum_r Gt[b,r,o] * At[b,r,i] )^2
+ * where Gt = G Qg and At = [A,1] Qa are the factors of the per-sample gradient already rotated
+ * into the eigenbasis (two kf_gemm calls).  Identical mathematics to
+ * module/tracker/factor.py:218-226 (Qg^T (g_b Qa), square_, sum(0)) because
+ * Qg^T (sum_r g_r a_r^T) Qa = (G Qg)^T (A' Qa); costs 2 R (I'^2 + O^2 + O I') instead of
+ * 2 O I' (I' + O + R) flops per sample.  Gt: [b,R,O] fp32 contiguous, At: [b,R,I'] fp32 contiguous.
+ * scale multiplies the per-sample gradient (gradient_scale, factor.py:269-270).
+ */
+int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const float* Gt, const float* At, int64_t b,
+                    int64_t R, int64_t O, int64_t Ip, float scale, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stage 3 -- preconditioning and pairwise scores
+ * ------------------------------------------------------------------------------------------- */
+
+/*
+ * out[i] = 1 / (Lambda[i] / n_lambda + damping), computed in fp64 (utils/constants.py:82),
+ * damping < 0 selects the heuristic 0.1 * mean(Lambda / n_lambda) (factor/config.py:331-338,
+ * utils/constants.py:22).  Lambda fp32 [numel]; out fp32 [numel]; workspace: >= 16 bytes, device.
+ */
+int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambda, double damping,
+                  void* workspace, void* stream);
+
+/*
+ * P[q,O,I'] = scale * Qg ( (Qg^T g_q Qa) o inv_lambda ) Qa^T,  g_q = sum_r G[q,r,:]^T [A[q,r,:],1]
+ * Replaces module/tracker/precondition.py:102-123 (per-sample gradient, precondition, scale) and
+ * factor/config.py:341-353 (four matmuls + mul_).  The forward rotation is done on the factors
+ * (G Qg, A' Qa) instead of on the [O,I'] gradient.
+ * G: [q,R,O], A: [q,R,I] (in_dtype, contiguous), Qg [O,O], Qa [I',I'], inv_lambda [O,I'] fp32.
+ * workspace (device): kf_precondition_workspace_bytes(q,R,O,I') bytes.
+ */
+int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip);
+int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_t q, int64_t R,
+                    int64_t O, int64_t I, int append_ones, const float* Qg, const float* Qa,
+                    const float* inv_lambda, float scale, void* workspace, int64_t workspace_bytes,
+                    void* stream);
+
+/*
+ * scores[q, n] += scale * sum_{o,i} P[q,o,i] * ( sum_r G[n,r,o] * A'[n,r,i] )   for n < b
+ * Replaces module/linear.py:112-122 and module/conv2d.py:199-209 (three-operand einsum),
+ * module/tracker/pairwise_score.py:41-45 and the per-layer add_ of score/dot_product.py:105-117:
+ * every layer accumulates into the same [Q, ld_scores] device buffer, one D2H per shard.
+ * P: [Q,O,I'] fp32 contiguous.  G: [b,R,O], A: [b,R,I] (in_dtype, contiguous); A' = [A,1] if
+ * append_ones.  R == 1 never materialises the per-sample gradient; R > 1 forms it in
+ * `workspace` (kf_pairwise_workspace_bytes) and contracts it with P on the MFMA engine.
+ */
+int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip);
+int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t Q, const void* G,
+                      const void* A, int in_dtype, int64_t b, int64_t R, int64_t O, int64_t I,
+                      int append_ones, float scale, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+/* Elementwise helper: dst[i] = (out_dtype) src[i] -- export of fp32 accumulators in the factor dtype. */
+int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KRONFLUENCE_HIP_H */

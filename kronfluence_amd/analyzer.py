@@ -1,0 +1,327 @@
+"""``prepare_model`` and ``Analyzer``: the user-facing API (reference ``analyzer.py:20-242`` and the
+orchestration subset of ``computer/{computer,factor_computer,score_computer}.py`` that the EK-FAC
+hot path needs: single data/module partition, explicit batch sizes, skip-if-exists, the same
+``influence_results/<analysis>/factors_<name>/*.safetensors`` layout).
+
+There is no CPU mode: every stage runs on an MI355X through ``libkronfluence_hip.so``.
+"""
+
+from __future__ import annotations
+
+import logging
+import os
+import time
+from pathlib import Path
+from typing import Dict, List, Optional, Sequence
+
+import torch
+from torch import nn
+from torch.utils import data
+from torch.utils.data import DistributedSampler, SequentialSampler
+
+from kronfluence_amd.arguments import FactorArguments, ScoreArguments
+from kronfluence_amd.factor.config import FactorConfig
+from kronfluence_amd.factor.covariance import (
+    covariance_matrices_exist, fit_covariance_matrices_with_loader, load_covariance_matrices, save_covariance_matrices,
+)
+from kronfluence_amd.factor.eigen import (
+    eigendecomposition_exist, fit_lambda_matrices_with_loader, lambda_matrices_exist, load_eigendecomposition,
+    load_lambda_matrices, perform_eigendecomposition, save_eigendecomposition, save_lambda_matrices,
+)
+from kronfluence_amd.module.tracked_module import TrackedModule
+from kronfluence_amd.module.utils import get_tracked_module_names, wrap_tracked_modules
+from kronfluence_amd.score.pairwise import (
+    compute_pairwise_scores_with_loaders, load_pairwise_scores, pairwise_scores_exist, save_pairwise_scores,
+)
+from kronfluence_amd.task import Task
+from kronfluence_amd.utils.constants import FACTOR_SAVE_PREFIX, FACTOR_TYPE, SCORE_SAVE_PREFIX, SCORE_TYPE
+from kronfluence_amd.utils.dataset import DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack
+from kronfluence_amd.utils.exceptions import FactorsNotFoundError, TrackedModuleNotFoundError
+from kronfluence_amd.utils.save import load_json, save_json
+from kronfluence_amd.utils.state import State
+
+
+def prepare_model(model: nn.Module, task: Task) -> nn.Module:
+    """Freezes every parameter and buffer, switches to eval mode and installs ``TrackedModule``
+    wrappers (reference ``analyzer.py:20-45``)."""
+    model.eval()
+    for tensor in list(model.parameters()) + list(model.buffers()):
+        tensor.requires_grad = False
+    return wrap_tracked_modules(model=model, task=task)
+
+
+class Analyzer:
+    def __init__(self, analysis_name: str, model: nn.Module, task: Task, cpu: bool = False,
+                 log_level: Optional[int] = None, log_main_process_only: bool = True, profile: bool = False,
+                 disable_tqdm: bool = False, output_dir: str = "./influence_results",
+                 disable_model_save: bool = True) -> None:
+        del log_main_process_only, disable_model_save
+        if cpu:
+            raise RuntimeError("`cpu=True` is not available: the MI355X-native engine has no CPU path.")
+        if not torch.cuda.is_available():
+            raise RuntimeError("No MI355X visible (torch.cuda.is_available() is False); there is no CPU fallback.")
+        self.name, self.task, self.disable_tqdm, self.profile = analysis_name, task, disable_tqdm, profile
+        self.state = State(cpu=False)
+        self.logger = logging.getLogger(f"kronfluence_amd.{analysis_name}")
+        if log_level is not None:
+            self.logger.setLevel(log_level)
+        if not any(isinstance(m, TrackedModule) for m in model.modules()):
+            raise TrackedModuleNotFoundError(
+                f"No `TrackedModule` found in model. Call `prepare_model` before initializing `Analyzer`."
+            )
+        self.model = model.to(self.state.device)
+        self.output_dir = Path(output_dir).joinpath(analysis_name).resolve()
+        if self.state.is_main_process:
+            os.makedirs(self.output_dir, exist_ok=True)
+        self._dataloader_params = DataLoaderKwargs()
+        self.timings: Dict[str, float] = {}
+        self.state.wait_for_everyone()
+
+    # -- helpers -----------------------------------------------------------------------------------
+    def set_dataloader_kwargs(self, dataloader_kwargs: DataLoaderKwargs) -> None:
+        self._dataloader_params = dataloader_kwargs
+
+    def factors_output_dir(self, factors_name: str) -> Path:
+        return (self.output_dir / (FACTOR_SAVE_PREFIX + factors_name)).resolve()
+
+    def scores_output_dir(self, scores_name: str) -> Path:
+        return (self.output_dir / (SCORE_SAVE_PREFIX + scores_name)).resolve()
+
+    def _timed(self, label: str):
+        analyzer = self
+
+        class _Timer:
+            def __enter__(self):
+                torch.cuda.synchronize()
+                self.t0 = time.perf_counter()
+
+            def __exit__(self, *exc):
+                torch.cuda.synchronize()
+                analyzer.timings[label] = analyzer.timings.get(label, 0.0) + time.perf_counter() - self.t0
+
+        return _Timer()
+
+    def _get_dataloader(self, dataset: data.Dataset, per_device_batch_size: int, dataloader_params: Dict,
+                        indices: Optional[Sequence[int]] = None, allow_duplicates: bool = False,
+                        stack: bool = False) -> data.DataLoader:
+        """Sampler choice as reference ``computer/computer.py:193-239``."""
+        if indices is not None:
+            dataset = data.Subset(dataset=dataset, indices=indices)
+        if self.state.use_distributed and not allow_duplicates:
+            sampler = DistributedEvalSampler(dataset, num_replicas=self.state.num_processes, rank=self.state.process_index)
+        elif self.state.use_distributed and stack:
+            sampler = DistributedSamplerWithStack(dataset, num_replicas=self.state.num_processes, rank=self.state.process_index)
+        elif self.state.use_distributed:
+            sampler = DistributedSampler(dataset, num_replicas=self.state.num_processes, rank=self.state.process_index,
+                                         shuffle=False, drop_last=False)
+        else:
+            sampler = SequentialSampler(dataset)
+        return data.DataLoader(dataset=dataset, batch_size=per_device_batch_size, sampler=sampler, drop_last=False,
+                               shuffle=False, **dataloader_params)
+
+    @staticmethod
+    def _require_batch_size(value: Optional[int], what: str) -> int:
+        if value is None:
+            raise ValueError(f"`{what}` must be given explicitly (automatic batch-size search is not part of this build).")
+        return value
+
+    @staticmethod
+    def _single_partition(*partitions: int) -> None:
+        if any(p != 1 for p in partitions):
+            raise NotImplementedError("Data/module partitioning is a memory work-around for 80 GB GPUs and is not "
+                                      "part of the MI355X hot path (SURVEY.md section 2.1 row 2).")
+
+    def _save_arguments(self, path: Path, arguments, overwrite: bool) -> None:
+        if self.state.is_main_process:
+            if path.exists() and not overwrite:
+                stored = load_json(path)
+                if stored != arguments.to_dict():
+                    raise ValueError(f"Arguments stored at `{path}` differ from the ones provided; pass "
+                                     f"`overwrite_output_dir=True` or use a different name.")
+            else:
+                save_json(arguments.to_dict(), path)
+
+    # -- factors -----------------------------------------------------------------------------------
+    def fit_covariance_matrices(self, factors_name: str, dataset: data.Dataset,
+                                per_device_batch_size: Optional[int] = None,
+                                initial_per_device_batch_size_attempt: int = 4096,
+                                dataloader_kwargs: Optional[DataLoaderKwargs] = None,
+                                factor_args: Optional[FactorArguments] = None,
+                                target_data_partitions: Optional[Sequence[int]] = None,
+                                target_module_partitions: Optional[Sequence[int]] = None,
+                                overwrite_output_dir: bool = False) -> None:
+        del initial_per_device_batch_size_attempt, target_data_partitions, target_module_partitions
+        factor_args = factor_args or FactorArguments()
+        self._single_partition(factor_args.covariance_data_partitions, factor_args.covariance_module_partitions)
+        out = self.factors_output_dir(factors_name)
+        if self.state.is_main_process:
+            os.makedirs(out, exist_ok=True)
+        self.state.wait_for_everyone()
+        if covariance_matrices_exist(out) and not overwrite_output_dir:
+            return
+        self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)
+        if not FactorConfig.CONFIGS[factor_args.strategy].requires_covariance_matrices:
+            return
+        batch_size = self._require_batch_size(per_device_batch_size, "per_device_batch_size")
+        total = len(dataset) if factor_args.covariance_max_examples is None else min(factor_args.covariance_max_examples, len(dataset))
+        loader = self._get_dataloader(dataset, batch_size, (dataloader_kwargs or self._dataloader_params).to_dict(),
+                                      indices=list(range(total)), allow_duplicates=False)
+        with self._timed("fit_covariance"):
+            _, factors = fit_covariance_matrices_with_loader(self.model, self.state, self.task, loader, factor_args)
+        if self.state.is_main_process:
+            save_covariance_matrices(out, factors, metadata=factor_args.to_str_dict())
+        self.state.wait_for_everyone()
+
+    def perform_eigendecomposition(self, factors_name: str, factor_args: Optional[FactorArguments] = None,
+                                   overwrite_output_dir: bool = False,
+                                   load_from_factors_name: Optional[str] = None) -> None:
+        factor_args = factor_args or FactorArguments()
+        out = self.factors_output_dir(factors_name)
+        if self.state.is_main_process:
+            os.makedirs(out, exist_ok=True)
+        self.state.wait_for_everyone()
+        if eigendecomposition_exist(out) and not overwrite_output_dir:
+            return
+        if not FactorConfig.CONFIGS[factor_args.strategy].requires_eigendecomposition:
+            return
+        source = self.factors_output_dir(load_from_factors_name) if load_from_factors_name else out
+        if not covariance_matrices_exist(source):
+            raise FactorsNotFoundError(f"Covariance matrices not found at `{source}`. "
+                                       f"To perform eigendecomposition, call `fit_covariance_matrices` first.")
+        covariance = load_covariance_matrices(source)
+        with self._timed("perform_eigendecomposition"):
+            eigen = perform_eigendecomposition(covariance, self.model, self.state, factor_args)
+        if self.state.is_main_process:
+            save_eigendecomposition(out, eigen, metadata=factor_args.to_str_dict())
+        self.state.wait_for_everyone()
+
+    def fit_lambda_matrices(self, factors_name: str, dataset: data.Dataset, per_device_batch_size: Optional[int] = None,
+                            initial_per_device_batch_size_attempt: int = 4096,
+                            dataloader_kwargs: Optional[DataLoaderKwargs] = None,
+                            factor_args: Optional[FactorArguments] = None,
+                            target_data_partitions: Optional[Sequence[int]] = None,
+                            target_module_partitions: Optional[Sequence[int]] = None,
+                            overwrite_output_dir: bool = False,
+                            load_from_factors_name: Optional[str] = None) -> None:
+        del initial_per_device_batch_size_attempt, target_data_partitions, target_module_partitions
+        factor_args = factor_args or FactorArguments()
+        self._single_partition(factor_args.lambda_data_partitions, factor_args.lambda_module_partitions)
+        out = self.factors_output_dir(factors_name)
+        if self.state.is_main_process:
+            os.makedirs(out, exist_ok=True)
+        self.state.wait_for_everyone()
+        if lambda_matrices_exist(out) and not overwrite_output_dir:
+            return
+        config = FactorConfig.CONFIGS[factor_args.strategy]
+        if not config.requires_lambda_matrices:
+            return
+        eigen = None
+        if config.requires_eigendecomposition_for_lambda:
+            source = self.factors_output_dir(load_from_factors_name) if load_from_factors_name else out
+            if not eigendecomposition_exist(source):
+                raise FactorsNotFoundError(f"Eigendecomposition results not found at `{source}`. "
+                                           f"To fit Lambda matrices, call `perform_eigendecomposition` first.")
+            eigen = load_eigendecomposition(source)
+        batch_size = self._require_batch_size(per_device_batch_size, "per_device_batch_size")
+        total = len(dataset) if factor_args.lambda_max_examples is None else min(factor_args.lambda_max_examples, len(dataset))
+        loader = self._get_dataloader(dataset, batch_size, (dataloader_kwargs or self._dataloader_params).to_dict(),
+                                      indices=list(range(total)), allow_duplicates=False)
+        with self._timed("fit_lambda"):
+            _, factors = fit_lambda_matrices_with_loader(self.model, self.state, self.task, loader, factor_args, eigen)
+        if self.state.is_main_process:
+            save_lambda_matrices(out, factors, metadata=factor_args.to_str_dict())
+        self.state.wait_for_everyone()
+
+    def fit_all_factors(self, factors_name: str, dataset: data.Dataset, per_device_batch_size: Optional[int] = None,
+                        initial_per_device_batch_size_attempt: int = 4096,
+                        dataloader_kwargs: Optional[DataLoaderKwargs] = None,
+                        factor_args: Optional[FactorArguments] = None, overwrite_output_dir: bool = False) -> None:
+        """Covariance -> eigendecomposition -> Lambda (reference ``analyzer.py:144-195``)."""
+        common = dict(factors_name=factors_name, factor_args=factor_args, overwrite_output_dir=overwrite_output_dir)
+        self.fit_covariance_matrices(dataset=dataset, per_device_batch_size=per_device_batch_size,
+                                     initial_per_device_batch_size_attempt=initial_per_device_batch_size_attempt,
+                                     dataloader_kwargs=dataloader_kwargs, **common)
+        self.perform_eigendecomposition(**common)
+        self.fit_lambda_matrices(dataset=dataset, per_device_batch_size=per_device_batch_size,
+                                 initial_per_device_batch_size_attempt=initial_per_device_batch_size_attempt,
+                                 dataloader_kwargs=dataloader_kwargs, **common)
+
+    def load_factor_args(self, factors_name: str) -> Optional[Dict]:
+        path = self.factors_output_dir(factors_name) / "factor_arguments.json"
+        return load_json(path) if path.exists() else None
+
+    def load_covariance_matrices(self, factors_name: str) -> Optional[FACTOR_TYPE]:
+        out = self.factors_output_dir(factors_name)
+        return load_covariance_matrices(out) if covariance_matrices_exist(out) else None
+
+    def load_eigendecomposition(self, factors_name: str) -> Optional[FACTOR_TYPE]:
+        out = self.factors_output_dir(factors_name)
+        return load_eigendecomposition(out) if eigendecomposition_exist(out) else None
+
+    def load_lambda_matrices(self, factors_name: str) -> Optional[FACTOR_TYPE]:
+        out = self.factors_output_dir(factors_name)
+        return load_lambda_matrices(out) if lambda_matrices_exist(out) else None
+
+    def load_all_factors(self, factors_name: str) -> FACTOR_TYPE:
+        """Everything the strategy needs for preconditioning (reference ``computer/computer.py:387-434``)."""
+        stored = self.load_factor_args(factors_name)
+        strategy = stored["strategy"] if stored else "ekfac"
+        config = FactorConfig.CONFIGS[strategy]
+        loaded: FACTOR_TYPE = {}
+        if config.requires_covariance_matrices_for_precondition:
+            loaded.update(self.load_covariance_matrices(factors_name) or {})
+        if config.requires_eigendecomposition_for_precondition:
+            loaded.update(self.load_eigendecomposition(factors_name) or {})
+        if config.requires_lambda_matrices_for_precondition:
+            loaded.update(self.load_lambda_matrices(factors_name) or {})
+        return loaded
+
+    # -- scores ------------------------------------------------------------------------------------
+    def compute_pairwise_scores(self, scores_name: str, factors_name: str, query_dataset: data.Dataset,
+                                train_dataset: data.Dataset, per_device_query_batch_size: int,
+                                per_device_train_batch_size: Optional[int] = None,
+                                initial_per_device_train_batch_size_attempt: int = 4096,
+                                query_indices: Optional[Sequence[int]] = None,
+                                train_indices: Optional[Sequence[int]] = None,
+                                dataloader_kwargs: Optional[DataLoaderKwargs] = None,
+                                score_args: Optional[ScoreArguments] = None,
+                                target_data_partitions: Optional[Sequence[int]] = None,
+                                target_module_partitions: Optional[Sequence[int]] = None,
+                                overwrite_output_dir: bool = False) -> Optional[SCORE_TYPE]:
+        del initial_per_device_train_batch_size_attempt, target_data_partitions, target_module_partitions
+        score_args = score_args or ScoreArguments()
+        self._single_partition(score_args.data_partitions, score_args.module_partitions)
+        out = self.scores_output_dir(scores_name)
+        if self.state.is_main_process:
+            os.makedirs(out, exist_ok=True)
+        self.state.wait_for_everyone()
+        if pairwise_scores_exist(out) and not overwrite_output_dir:
+            return self.load_pairwise_scores(scores_name)
+        stored = self.load_factor_args(factors_name)
+        if stored is None:
+            raise FactorsNotFoundError(f"Factors with name `{factors_name}` not found at `{self.factors_output_dir(factors_name)}`.")
+        factor_args = FactorArguments(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
+                                         for k, v in stored.items()})
+        self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
+        loaded = self.load_all_factors(factors_name)
+        if not loaded:
+            raise FactorsNotFoundError(f"Factors with name `{factors_name}` are incomplete.")
+        params = (dataloader_kwargs or self._dataloader_params).to_dict()
+        train_batch = self._require_batch_size(per_device_train_batch_size, "per_device_train_batch_size")
+        query_loader = self._get_dataloader(query_dataset, per_device_query_batch_size, params, indices=query_indices,
+                                            allow_duplicates=True)
+        train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=train_indices,
+                                            allow_duplicates=True, stack=True)
+        with self._timed("compute_pairwise_scores"):
+            scores = compute_pairwise_scores_with_loaders(
+                loaded_factors=loaded, model=self.model, state=self.state, task=self.task, query_loader=query_loader,
+                per_device_query_batch_size=per_device_query_batch_size, train_loader=train_loader,
+                score_args=score_args, factor_args=factor_args, tracked_module_names=get_tracked_module_names(self.model))
+        if self.state.is_main_process:
+            save_pairwise_scores(out, scores, metadata=score_args.to_str_dict())
+        self.state.wait_for_everyone()
+        return scores if self.state.is_main_process else None
+
+    def load_pairwise_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
+        out = self.scores_output_dir(scores_name)
+        return load_pairwise_scores(out) if pairwise_scores_exist(out) else None

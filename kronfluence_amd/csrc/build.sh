@@ -1,0 +1,18 @@
+#!/usr/bin/env bash
+# Builds libkronfluence_hip.so for gfx950 in-tree (the .so travels to the GPU box with the snapshot).
+set -euo pipefail
+here="$(cd "$(dirname "${BASH_SOURCE[0]}")" && pwd)"
+out="${here}/../libkronfluence_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function)
+mkdir -p "${here}/obj"
+pids=()
+for src in kf_kernels kf_eigh; do
+  if [[ ! -f "${here}/obj/${src}.o" || "${here}/${src}.hip" -nt "${here}/obj/${src}.o" || "${here}/kf_engine.h" -nt "${here}/obj/${src}.o" || "${here}/../../include/kronfluence_hip.h" -nt "${here}/obj/${src}.o" ]]; then
+    "${HIPCC}" "${flags[@]}" -c "${here}/${src}.hip" -o "${here}/obj/${src}.o" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]:-}"; do [[ -n "${p}" ]] && wait "${p}"; done
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${here}/obj/kf_kernels.o" "${here}/obj/kf_eigh.o" -o "${out}"
+echo "built ${out}"

@@ -1,0 +1,174 @@
+// kf_eigh.hip -- fp64 symmetric eigensolver for the EK-FAC covariance factors (gfx950).
+//
+// Replaces torch.linalg.eigh (LAPACK syevd) at factor/eigen.py:205.  Algorithm: one-sided
+// (Hestenes) Jacobi.  With S symmetric, W := S and V := I; every rotation J is applied to the
+// columns of both (W <- W J, V <- V J) so that W = S V throughout; at convergence the columns of W
+// are mutually orthogonal, hence V^T S^2 V is diagonal and V holds the eigenvectors of S.  The
+// eigenvalue of column j is the Rayleigh quotient v_j . w_j (sign included).  Rotations of one
+// round act on disjoint column pairs (round-robin tournament schedule), one workgroup per pair;
+// both matrices are stored transposed (a "column" is a contiguous row) so every access is a
+// coalesced stream of doubles.  All arithmetic is fp64 VALU (the matrices are L2/MALL resident).
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/kronfluence_hip.h"
+
+namespace {
+
+constexpr int EB = 256;  // threads per pair-workgroup
+
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+    // wave64 shuffle reduction, then across the 4 waves through LDS
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) scratch[wave] = v;
+    __syncthreads();
+    return scratch[0] + scratch[1] + scratch[2] + scratch[3];
+}
+
+// Wt = 0.5 * (cov + cov^T) / count   (symmetric, so Wt == W),  Vt = I
+__global__ void eigh_init_kernel(double* Wt, double* Vt, const void* cov, int is_f64, double count, int64_t d) {
+    const int64_t total = d * d;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t i = e / d, j = e % d;
+        double a, b;
+        if (is_f64) { a = reinterpret_cast<const double*>(cov)[i * d + j]; b = reinterpret_cast<const double*>(cov)[j * d + i]; }
+        else { a = reinterpret_cast<const float*>(cov)[i * d + j]; b = reinterpret_cast<const float*>(cov)[j * d + i]; }
+        // mirror the reference's op order: divide, then add the transpose, then halve (eigen.py:198-203)
+        Wt[e] = 0.5 * (a / count + b / count);
+        Vt[e] = (i == j) ? 1.0 : 0.0;
+    }
+}
+
+// One round of the tournament: block k rotates the pair (p, q) of round `round`.
+// npl = number of "players" (d rounded up to even); player npl-1 may be a bye when d is odd.
+__global__ __launch_bounds__(EB) void jacobi_round_kernel(double* Wt, double* Vt, int64_t d, int npl, int round,
+                                                          double tol, int* rotated) {
+    __shared__ double scratch[4];
+    const int k = blockIdx.x;
+    int p, q;
+    const int m = npl - 1;
+    if (k == 0) { p = round % m; q = m; }
+    else { p = (round + k) % m; q = (round - k + m) % m; }
+    if (p >= d || q >= d) return;
+    double* wp = Wt + static_cast<int64_t>(p) * d;
+    double* wq = Wt + static_cast<int64_t>(q) * d;
+    double alpha = 0.0, beta = 0.0, gamma = 0.0;
+    for (int64_t i = threadIdx.x; i < d; i += EB) {
+        const double x = wp[i], y = wq[i];
+        alpha += x * x; beta += y * y; gamma += x * y;
+    }
+    alpha = block_sum(alpha, scratch);
+    beta = block_sum(beta, scratch);
+    gamma = block_sum(gamma, scratch);
+    const double lim = tol * sqrt(alpha) * sqrt(beta);
+    if (!(fabs(gamma) > lim)) return;  // uniform across the block (also catches NaN and zero columns)
+    const double zeta = (beta - alpha) / (2.0 * gamma);
+    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+    const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
+    double* vp = Vt + static_cast<int64_t>(p) * d;
+    double* vq = Vt + static_cast<int64_t>(q) * d;
+    for (int64_t i = threadIdx.x; i < d; i += EB) {
+        const double x = wp[i], y = wq[i];
+        wp[i] = c * x - s * y; wq[i] = s * x + c * y;
+        const double u = vp[i], v = vq[i];
+        vp[i] = c * u - s * v; vq[i] = s * u + c * v;
+    }
+    if (threadIdx.x == 0) atomicAdd(rotated, 1);
+}
+
+// lambda_j = v_j . w_j
+__global__ __launch_bounds__(EB) void rayleigh_kernel(double* lam, const double* Wt, const double* Vt, int64_t d) {
+    __shared__ double scratch[4];
+    const int64_t j = blockIdx.x;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < d; i += EB) s += Wt[j * d + i] * Vt[j * d + i];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) lam[j] = s;
+}
+
+// rank_j = #{k : lam_k < lam_j or (lam_k == lam_j and k < j)}; evals[rank_j] = lam_j
+__global__ void rank_kernel(int* rank, double* evals, const double* lam, int64_t d) {
+    const int64_t j = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (j >= d) return;
+    const double x = lam[j];
+    int r = 0;
+    for (int64_t k = 0; k < d; ++k) {
+        const double y = lam[k];
+        r += (y < x || (y == x && k < j)) ? 1 : 0;
+    }
+    rank[j] = r;
+    evals[r] = x;
+}
+
+// evecs[i, rank_j] = Vt[j, i]  (eigenvectors in columns, ascending eigenvalue order)
+__global__ void scatter_vectors_kernel(double* evecs, const double* Vt, const int* rank, int64_t d) {
+    __shared__ double tile[32][33];
+    const int64_t j0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t j = j0 + r, i = i0 + tx;
+        tile[r][tx] = (j < d && i < d) ? Vt[j * d + i] : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t i = i0 + r, j = j0 + tx;
+        if (i < d && j < d) evecs[i * d + rank[j]] = tile[tx][r];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t kf_eigh_workspace_bytes(int64_t d) {
+    // Wt, Vt (d*d doubles each), lam (d doubles), rank (d ints), flag; padded
+    return static_cast<int64_t>(sizeof(double)) * (2 * d * d + d) + static_cast<int64_t>(sizeof(int)) * (d + 16) + 256;
+}
+
+int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double* evals, double* evecs, void* workspace,
+                int64_t workspace_bytes, int max_sweeps, int* sweeps_done, void* stream) {
+    if (!cov || !evals || !evecs || !workspace || d <= 0 || !(count > 0.0)) return KF_ERR_INVALID_ARGUMENT;
+    if (cov_dtype != KF_F32 && cov_dtype != KF_F64) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (workspace_bytes < kf_eigh_workspace_bytes(d)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (d >= (1 << 24)) return KF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (max_sweeps <= 0) max_sweeps = 30;
+    double* Wt = reinterpret_cast<double*>(workspace);
+    double* Vt = Wt + d * d;
+    double* lam = Vt + d * d;
+    int* rank = reinterpret_cast<int*>(lam + d);
+    int* flag = rank + d + (d & 1);  // keep 8-byte alignment irrelevant for int; distinct word
+
+    const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((d * d + 255) / 256, 4096)));
+    hipLaunchKernelGGL(eigh_init_kernel, dim3(g), dim3(256), 0, st, Wt, Vt, cov, cov_dtype == KF_F64 ? 1 : 0, count, d);
+
+    const int npl = static_cast<int>(d + (d & 1));
+    const int pairs = npl / 2, rounds = npl - 1;
+    const double tol = 4.0 * 2.220446049250313e-16 * sqrt(static_cast<double>(d));
+    int sweeps = 0, status = KF_ERR_NOT_CONVERGED;
+    if (d == 1) { status = KF_OK; }
+    for (; d > 1 && sweeps < max_sweeps; ++sweeps) {
+        if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        for (int r = 0; r < rounds; ++r)
+            hipLaunchKernelGGL(jacobi_round_kernel, dim3(pairs), dim3(EB), 0, st, Wt, Vt, d, npl, r, tol, flag);
+        int host_flag = 1;
+        if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        if (host_flag == 0) { status = KF_OK; ++sweeps; break; }
+    }
+    if (sweeps_done) *sweeps_done = sweeps;
+    hipLaunchKernelGGL(rayleigh_kernel, dim3(static_cast<unsigned>(d)), dim3(EB), 0, st, lam, Wt, Vt, d);
+    hipLaunchKernelGGL(rank_kernel, dim3(static_cast<unsigned>((d + 255) / 256)), dim3(256), 0, st, rank, evals, lam, d);
+    const unsigned t = static_cast<unsigned>((d + 31) / 32);
+    hipLaunchKernelGGL(scatter_vectors_kernel, dim3(t, t), dim3(32, 8), 0, st, evecs, Vt, rank, d);
+    if (hipGetLastError() != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    return status;
+}
+
+}  // extern "C"

@@ -1,0 +1,648 @@
+// kf_kernels.hip -- gfx950 kernels and C ABI of the EK-FAC hot path (see include/kronfluence_hip.h).
+//
+// Dense contractions (covariance SYRK, eigenbasis rotations, Lambda, preconditioner, per-sample
+// gradient, pairwise-score GEMM) run on the fp32 MFMA tile engine of kf_engine.h; elementwise and
+// reduction stages (im2col, 1/(Lambda/n+damping), casts) are coalesced streaming kernels.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/kronfluence_hip.h"
+#include "kf_engine.h"
+
+using namespace kf;
+
+namespace {
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_LAUNCH_FAILED; }
+inline bool float_dtype(int d) { return d == KF_F32 || d == KF_BF16 || d == KF_F16 || d == KF_F64; }
+inline int64_t dtype_size(int d) {
+    switch (d) {
+        case KF_F32: case KF_I32: return 4;
+        case KF_BF16: case KF_F16: return 2;
+        case KF_F64: case KF_I64: return 8;
+        default: return 1;
+    }
+}
+
+__device__ __forceinline__ void store_as(void* p, int dtype, int64_t idx, float v) {
+    switch (dtype) {
+        case F32: reinterpret_cast<float*>(p)[idx] = v; break;
+        case BF16: {  // round-to-nearest-even
+            uint32_t u = __float_as_uint(v);
+            if ((u & 0x7fffffffu) > 0x7f800000u) { u |= 0x00400000u; }
+            else { u += 0x7fffu + ((u >> 16) & 1u); }
+            reinterpret_cast<uint16_t*>(p)[idx] = static_cast<uint16_t>(u >> 16);
+            break;
+        }
+        case F16: reinterpret_cast<_Float16*>(p)[idx] = static_cast<_Float16>(v); break;
+        default: reinterpret_cast<double*>(p)[idx] = static_cast<double>(v); break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic strided batched GEMM
+// ------------------------------------------------------------------------------------------------
+struct GemmArgs {
+    float* C;
+    int64_t ldc, c_batch_stride;
+    kf_view A, B;
+    int M, N, K;        // extents including the virtual ones row / k
+    int ksplit, kchunk;
+    float alpha, beta;
+    const float* mul;
+    int64_t ld_mul;
+    int atomic;         // accumulate with atomicAdd (split-K or batch-summing); beta pre-applied
+};
+
+__device__ __forceinline__ StridedLoader make_loader(const kf_view& v, int64_t z, int row0, int contig_k) {
+    StridedLoader l;
+    l.dtype = v.dtype;
+    l.row_stride = v.row_stride;
+    l.k_stride = v.k_stride;
+    const int64_t off = z * v.batch_stride + static_cast<int64_t>(row0) * v.row_stride;
+    l.p = reinterpret_cast<const char*>(v.p) + off * (v.dtype == F32 ? 4 : (v.dtype == F64 ? 8 : 2));
+    l.rows = static_cast<int>(v.rows) - row0;  // >= 0: row0 <= rows whenever a tile exists
+    l.depth = static_cast<int>(v.depth);
+    l.ones_row = v.ones_row;
+    l.ones_k = v.ones_k;
+    l.square = v.square;
+    l.contig_k = contig_k;
+    return l;
+}
+
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs a) {
+    __shared__ float smem[SMEM_FLOATS];
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int z = blockIdx.z / a.ksplit, ks = blockIdx.z % a.ksplit;
+    const int k_begin = ks * a.kchunk;
+    const int k_end = min(a.K, k_begin + a.kchunk);
+    StridedLoader la = make_loader(a.A, z, m0, a.A.k_stride == 1);
+    StridedLoader lb = make_loader(a.B, z, n0, a.B.k_stride == 1);
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    mainloop(la, lb, k_begin, k_end, acc, smem);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    float* C = a.C + static_cast<int64_t>(z) * a.c_batch_stride;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + acc_row(wm, ti, r, lane), n = n0 + acc_col(wn, tj, lane);
+                if (m < a.M && n < a.N) {
+                    float v = a.alpha * acc[ti][tj][r];
+                    if (a.mul) v *= a.mul[static_cast<int64_t>(m) * a.ld_mul + n];
+                    float* dst = C + static_cast<int64_t>(m) * a.ldc + n;
+                    if (a.atomic) atomicAdd(dst, v);
+                    else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
+                }
+            }
+}
+
+__global__ void scale_matrix_kernel(float* C, int64_t ldc, int64_t batch_stride, int M, int N, float beta) {
+    const int64_t total = static_cast<int64_t>(M) * N;
+    float* base = C + blockIdx.y * batch_stride;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < total;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        float* p = base + (i / N) * ldc + (i % N);
+        *p = beta == 0.0f ? 0.0f : beta * *p;
+    }
+}
+
+int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
+                int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, hipStream_t st) {
+    if (!C || !A.p || !B.p || batch < 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!float_dtype(A.dtype) || !float_dtype(B.dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (A.depth + A.ones_k != B.depth + B.ones_k) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t M = A.rows + A.ones_row, N = B.rows + B.ones_row, K = A.depth + A.ones_k;
+    if (M <= 0 || N <= 0 || batch == 0) return KF_OK;
+    if (M >= (1LL << 30) || N >= (1LL << 30) || K >= (1LL << 30)) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
+    const bool batch_sum = (c_batch_stride == 0 && batch > 1);
+    // split-K so that small-output / deep-K contractions still fill 256 CUs
+    int64_t ksplit = 1;
+    const int64_t ksteps = cdiv(K, BK);
+    const int64_t want = 1024;
+    if (tiles * batch < want && ksteps >= 8) {
+        ksplit = std::min<int64_t>(cdiv(want, tiles * batch), ksteps / 4);
+        if (ksplit < 1) ksplit = 1;
+    }
+    int64_t kchunk = cdiv(ksteps, ksplit) * BK;
+    ksplit = cdiv(K, kchunk);
+    if (K == 0) { ksplit = 1; kchunk = BK; }
+    const bool atomic = batch_sum || ksplit > 1;
+    if (batch * ksplit > 65535) return KF_ERR_INVALID_ARGUMENT;
+    if (atomic && beta != 1.0f) {
+        dim3 g(static_cast<unsigned>(std::min<int64_t>(cdiv(M * N, 256), 4096)), batch_sum ? 1 : static_cast<unsigned>(batch));
+        hipLaunchKernelGGL(scale_matrix_kernel, g, dim3(256), 0, st, C, ldc, c_batch_stride, static_cast<int>(M), static_cast<int>(N), beta);
+    }
+    GemmArgs a;
+    a.C = C; a.ldc = ldc; a.c_batch_stride = c_batch_stride; a.A = A; a.B = B;
+    a.M = static_cast<int>(M); a.N = static_cast<int>(N); a.K = static_cast<int>(K);
+    a.ksplit = static_cast<int>(ksplit); a.kchunk = static_cast<int>(kchunk);
+    a.alpha = alpha; a.beta = beta; a.mul = mul; a.ld_mul = ld_mul; a.atomic = atomic ? 1 : 0;
+    dim3 grid(static_cast<unsigned>(cdiv(N, BN)), static_cast<unsigned>(cdiv(M, BM)), static_cast<unsigned>(batch * ksplit));
+    hipLaunchKernelGGL(gemm_kernel, grid, dim3(NTHREADS), 0, st, a);
+    return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 1: covariance SYRK with fused flatten / mask / ones column
+// ------------------------------------------------------------------------------------------------
+struct SyrkLoader {
+    const void* p; int dtype;
+    int64_t n_rows, rows_inner, outer_stride, row_stride, col_stride;
+    const void* mask; int mask_dtype;
+    int d_in, d, col0;   // features [col0, col0+128) of X'
+    int contig_k;
+    // "row" r = feature index (tile-relative), k = sample row
+    __device__ __forceinline__ float get(int r, int k) const {
+        const int c = col0 + r;
+        if (c >= d || k >= n_rows) return 0.0f;
+        const float mk = mask ? load_f32(mask, mask_dtype, k) : 1.0f;
+        if (c == d_in) return mk;  // ones column (only reachable when d == d_in + 1)
+        int64_t off;
+        if (rows_inner >= n_rows) off = static_cast<int64_t>(k) * row_stride;
+        else off = (k / rows_inner) * outer_stride + (k % rows_inner) * row_stride;
+        return mk * load_f32(p, dtype, off + static_cast<int64_t>(c) * col_stride);
+    }
+};
+
+struct SyrkArgs {
+    float* C; int64_t ldc;
+    SyrkLoader base;
+    int tiles, ksplit; int64_t kchunk;
+    float alpha; int atomic;
+};
+
+__global__ __launch_bounds__(NTHREADS) void syrk_kernel(SyrkArgs a) {
+    __shared__ float smem[SMEM_FLOATS];
+    // upper-triangular tile pair (ti <= tj) from the linear block index
+    int t = blockIdx.x, ti = 0;
+    while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
+    const int tj = ti + t;
+    SyrkLoader la = a.base, lb = a.base;
+    la.col0 = ti * BM;
+    lb.col0 = tj * BN;
+    const int64_t k_begin = static_cast<int64_t>(blockIdx.y) * a.kchunk;
+    const int64_t k_end = min(a.base.n_rows, k_begin + a.kchunk);
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    mainloop(la, lb, static_cast<int>(k_begin), static_cast<int>(k_end), acc, smem);
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const int d = a.base.d;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = ti * BM + acc_row(wm, i, r, lane), n = tj * BN + acc_col(wn, j, lane);
+                if (m < d && n < d) {
+                    const float v = a.alpha * acc[i][j][r];
+                    float* up = a.C + static_cast<int64_t>(m) * a.ldc + n;
+                    float* lo = a.C + static_cast<int64_t>(n) * a.ldc + m;
+                    if (a.atomic) { atomicAdd(up, v); if (ti != tj) atomicAdd(lo, v); }
+                    else { *up += v; if (ti != tj) *lo += v; }
+                }
+            }
+}
+
+__global__ void count_kernel(int64_t* count, const void* mask, int mask_dtype, int64_t n) {
+    // one block: count += sum(mask)  (exact in int64 for 0/1 masks)
+    __shared__ long long part[256];
+    long long s = 0;
+    for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        switch (mask_dtype) {
+            case I64: s += reinterpret_cast<const int64_t*>(mask)[i]; break;
+            case I32: s += reinterpret_cast<const int32_t*>(mask)[i]; break;
+            case U8: s += reinterpret_cast<const uint8_t*>(mask)[i]; break;
+            default: s += static_cast<long long>(llrintf(load_f32(mask, mask_dtype, i))); break;
+        }
+    }
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *count += part[0];
+}
+
+__global__ void add_count_kernel(int64_t* count, int64_t n) { *count += n; }
+
+// ------------------------------------------------------------------------------------------------
+// im2col (conv2d.py:15-64): out[b, p, i] with i = (c, ky, kx); group mean folded in
+// ------------------------------------------------------------------------------------------------
+struct Im2colArgs {
+    void* out; int out_dtype; const void* x; int in_dtype;
+    int64_t b, C, H, W; int k1, k2, s1, s2, p1, p2, d1, d2, groups, append_ones;
+    int64_t O1, O2, Cg, Ip;
+};
+
+__global__ void im2col_kernel(Im2colArgs a) {
+    const int64_t P = a.O1 * a.O2;
+    const int64_t total = a.b * P * a.Ip;
+    const float inv_g = 1.0f / static_cast<float>(a.groups);
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t i = e % a.Ip, bp = e / a.Ip, p = bp % P, n = bp / P;
+        float v;
+        if (a.append_ones && i == a.Ip - 1) {
+            v = 1.0f;
+        } else {
+            const int64_t kx = i % a.k2, ky = (i / a.k2) % a.k1, c = i / (a.k1 * a.k2);
+            const int64_t oy = p / a.O2, ox = p % a.O2;
+            const int64_t iy = oy * a.s1 - a.p1 + ky * a.d1, ix = ox * a.s2 - a.p2 + kx * a.d2;
+            v = 0.0f;
+            if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) {
+                for (int g = 0; g < a.groups; ++g)
+                    v += load_f32(a.x, a.in_dtype, ((n * a.C + g * a.Cg + c) * a.H + iy) * a.W + ix);
+                if (a.groups > 1) v *= inv_g;
+            }
+        }
+        store_as(a.out, a.out_dtype, e, v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 2: Lambda for R > 1 -- per sample z: M_z = Gt_z^T At_z (K = R), Lambda += M_z^2
+// ------------------------------------------------------------------------------------------------
+struct LambdaArgs {
+    float* L; int64_t ldl; const float* Gt; const float* At;
+    int b, R, O, Ip, zchunk; float scale2;
+};
+
+__global__ __launch_bounds__(NTHREADS) void lambda_kernel(LambdaArgs a) {
+    __shared__ float smem[SMEM_FLOATS];
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
+    const int z_begin = blockIdx.z * a.zchunk, z_end = min(a.b, z_begin + a.zchunk);
+    f32x16 sq[2][2];
+    zero_acc(sq);
+    for (int z = z_begin; z < z_end; ++z) {
+        StridedLoader la, lb;
+        la.p = a.Gt + (static_cast<int64_t>(z) * a.R) * a.O + m0; la.dtype = F32;
+        la.row_stride = 1; la.k_stride = a.O; la.rows = max(a.O - m0, 0); la.depth = a.R;
+        la.ones_row = la.ones_k = la.square = 0; la.contig_k = 0;
+        lb = la;
+        lb.p = a.At + (static_cast<int64_t>(z) * a.R) * a.Ip + n0; lb.k_stride = a.Ip; lb.rows = max(a.Ip - n0, 0);
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        mainloop(la, lb, 0, a.R, acc, smem);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sq[i][j][r] += acc[i][j][r] * acc[i][j][r];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    const bool atomic = gridDim.z > 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + acc_row(wm, i, r, lane), n = n0 + acc_col(wn, j, lane);
+                if (m < a.O && n < a.Ip) {
+                    float* dst = a.L + static_cast<int64_t>(m) * a.ldl + n;
+                    const float v = a.scale2 * sq[i][j][r];
+                    if (atomic) atomicAdd(dst, v); else *dst += v;
+                }
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 3a: inverse Lambda in fp64
+// ------------------------------------------------------------------------------------------------
+__global__ void sum_f64_kernel(double* out, const float* x, int64_t n) {
+    __shared__ double part[256];
+    double s = 0.0;
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        s += static_cast<double>(x[i]);
+    part[threadIdx.x] = s;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) atomicAdd(out, part[0]);
+}
+
+__global__ void inv_lambda_kernel(float* out, const float* L, int64_t n, double n_lambda, double damping,
+                                  const double* sum) {
+    double damp = damping;
+    if (damping < 0.0) damp = 0.1 * (*sum / n_lambda) / static_cast<double>(n);
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        out[i] = static_cast<float>(1.0 / (static_cast<double>(L[i]) / n_lambda + damp));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stage 3b: pairwise score, R == 1:  scores[q,n] += scale * sum_o G[n,o] * (sum_i P[q,o,i] A'[n,i])
+// One block = (q, 128 rows of o) x 128 train samples; K loop over i on the MFMA engine, then the
+// G-weighted reduction over the tile's o rows in registers / LDS, one atomicAdd per (q, n).
+// ------------------------------------------------------------------------------------------------
+struct ScoreArgs {
+    float* scores; int64_t ld_scores; const float* P; const void* G; const void* A; int in_dtype;
+    int Q, b, O, I, Ip, append_ones, tiles_per_q; float scale;
+};
+
+__global__ __launch_bounds__(NTHREADS) void score_r1_kernel(ScoreArgs a) {
+    __shared__ float smem[SMEM_FLOATS];
+    const int n0 = blockIdx.x * BN;
+    const int q = blockIdx.y / a.tiles_per_q, o0 = (blockIdx.y % a.tiles_per_q) * BM;
+    StridedLoader la, lb;
+    la.p = a.P + (static_cast<int64_t>(q) * a.O + o0) * a.Ip; la.dtype = F32;
+    la.row_stride = a.Ip; la.k_stride = 1; la.rows = a.O - o0; la.depth = a.Ip;
+    la.ones_row = la.ones_k = la.square = 0; la.contig_k = 1;
+    lb.p = reinterpret_cast<const char*>(a.A) + static_cast<int64_t>(n0) * a.I * (a.in_dtype == F32 ? 4 : 2);
+    lb.dtype = a.in_dtype; lb.row_stride = a.I; lb.k_stride = 1; lb.rows = max(a.b - n0, 0); lb.depth = a.I;
+    lb.ones_row = 0; lb.ones_k = a.append_ones; lb.square = 0; lb.contig_k = 1;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    mainloop(la, lb, 0, a.Ip, acc, smem);
+
+    // epilogue: this lane owns column n (two of them, tj = 0,1) and 32 rows per column
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
+    float colsum[2] = {0.0f, 0.0f};
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) {
+        const int n = n0 + acc_col(wn, tj, lane);
+        if (n < a.b) {
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int o = o0 + acc_row(wm, ti, r, lane);
+                    if (o < a.O)
+                        colsum[tj] += acc[ti][tj][r] * load_f32(a.G, a.in_dtype, static_cast<int64_t>(n) * a.O + o);
+                }
+        }
+    }
+    // lanes l and l+32 hold the two row halves of the same column
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj) colsum[tj] += __shfl_xor(colsum[tj], 32);
+    // combine the two waves stacked along m (wm = 0,1) through LDS, then one atomic per column
+    __syncthreads();  // smem no longer read by the mainloop
+    if (wm == 1 && lane < 32) { smem[wn * 64 + lane] = colsum[0]; smem[wn * 64 + 32 + lane] = colsum[1]; }
+    __syncthreads();
+    if (wm == 0 && lane < 32) {
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+            const int n = n0 + wn * 64 + tj * 32 + lane;
+            if (n < a.b)
+                atomicAdd(a.scores + static_cast<int64_t>(q) * a.ld_scores + n,
+                          a.scale * (colsum[tj] + smem[wn * 64 + tj * 32 + lane]));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cast
+// ------------------------------------------------------------------------------------------------
+__global__ void cast_kernel(void* dst, int dd, const void* src, int sd, int64_t n) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; i < n;
+         i += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        if (sd == F64 && dd == F64) reinterpret_cast<double*>(dst)[i] = reinterpret_cast<const double*>(src)[i];
+        else if (sd == F64) store_as(dst, dd, i, static_cast<float>(reinterpret_cast<const double*>(src)[i]));
+        else if (dd == F64) reinterpret_cast<double*>(dst)[i] = static_cast<double>(load_f32(src, sd, i));
+        else store_as(dst, dd, i, load_f32(src, sd, i));
+    }
+}
+
+inline unsigned stream_grid(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048))); }
+
+kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, int64_t rows, int64_t depth,
+                  int ones_row = 0, int ones_k = 0, int square = 0) {
+    kf_view v;
+    v.p = p; v.dtype = dtype; v.batch_stride = bs; v.row_stride = rs; v.k_stride = ks;
+    v.rows = rows; v.depth = depth; v.ones_row = ones_row; v.ones_k = ones_k; v.square = square;
+    return v;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int kf_abi_version(void) { return 1; }
+
+const char* kf_status_string(int s) {
+    switch (s) {
+        case KF_OK: return "ok";
+        case KF_ERR_INVALID_ARGUMENT: return "invalid argument";
+        case KF_ERR_UNSUPPORTED_DTYPE: return "unsupported dtype";
+        case KF_ERR_LAUNCH_FAILED: return "kernel launch failed";
+        case KF_ERR_WORKSPACE_TOO_SMALL: return "workspace too small";
+        case KF_ERR_NOT_CONVERGED: return "eigensolver did not converge";
+        case KF_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+int kf_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return KF_ERR_NO_DEVICE; }
+    return n;
+}
+
+int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_rows, int64_t d_in,
+                  int64_t rows_inner, int64_t outer_stride, int64_t row_stride, int64_t col_stride,
+                  const void* mask, int mask_dtype, int append_ones, float alpha, int64_t* count, void* stream) {
+    if (!C || !X || n_rows < 0 || d_in <= 0 || rows_inner <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!float_dtype(in_dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (n_rows >= (1LL << 31) - BK) return KF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    const int64_t d = d_in + (append_ones ? 1 : 0);
+    if (count) {
+        if (mask) hipLaunchKernelGGL(count_kernel, dim3(1), dim3(256), 0, st, count, mask, mask_dtype, n_rows);
+        else hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, st, count, n_rows);
+    }
+    if (n_rows == 0) return launch_status();
+    SyrkArgs a;
+    a.C = C; a.ldc = ldc;
+    a.base.p = X; a.base.dtype = in_dtype; a.base.n_rows = n_rows; a.base.rows_inner = rows_inner;
+    a.base.outer_stride = outer_stride; a.base.row_stride = row_stride; a.base.col_stride = col_stride;
+    a.base.mask = mask; a.base.mask_dtype = mask_dtype; a.base.d_in = static_cast<int>(d_in);
+    a.base.d = static_cast<int>(d); a.base.col0 = 0;
+    a.base.contig_k = (col_stride != 1);  // lanes walk the contiguous memory direction
+    a.tiles = static_cast<int>(cdiv(d, BM));
+    const int64_t pairs = static_cast<int64_t>(a.tiles) * (a.tiles + 1) / 2;
+    const int64_t ksteps = cdiv(n_rows, BK);
+    int64_t ksplit = 1;
+    if (pairs < 1024 && ksteps >= 8) ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, pairs), ksteps / 4));
+    a.kchunk = cdiv(ksteps, ksplit) * BK;
+    ksplit = cdiv(n_rows, a.kchunk);
+    a.ksplit = static_cast<int>(ksplit);
+    a.alpha = alpha; a.atomic = ksplit > 1;
+    if (ksplit > 65535) return KF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(syrk_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(ksplit)), dim3(NTHREADS), 0, st, a);
+    return launch_status();
+}
+
+int kf_im2col(void* out, int out_dtype, const void* x, int in_dtype, int64_t b, int64_t C, int64_t H, int64_t W,
+              int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2, int groups, int append_ones,
+              void* stream) {
+    if (!out || !x || b < 0 || C <= 0 || groups <= 0 || C % groups != 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!float_dtype(in_dtype) || !float_dtype(out_dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    Im2colArgs a;
+    a.out = out; a.out_dtype = out_dtype; a.x = x; a.in_dtype = in_dtype; a.b = b; a.C = C; a.H = H; a.W = W;
+    a.k1 = k1; a.k2 = k2; a.s1 = s1; a.s2 = s2; a.p1 = p1; a.p2 = p2; a.d1 = d1; a.d2 = d2;
+    a.groups = groups; a.append_ones = append_ones ? 1 : 0;
+    a.O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1;
+    a.O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
+    if (a.O1 <= 0 || a.O2 <= 0) return KF_ERR_INVALID_ARGUMENT;
+    a.Cg = C / groups;
+    a.Ip = a.Cg * k1 * k2 + a.append_ones;
+    const int64_t total = b * a.O1 * a.O2 * a.Ip;
+    if (total == 0) return KF_OK;
+    hipLaunchKernelGGL(im2col_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), a);
+    return launch_status();
+}
+
+int kf_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view* A, const kf_view* B, int64_t batch,
+            float alpha, float beta, const float* mul, int64_t ld_mul, void* stream) {
+    if (!A || !B) return KF_ERR_INVALID_ARGUMENT;
+    return launch_gemm(C, ldc, c_batch_stride, *A, *B, batch, alpha, beta, mul, ld_mul, as_stream(stream));
+}
+
+int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const float* Gt, const float* At, int64_t b, int64_t R,
+                    int64_t O, int64_t Ip, float scale, void* stream) {
+    if (!Lambda || !Gt || !At || b < 0 || R <= 0 || O <= 0 || Ip <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (b == 0) return KF_OK;
+    hipStream_t st = as_stream(stream);
+    if (R == 1) {
+        // Lambda += scale^2 * (Gt o Gt)^T (At o At): one GEMM over the batch dimension
+        kf_view A = make_view(Gt, KF_F32, 0, 1, O, O, b, 0, 0, 1);
+        kf_view B = make_view(At, KF_F32, 0, 1, Ip, Ip, b, 0, 0, 1);
+        return launch_gemm(Lambda, ld_lambda, 0, A, B, 1, scale * scale, 1.0f, nullptr, 0, st);
+    }
+    LambdaArgs a;
+    a.L = Lambda; a.ldl = ld_lambda; a.Gt = Gt; a.At = At;
+    a.b = static_cast<int>(b); a.R = static_cast<int>(R); a.O = static_cast<int>(O); a.Ip = static_cast<int>(Ip);
+    a.scale2 = scale * scale;
+    const int64_t tiles = cdiv(O, BM) * cdiv(Ip, BN);
+    int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, tiles)));
+    a.zchunk = static_cast<int>(cdiv(b, zsplit));
+    zsplit = cdiv(b, a.zchunk);
+    if (zsplit > 65535) return KF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(lambda_kernel, dim3(static_cast<unsigned>(cdiv(Ip, BN)), static_cast<unsigned>(cdiv(O, BM)), static_cast<unsigned>(zsplit)),
+                       dim3(NTHREADS), 0, st, a);
+    return launch_status();
+}
+
+int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambda, double damping, void* workspace,
+                  void* stream) {
+    if (!out || !Lambda || numel < 0 || n_lambda <= 0.0 || !workspace) return KF_ERR_INVALID_ARGUMENT;
+    if (numel == 0) return KF_OK;
+    hipStream_t st = as_stream(stream);
+    double* sum = reinterpret_cast<double*>(workspace);
+    if (damping < 0.0) {
+        if (hipMemsetAsync(sum, 0, sizeof(double), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        hipLaunchKernelGGL(sum_f64_kernel, dim3(stream_grid(numel)), dim3(256), 0, st, sum, Lambda, numel);
+    }
+    hipLaunchKernelGGL(inv_lambda_kernel, dim3(stream_grid(numel)), dim3(256), 0, st, out, Lambda, numel, n_lambda, damping, sum);
+    return launch_status();
+}
+
+int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip) {
+    return static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ip + q * O * Ip);
+}
+
+int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O, int64_t I,
+                    int append_ones, const float* Qg, const float* Qa, const float* inv_lambda, float scale,
+                    void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!P || !G || !A || !Qg || !Qa || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!float_dtype(in_dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    const int64_t Ip = I + (append_ones ? 1 : 0);
+    if (!workspace || workspace_bytes < kf_precondition_workspace_bytes(q, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (q == 0) return KF_OK;
+    hipStream_t st = as_stream(stream);
+    float* Gt = reinterpret_cast<float*>(workspace);
+    float* At = Gt + q * R * O;
+    float* T = At + q * R * Ip;
+    int rc;
+    // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']
+    rc = launch_gemm(Gt, O, 0, make_view(G, in_dtype, 0, O, 1, q * R, O), make_view(Qg, KF_F32, 0, 1, O, O, O), 1, 1.0f, 0.0f, nullptr, 0, st);
+    if (rc != KF_OK) return rc;
+    // At[(q r), i'] = sum_i [A,1][(q r), i] Qa[i, i']
+    rc = launch_gemm(At, Ip, 0, make_view(A, in_dtype, 0, I, 1, q * R, I, 0, append_ones ? 1 : 0), make_view(Qa, KF_F32, 0, 1, Ip, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
+    if (rc != KF_OK) return rc;
+    // rot[q][o,i] = (sum_r Gt[q,r,o] At[q,r,i]) * inv_lambda[o,i]   (stored in the caller's P buffer)
+    rc = launch_gemm(P, Ip, O * Ip, make_view(Gt, KF_F32, R * O, 1, O, O, R), make_view(At, KF_F32, R * Ip, 1, Ip, Ip, R), q, 1.0f, 0.0f, inv_lambda, Ip, st);
+    if (rc != KF_OK) return rc;
+    // T[(q o), j] = sum_i rot[(q o), i] Qa[j, i]
+    rc = launch_gemm(T, Ip, 0, make_view(P, KF_F32, 0, Ip, 1, q * O, Ip), make_view(Qa, KF_F32, 0, Ip, 1, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
+    if (rc != KF_OK) return rc;
+    // P[q][m, n] = scale * sum_o Qg[m, o] T[q][o, n]
+    rc = launch_gemm(P, Ip, O * Ip, make_view(Qg, KF_F32, 0, O, 1, O, O), make_view(T, KF_F32, O * Ip, 1, Ip, Ip, O), q, scale, 0.0f, nullptr, 0, st);
+    return rc;
+}
+
+int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip) {
+    if (R <= 1) return 16;
+    return static_cast<int64_t>(sizeof(float)) * b * O * Ip;
+}
+
+int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t Q, const void* G, const void* A,
+                      int in_dtype, int64_t b, int64_t R, int64_t O, int64_t I, int append_ones, float scale,
+                      void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!scores || !P || !G || !A || Q < 0 || b < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (in_dtype != KF_F32 && in_dtype != KF_BF16 && in_dtype != KF_F16) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (Q == 0 || b == 0) return KF_OK;
+    hipStream_t st = as_stream(stream);
+    const int64_t Ip = I + (append_ones ? 1 : 0);
+    if (R == 1) {
+        ScoreArgs a;
+        a.scores = scores; a.ld_scores = ld_scores; a.P = P; a.G = G; a.A = A; a.in_dtype = in_dtype;
+        a.Q = static_cast<int>(Q); a.b = static_cast<int>(b); a.O = static_cast<int>(O); a.I = static_cast<int>(I);
+        a.Ip = static_cast<int>(Ip); a.append_ones = append_ones ? 1 : 0;
+        a.tiles_per_q = static_cast<int>(cdiv(O, BM)); a.scale = scale;
+        const int64_t gy = Q * a.tiles_per_q;
+        if (gy > 65535) {
+            // y-dimension limit: fall through in slabs of queries
+            const int64_t qs = 65535 / a.tiles_per_q;
+            for (int64_t q0 = 0; q0 < Q; q0 += qs) {
+                ScoreArgs s = a;
+                s.Q = static_cast<int>(std::min<int64_t>(qs, Q - q0));
+                s.P = P + q0 * O * Ip; s.scores = scores + q0 * ld_scores;
+                hipLaunchKernelGGL(score_r1_kernel, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(s.Q * a.tiles_per_q)), dim3(NTHREADS), 0, st, s);
+            }
+            return launch_status();
+        }
+        hipLaunchKernelGGL(score_r1_kernel, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(gy)), dim3(NTHREADS), 0, st, a);
+        return launch_status();
+    }
+    if (!workspace || workspace_bytes < kf_pairwise_workspace_bytes(b, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    float* psg = reinterpret_cast<float*>(workspace);
+    // psg[n][o, i] = sum_r G[n,r,o] A'[n,r,i]
+    int rc = launch_gemm(psg, Ip, O * Ip, make_view(G, in_dtype, R * O, 1, O, O, R),
+                         make_view(A, in_dtype, R * I, 1, I, I, R, append_ones ? 1 : 0, 0), b, 1.0f, 0.0f, nullptr, 0, st);
+    if (rc != KF_OK) return rc;
+    // scores[q, n] += scale * sum_d P[q, d] psg[n, d]
+    return launch_gemm(scores, ld_scores, 0, make_view(P, KF_F32, 0, O * Ip, 1, Q, O * Ip),
+                       make_view(psg, KF_F32, 0, O * Ip, 1, b, O * Ip), 1, scale, 1.0f, nullptr, 0, st);
+}
+
+int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream) {
+    if (!dst || !src || numel < 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!float_dtype(dst_dtype) || !float_dtype(src_dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (numel == 0) return KF_OK;
+    hipLaunchKernelGGL(cast_kernel, dim3(stream_grid(numel)), dim3(256), 0, as_stream(stream), dst, dst_dtype, src, src_dtype, numel);
+    return launch_status();
+}
+
+}  // extern "C"

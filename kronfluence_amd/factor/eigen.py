@@ -1,0 +1,161 @@
+"""Stage 2: eigendecomposition (reference ``factor/eigen.py:140-224``) and Lambda fitting
+(``:345-462``), plus their safetensors layout (``:46-91, 227-290``)."""
+
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from safetensors.torch import load_file, save_file
+from torch import autocast, nn
+from torch.utils import data
+
+from kronfluence_amd import ops
+from kronfluence_amd.arguments import FactorArguments
+from kronfluence_amd.factor.covariance import _loss_scale
+from kronfluence_amd.module.tracked_module import ModuleMode
+from kronfluence_amd.module.utils import (
+    finalize_iteration, get_tracked_module_names, load_factors, set_factors, set_gradient_scale, set_mode,
+    synchronize_factors, update_factor_args,
+)
+from kronfluence_amd.task import Task
+from kronfluence_amd.utils.constants import (
+    ACTIVATION_COVARIANCE_MATRIX_NAME, ACTIVATION_EIGENVALUES_NAME, ACTIVATION_EIGENVECTORS_NAME,
+    EIGENDECOMPOSITION_FACTOR_NAMES, FACTOR_TYPE, GRADIENT_COVARIANCE_MATRIX_NAME, GRADIENT_EIGENVALUES_NAME,
+    GRADIENT_EIGENVECTORS_NAME, LAMBDA_FACTOR_NAMES, LAMBDA_MATRIX_NAME, NUM_ACTIVATION_COVARIANCE_PROCESSED,
+    NUM_GRADIENT_COVARIANCE_PROCESSED,
+)
+from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
+from kronfluence_amd.utils.state import State, no_sync
+
+
+def eigendecomposition_save_path(output_dir: Path, factor_name: str) -> Path:
+    assert factor_name in EIGENDECOMPOSITION_FACTOR_NAMES
+    return output_dir / f"{factor_name}.safetensors"
+
+
+def save_eigendecomposition(output_dir: Path, factors: FACTOR_TYPE, metadata: Optional[Dict[str, str]] = None) -> None:
+    assert set(factors.keys()) == set(EIGENDECOMPOSITION_FACTOR_NAMES)
+    for name in factors:
+        save_file(tensors={k: v.contiguous() for k, v in factors[name].items()},
+                  filename=str(eigendecomposition_save_path(output_dir, name)), metadata=metadata)
+
+
+def load_eigendecomposition(output_dir: Path) -> FACTOR_TYPE:
+    return {name: load_file(filename=str(eigendecomposition_save_path(output_dir, name)))
+            for name in EIGENDECOMPOSITION_FACTOR_NAMES}
+
+
+def eigendecomposition_exist(output_dir: Path) -> bool:
+    return all(eigendecomposition_save_path(output_dir, name).exists() for name in EIGENDECOMPOSITION_FACTOR_NAMES)
+
+
+def lambda_matrices_save_path(output_dir: Path, factor_name: str, partition=None) -> Path:
+    assert factor_name in LAMBDA_FACTOR_NAMES
+    if partition is not None:
+        return output_dir / f"{factor_name}_data_partition{partition[0]}_module_partition{partition[1]}.safetensors"
+    return output_dir / f"{factor_name}.safetensors"
+
+
+def save_lambda_matrices(output_dir: Path, factors: FACTOR_TYPE, partition=None, metadata: Optional[Dict[str, str]] = None) -> None:
+    assert set(factors.keys()) == set(LAMBDA_FACTOR_NAMES)
+    for name in factors:
+        save_file(tensors={k: v.contiguous() for k, v in factors[name].items()},
+                  filename=str(lambda_matrices_save_path(output_dir, name, partition)), metadata=metadata)
+
+
+def load_lambda_matrices(output_dir: Path, partition=None) -> FACTOR_TYPE:
+    return {name: load_file(filename=str(lambda_matrices_save_path(output_dir, name, partition)))
+            for name in LAMBDA_FACTOR_NAMES}
+
+
+def lambda_matrices_exist(output_dir: Path, partition=None) -> bool:
+    return all(lambda_matrices_save_path(output_dir, name, partition).exists() for name in LAMBDA_FACTOR_NAMES)
+
+
+@torch.no_grad()
+def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module, state: State,
+                               factor_args: FactorArguments, disable_tqdm: bool = False) -> FACTOR_TYPE:
+    """``eigh(0.5 (C + C^T) / count)`` in fp64 for both factors of every tracked layer, on the MI355X
+    (``kf_eigh_f64``).  The 2L matrices are independent: with several ranks they are dealt
+    round-robin and the results are exchanged by broadcast, instead of rank 0 doing all of them while
+    the others wait at a barrier (reference ``factor_computer.py:449-470``).  Results are cast back
+    to the covariance dtype and returned on the CPU (``eigen.py:214-219``)."""
+    del disable_tqdm
+    out: FACTOR_TYPE = {name: {} for name in EIGENDECOMPOSITION_FACTOR_NAMES}
+    jobs = []
+    for module_name in get_tracked_module_names(model):
+        for cov_name, count_name, vec_name, val_name in (
+            (ACTIVATION_COVARIANCE_MATRIX_NAME, NUM_ACTIVATION_COVARIANCE_PROCESSED, ACTIVATION_EIGENVECTORS_NAME,
+             ACTIVATION_EIGENVALUES_NAME),
+            (GRADIENT_COVARIANCE_MATRIX_NAME, NUM_GRADIENT_COVARIANCE_PROCESSED, GRADIENT_EIGENVECTORS_NAME,
+             GRADIENT_EIGENVALUES_NAME),
+        ):
+            jobs.append((module_name, cov_name, count_name, vec_name, val_name))
+    world = state.num_processes if (state.use_distributed and dist.is_initialized()) else 1
+    for index, (module_name, cov_name, count_name, vec_name, val_name) in enumerate(jobs):
+        cov = covariance_factors[cov_name][module_name]
+        original_dtype = cov.dtype
+        owner = index % world
+        d = cov.shape[0]
+        if owner == state.process_index or world == 1:
+            work = cov.to(device=state.device)
+            if work.dtype not in (torch.float32, torch.float64):
+                work = work.to(torch.float32)
+            evals, evecs, _ = ops.eigh(work, float(covariance_factors[count_name][module_name].item()))
+        else:
+            evals = torch.empty(d, dtype=torch.float64, device=state.device)
+            evecs = torch.empty((d, d), dtype=torch.float64, device=state.device)
+        if world > 1:
+            dist.broadcast(evals, src=owner)
+            dist.broadcast(evecs, src=owner)
+        out[val_name][module_name] = evals.to(dtype=original_dtype, device="cpu").contiguous()
+        out[vec_name][module_name] = evecs.to(dtype=original_dtype, device="cpu").contiguous()
+    return out
+
+
+def fit_lambda_matrices_with_loader(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
+                                    factor_args: FactorArguments, eigen_factors: Optional[FACTOR_TYPE] = None,
+                                    tracked_module_names: Optional[List[str]] = None,
+                                    disable_tqdm: bool = False) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+    del disable_tqdm
+    update_factor_args(model, factor_args)
+    if tracked_module_names is None:
+        tracked_module_names = get_tracked_module_names(model)
+    set_mode(model, ModuleMode.LAMBDA, tracked_module_names, release_memory=True)
+    if eigen_factors is not None:
+        for name in eigen_factors:
+            set_factors(model, name, eigen_factors[name], clone=True)
+    num_data_processed = torch.zeros((1,), dtype=torch.int64)
+    enable_amp = factor_args.amp_dtype is not None
+    scale = _loss_scale(factor_args)
+    if scale != 1.0:
+        set_gradient_scale(model, 1.0 / scale)
+    for batch in loader:
+        batch = send_to_device(batch, state.device)
+        with no_sync(model, state):
+            model.zero_grad(set_to_none=True)
+            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=factor_args.amp_dtype):
+                loss = task.compute_train_loss(batch=batch, model=model, sample=not factor_args.use_empirical_fisher)
+            (loss * scale if scale != 1.0 else loss).backward()
+        if factor_args.has_shared_parameters:
+            finalize_iteration(model, tracked_module_names)
+        num_data_processed.add_(find_batch_size(batch))
+        del loss
+    if state.use_distributed:
+        synchronize_factors(model, LAMBDA_FACTOR_NAMES, tracked_module_names, state.device, extra=[num_data_processed])
+    saved: FACTOR_TYPE = {}
+    if state.is_main_process:
+        for name in LAMBDA_FACTOR_NAMES:
+            factor = load_factors(model, name, tracked_module_names, cpu=True,
+                                  dtype=factor_args.lambda_dtype if name == LAMBDA_MATRIX_NAME else None)
+            if len(factor) == 0:
+                raise ValueError(f"Factor `{name}` has not been computed.")
+            saved[name] = factor
+    model.zero_grad(set_to_none=True)
+    set_gradient_scale(model, 1.0)
+    set_mode(model, ModuleMode.DEFAULT, release_memory=True)
+    state.wait_for_everyone()
+    return num_data_processed, saved

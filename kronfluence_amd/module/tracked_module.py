@@ -1,0 +1,203 @@
+"""``TrackedModule``: the wrapper installed around every tracked ``nn.Linear`` / ``nn.Conv2d``.
+
+This is the drop-in boundary of the hot path (reference
+``module/tracked_module.py:49-416``): same constructor, same ``ModuleMode`` table, same ``storage``
+keys, same model-facing behaviour (the wrapped forward is untouched; a zero parameter makes the
+output require grad so a tensor hook fires although every weight is frozen).
+
+Two groups of per-module operators exist:
+
+* the reference's operator API (``get_flattened_activation`` ... ``compute_pairwise_score``), kept
+  so that custom subclasses and tests written against the reference keep working; and
+* fused accumulate-style operators (``accumulate_*``) that the trackers call on the hot path: they
+  hand the hooked activation / output-gradient tensors straight to the HIP kernels (no flatten,
+  ``cat``, cast or per-sample-gradient materialisation in between).
+"""
+
+from __future__ import annotations
+
+from typing import Any, Callable, Dict, List, Optional, Tuple, Type, Union
+
+import torch
+from torch import nn
+
+from kronfluence_amd.arguments import FactorArguments, ScoreArguments
+from kronfluence_amd.factor.config import FactorConfig
+from kronfluence_amd.module.tracker.base import BaseTracker
+from kronfluence_amd.module.tracker.factor import CovarianceTracker, LambdaTracker
+from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+from kronfluence_amd.module.tracker.precondition import PreconditionTracker
+from kronfluence_amd.utils.constants import (
+    ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
+    AGGREGATED_GRADIENT_NAME,
+    COVARIANCE_FACTOR_NAMES,
+    EIGENDECOMPOSITION_FACTOR_NAMES,
+    LAMBDA_FACTOR_NAMES,
+    PAIRWISE_SCORE_MATRIX_NAME,
+    PRECONDITIONED_GRADIENT_NAME,
+    SELF_SCORE_VECTOR_NAME,
+)
+
+
+class ModuleMode(str):
+    """String-valued mode constants (the reference uses a ``str`` enum with the same values)."""
+
+    DEFAULT = "default"
+    COVARIANCE = "covariance"
+    LAMBDA = "lambda"
+    PRECONDITION_GRADIENT = "precondition_gradient"
+    PAIRWISE_SCORE = "pairwise_score"
+    SELF_SCORE = "self_score"
+    SELF_MEASUREMENT_SCORE = "self_measurement_score"
+    GRADIENT_AGGREGATION = "gradient_aggregation"
+
+
+class _OutOfScopeTracker(BaseTracker):
+    """Modes outside the accelerated path (self-influence, gradient aggregation)."""
+
+    def register_hooks(self) -> None:
+        raise NotImplementedError(
+            f"Mode `{self.module.current_mode}` is not part of the MI355X hot path (pairwise EK-FAC scoring)."
+        )
+
+
+class TrackedModule(nn.Module):
+    SUPPORTED_MODULES: Dict[Type[nn.Module], Any] = {}
+
+    def __init_subclass__(cls, module_type: Optional[Type[nn.Module]] = None, **kwargs: Any) -> None:
+        super().__init_subclass__(**kwargs)
+        if module_type is not None:
+            cls.SUPPORTED_MODULES[module_type] = cls
+
+    def __init__(self, name: str, original_module: nn.Module, factor_args: Optional[FactorArguments] = None,
+                 score_args: Optional[ScoreArguments] = None,
+                 per_sample_gradient_process_fnc: Optional[Callable] = None) -> None:
+        super().__init__()
+        self.name = name
+        self.original_module = original_module
+        # requires_grad zero: keeps autograd alive through a fully frozen layer
+        self._constant = nn.Parameter(torch.zeros(1, dtype=original_module.weight.dtype, requires_grad=True))
+        self.current_mode = ModuleMode.DEFAULT
+        self.factor_args = factor_args if factor_args is not None else FactorArguments()
+        self.score_args = score_args if score_args is not None else ScoreArguments()
+        self.per_sample_gradient_process_fnc = per_sample_gradient_process_fnc
+        self._trackers: Dict[str, BaseTracker] = {
+            ModuleMode.DEFAULT: BaseTracker(self),
+            ModuleMode.COVARIANCE: CovarianceTracker(self),
+            ModuleMode.LAMBDA: LambdaTracker(self),
+            ModuleMode.PRECONDITION_GRADIENT: PreconditionTracker(self),
+            ModuleMode.PAIRWISE_SCORE: PairwiseScoreTracker(self),
+            ModuleMode.GRADIENT_AGGREGATION: _OutOfScopeTracker(self),
+            ModuleMode.SELF_SCORE: _OutOfScopeTracker(self),
+            ModuleMode.SELF_MEASUREMENT_SCORE: _OutOfScopeTracker(self),
+        }
+        self.attention_mask: Optional[torch.Tensor] = None
+        self.gradient_scale: float = 1.0
+        self.einsum_path: Optional[List[int]] = None  # kept for attribute compatibility; unused
+        # (scores buffer [Q, N], column offset) shared by all layers during the train pass
+        self.score_sink: Optional[Tuple[torch.Tensor, int]] = None
+        self.storage: Dict[str, Any] = {}
+        for key in (COVARIANCE_FACTOR_NAMES + EIGENDECOMPOSITION_FACTOR_NAMES + LAMBDA_FACTOR_NAMES
+                    + [AGGREGATED_GRADIENT_NAME, PRECONDITIONED_GRADIENT_NAME,
+                       ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, PAIRWISE_SCORE_MATRIX_NAME, SELF_SCORE_VECTOR_NAME]):
+            self.storage[key] = None
+
+    # -- model-facing -------------------------------------------------------------------------------
+    def forward(self, inputs: torch.Tensor, *args: Any, **kwargs: Any) -> torch.Tensor:
+        outputs = self.original_module(inputs, *args, **kwargs)
+        return outputs if outputs.requires_grad else outputs + self._constant
+
+    # -- bookkeeping (reference tracked_module.py:170-318) -----------------------------------------
+    def prepare_storage(self, device: torch.device) -> None:
+        FactorConfig.CONFIGS[self.factor_args.strategy].prepare(storage=self.storage, score_args=self.score_args,
+                                                                device=device)
+
+    def update_factor_args(self, factor_args: FactorArguments) -> None:
+        self.factor_args = factor_args
+
+    def update_score_args(self, score_args: ScoreArguments) -> None:
+        self.score_args = score_args
+
+    def get_factor(self, factor_name: str) -> Optional[torch.Tensor]:
+        return self.storage.get(factor_name)
+
+    def release_factor(self, factor_name: str) -> None:
+        if self.storage.get(factor_name) is not None:
+            self.storage[factor_name] = None
+
+    def set_factor(self, factor_name: str, factor: Any) -> None:
+        if factor_name in self.storage:
+            self.storage[factor_name] = factor
+
+    def set_mode(self, mode: str, release_memory: bool = False) -> None:
+        self._trackers[self.current_mode].release_hooks()
+        self.einsum_path = None
+        self.current_mode = mode
+        if release_memory:
+            for tracker in self._trackers.values():
+                tracker.release_memory()
+        self._trackers[self.current_mode].register_hooks()
+
+    def set_attention_mask(self, attention_mask: Optional[torch.Tensor] = None) -> None:
+        self.attention_mask = attention_mask
+
+    def set_gradient_scale(self, scale: float = 1.0) -> None:
+        self.gradient_scale = scale
+
+    def finalize_iteration(self) -> None:
+        self._trackers[self.current_mode].finalize_iteration()
+
+    def exist(self) -> bool:
+        return self._trackers[self.current_mode].exist()
+
+    def synchronize(self, num_processes: int) -> None:
+        self._trackers[self.current_mode].synchronize(num_processes=num_processes)
+
+    def truncate(self, keep_size: int) -> None:
+        self._trackers[self.current_mode].truncate(keep_size=keep_size)
+
+    def accumulate_iterations(self) -> None:
+        self._trackers[self.current_mode].accumulate_iterations()
+
+    def finalize_all_iterations(self) -> None:
+        self._trackers[self.current_mode].finalize_all_iterations()
+
+    # -- reference operator API (abstract in tracked_module.py:320-416) -----------------------------
+    def get_flattened_activation(self, input_activation: torch.Tensor) -> Tuple[torch.Tensor, Union[torch.Tensor, int]]:
+        raise NotImplementedError
+
+    def get_flattened_gradient(self, output_gradient: torch.Tensor) -> Tuple[torch.Tensor, Union[torch.Tensor, int]]:
+        raise NotImplementedError
+
+    def compute_per_sample_gradient(self, input_activation: torch.Tensor, output_gradient: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def compute_pairwise_score(self, preconditioned_gradient: torch.Tensor, input_activation: torch.Tensor,
+                               output_gradient: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+    def compute_summed_gradient(self, input_activation: torch.Tensor, output_gradient: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("Gradient aggregation is outside the accelerated hot path (SURVEY.md 8f).")
+
+    def compute_self_measurement_score(self, preconditioned_gradient: torch.Tensor, input_activation: torch.Tensor,
+                                       output_gradient: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError("Self-influence is outside the accelerated hot path (SURVEY.md 8f).")
+
+    # -- fused hot-path operators ------------------------------------------------------------------
+    @property
+    def has_bias(self) -> bool:
+        return self.original_module.bias is not None
+
+    def accumulate_activation_covariance(self, cov: Optional[torch.Tensor], count: Optional[torch.Tensor],
+                                         input_activation: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``cov += X'^T X'``, ``count += rows`` for the hooked input; allocates on first use."""
+        raise NotImplementedError
+
+    def accumulate_gradient_covariance(self, cov: Optional[torch.Tensor], count: Optional[torch.Tensor],
+                                       output_gradient: torch.Tensor, alpha: float) -> Tuple[torch.Tensor, torch.Tensor]:
+        raise NotImplementedError
+
+    def gradient_factors(self, input_activation: torch.Tensor, output_gradient: torch.Tensor
+                         ) -> Tuple[torch.Tensor, torch.Tensor, bool]:
+        """``(G [b,R,O], A [b,R,I], append_ones)`` with ``g_b = sum_r G[b,r,:]^T [A[b,r,:], 1]``."""
+        raise NotImplementedError

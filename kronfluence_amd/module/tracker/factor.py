@@ -1,0 +1,185 @@
+"""Covariance and Lambda trackers (reference ``module/tracker/factor.py:25-327``).
+
+MI355X-first differences, results identical within fp tolerance:
+
+* accumulators are fp32 tensors resident in HBM whatever the factor dtype (the reference
+  accumulates in the factor dtype, e.g. bf16); they are cast once, on export;
+* the covariance hooks feed the hooked tensors straight to ``kf_syrk_accum`` -- flatten, mask,
+  ones column and ``addmm_`` are one kernel;
+* Lambda never materialises the ``[b, O, I']`` per-sample gradient: it rotates the gradient's
+  factors (``G Qg``, ``[A,1] Qa``) and squares their batched product (``kf_lambda_accum``), which is
+  the same mathematics at 2R(I'^2+O^2+OI') instead of 2OI'(I'+O+R) flops per sample.
+"""
+
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from kronfluence_amd import ops
+from kronfluence_amd.factor.config import FactorConfig
+from kronfluence_amd.module.tracker.base import BaseTracker
+from kronfluence_amd.utils.constants import (
+    ACTIVATION_COVARIANCE_MATRIX_NAME,
+    ACTIVATION_EIGENVECTORS_NAME,
+    COVARIANCE_FACTOR_NAMES,
+    EIGENDECOMPOSITION_FACTOR_NAMES,
+    GRADIENT_COVARIANCE_MATRIX_NAME,
+    GRADIENT_EIGENVECTORS_NAME,
+    LAMBDA_FACTOR_NAMES,
+    LAMBDA_MATRIX_NAME,
+    NUM_ACTIVATION_COVARIANCE_PROCESSED,
+    NUM_GRADIENT_COVARIANCE_PROCESSED,
+    NUM_LAMBDA_PROCESSED,
+)
+from kronfluence_amd.utils.exceptions import FactorsNotFoundError
+
+
+def _all_reduce_sum(tensors) -> None:
+    """SUM over ranks (RCCL when the tensors are on GPU; gloo in the CPU tests)."""
+    for t in tensors:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+
+class CovarianceTracker(BaseTracker):
+    def register_hooks(self) -> None:
+        module = self.module
+        storage = module.storage
+
+        @torch.no_grad()
+        def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
+            del mod
+            cov, count = module.accumulate_activation_covariance(
+                storage[ACTIVATION_COVARIANCE_MATRIX_NAME], storage[NUM_ACTIVATION_COVARIANCE_PROCESSED],
+                inputs[0].detach())
+            storage[ACTIVATION_COVARIANCE_MATRIX_NAME] = cov
+            storage[NUM_ACTIVATION_COVARIANCE_PROCESSED] = count
+            self.cached_hooks.append(outputs.register_hook(backward_hook))
+
+        @torch.no_grad()
+        def backward_hook(output_gradient: torch.Tensor) -> None:
+            self.cached_hooks.pop().remove()
+            alpha = module.gradient_scale**2.0 if module.gradient_scale != 1.0 else 1.0  # factor.py:90-92
+            cov, count = module.accumulate_gradient_covariance(
+                storage[GRADIENT_COVARIANCE_MATRIX_NAME], storage[NUM_GRADIENT_COVARIANCE_PROCESSED],
+                output_gradient.detach(), alpha)
+            storage[GRADIENT_COVARIANCE_MATRIX_NAME] = cov
+            storage[NUM_GRADIENT_COVARIANCE_PROCESSED] = count
+
+        self.registered_hooks.append(module.register_forward_hook(forward_hook))
+
+    def exist(self) -> bool:
+        return all(self.module.storage[name] is not None for name in COVARIANCE_FACTOR_NAMES)
+
+    def synchronize(self, num_processes: int) -> None:
+        """Stand-alone form of C1 (reference ``factor.py:132-142``); the stage loop normally uses the
+        bucketed ``module.utils.synchronize_factors`` instead (one flat all-reduce for all layers)."""
+        del num_processes
+        if dist.is_initialized() and self.exist():
+            _all_reduce_sum([self.module.storage[name] for name in COVARIANCE_FACTOR_NAMES])
+
+    def release_memory(self) -> None:
+        for name in COVARIANCE_FACTOR_NAMES:
+            self.module.storage[name] = None
+
+
+class LambdaTracker(BaseTracker):
+    def _eigenvectors(self, device: torch.device) -> Tuple[torch.Tensor, torch.Tensor]:
+        storage = self.module.storage
+        if storage[ACTIVATION_EIGENVECTORS_NAME] is None or storage[GRADIENT_EIGENVECTORS_NAME] is None:
+            raise FactorsNotFoundError(
+                f"The strategy {self.module.factor_args.strategy} requires eigendecomposition "
+                f"results for Lambda computations, but they are not found."
+            )
+        for name in (ACTIVATION_EIGENVECTORS_NAME, GRADIENT_EIGENVECTORS_NAME):
+            q = storage[name]
+            if q.device != device or q.dtype != torch.float32 or not q.is_contiguous():
+                storage[name] = q.to(device=device, dtype=torch.float32).contiguous()  # once (factor.py:191-201)
+        return storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
+
+    def _update_from_factors(self, g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> None:
+        module, storage = self.module, self.module.storage
+        b, r, o = g.shape
+        q_a, q_g = self._eigenvectors(g.device)
+        ip = q_a.shape[0]
+        if storage[LAMBDA_MATRIX_NAME] is None:
+            storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=g.device)
+            storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
+        storage[NUM_LAMBDA_PROCESSED].add_(b)  # samples, not tokens (factor.py:203)
+        gt = ops.matmul_nn(g.reshape(b * r, o), q_g)
+        at = ops.matmul_nn(a.reshape(b * r, a.shape[-1]), q_a, append_ones=append_ones)
+        ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
+
+    def _update_from_gradient(self, per_sample_gradient: torch.Tensor) -> None:
+        """Materialised-gradient form (post-processed or shared-parameter gradients):
+        ``Lambda += sum_b (Qg^T g_b Qa)^2`` with both rotations on the MFMA engine."""
+        storage = self.module.storage
+        g = per_sample_gradient.to(torch.float32).contiguous()
+        b, o, ip = g.shape
+        q_a, q_g = self._eigenvectors(g.device)
+        if storage[LAMBDA_MATRIX_NAME] is None:
+            storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=g.device)
+            storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
+        storage[NUM_LAMBDA_PROCESSED].add_(b)
+        t1 = torch.empty((b * o, ip), dtype=torch.float32, device=g.device)
+        ops.gemm(t1, ip, 0, ops.view(g, 0, ip, 1, b * o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
+        t2 = torch.empty((b, o, ip), dtype=torch.float32, device=g.device)
+        ops.gemm(t2, ip, o * ip, ops.view(q_g, 0, 1, o, o, o), ops.view(t1, o * ip, 1, ip, ip, o), batch=b)
+        scale = self.module.gradient_scale
+        storage[LAMBDA_MATRIX_NAME].add_(t2.square_().sum(dim=0), alpha=scale * scale)
+
+    def register_hooks(self) -> None:
+        module = self.module
+
+        @torch.no_grad()
+        def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
+            del mod
+            self._cache_activation(inputs[0].detach().clone())
+            self.cached_hooks.append(
+                outputs.register_hook(shared_backward_hook if module.factor_args.has_shared_parameters else backward_hook))
+
+        @torch.no_grad()
+        def backward_hook(output_gradient: torch.Tensor) -> None:
+            activation = self._take_activation()
+            self.cached_hooks.pop().remove()
+            if module.per_sample_gradient_process_fnc is None:
+                g, a, ones = module.gradient_factors(activation, output_gradient.detach())
+                self._update_from_factors(g, a, ones)
+            else:
+                self._update_from_gradient(module.compute_per_sample_gradient(activation, output_gradient.detach()))
+
+        @torch.no_grad()
+        def shared_backward_hook(output_gradient: torch.Tensor) -> None:
+            activation = self._take_activation()
+            self.cached_hooks.pop().remove()
+            psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
+            if self.cached_per_sample_gradient is None:
+                self.cached_per_sample_gradient = torch.zeros_like(psg)
+            self.cached_per_sample_gradient.add_(psg)
+
+        self.registered_hooks.append(module.register_forward_hook(forward_hook))
+
+    @torch.no_grad()
+    def finalize_iteration(self) -> None:
+        if self.module.factor_args.has_shared_parameters and self.cached_per_sample_gradient is not None:
+            self._update_from_gradient(self.cached_per_sample_gradient)
+        self.clear_all_cache()
+
+    def exist(self) -> bool:
+        return all(self.module.storage[name] is not None for name in LAMBDA_FACTOR_NAMES)
+
+    def synchronize(self, num_processes: int) -> None:
+        del num_processes
+        if dist.is_initialized() and self.exist():
+            storage = self.module.storage
+            count = storage[NUM_LAMBDA_PROCESSED].to(storage[LAMBDA_MATRIX_NAME].device)
+            _all_reduce_sum([storage[LAMBDA_MATRIX_NAME], count])
+            storage[NUM_LAMBDA_PROCESSED] = count.cpu()
+
+    def release_memory(self) -> None:
+        self.clear_all_cache()
+        for name in LAMBDA_FACTOR_NAMES:
+            self.module.storage[name] = None

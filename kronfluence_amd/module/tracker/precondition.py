@@ -1,0 +1,117 @@
+"""Preconditioned query gradients (reference ``module/tracker/precondition.py``).
+
+The hook hands the query batch's activation / output-gradient factors to ``kf_precondition``
+(per-sample gradient + EK-FAC preconditioner + scale in one call chain on the MFMA engine); results
+stay resident in HBM in fp32.  Low-rank query batching (``query_gradient_low_rank``) is a
+"next" row and is rejected up front by the score stage.
+"""
+
+from __future__ import annotations
+
+from typing import Tuple
+
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from kronfluence_amd import ops
+from kronfluence_amd.factor.config import FactorConfig
+from kronfluence_amd.module.tracker.base import BaseTracker
+from kronfluence_amd.utils.constants import (
+    ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
+    ACTIVATION_EIGENVECTORS_NAME,
+    GRADIENT_EIGENVECTORS_NAME,
+    LAMBDA_MATRIX_NAME,
+    PRECONDITIONED_GRADIENT_NAME,
+)
+
+
+class PreconditionTracker(BaseTracker):
+    def _store(self, preconditioned: torch.Tensor) -> None:
+        self.module.storage[PRECONDITIONED_GRADIENT_NAME] = preconditioned
+
+    def register_hooks(self) -> None:
+        module = self.module
+        storage = module.storage
+
+        @torch.no_grad()
+        def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
+            del mod
+            self._cache_activation(inputs[0].detach().clone())
+            self.cached_hooks.append(
+                outputs.register_hook(shared_backward_hook if module.factor_args.has_shared_parameters else backward_hook))
+
+        @torch.no_grad()
+        def backward_hook(output_gradient: torch.Tensor) -> None:
+            activation = self._take_activation()
+            self.cached_hooks.pop().remove()
+            if module.per_sample_gradient_process_fnc is None and module.factor_args.strategy == "ekfac":
+                g, a, ones = module.gradient_factors(activation, output_gradient.detach())
+                self._store(ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
+                                             storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
+                                             scale=module.gradient_scale))
+            else:
+                psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
+                out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(psg, storage)
+                if module.gradient_scale != 1.0:
+                    out.mul_(module.gradient_scale)
+                self._store(out)
+
+        @torch.no_grad()
+        def shared_backward_hook(output_gradient: torch.Tensor) -> None:
+            activation = self._take_activation()
+            self.cached_hooks.pop().remove()
+            psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
+            if self.cached_per_sample_gradient is None:
+                self.cached_per_sample_gradient = torch.zeros_like(psg)
+            self.cached_per_sample_gradient.add_(psg)
+
+        self.registered_hooks.append(module.register_forward_hook(forward_hook))
+
+    @torch.no_grad()
+    def finalize_iteration(self) -> None:
+        module = self.module
+        if module.factor_args.has_shared_parameters and self.cached_per_sample_gradient is not None:
+            out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(
+                self.cached_per_sample_gradient, module.storage)
+            if module.gradient_scale != 1.0:
+                out.mul_(module.gradient_scale)
+            self._store(out)
+        self.clear_all_cache()
+
+    def exist(self) -> bool:
+        storage = self.module.storage
+        return (storage[PRECONDITIONED_GRADIENT_NAME] is not None
+                or storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] is not None)
+
+    def synchronize(self, num_processes: int = 1) -> None:
+        """C4: all-gather the ``[q, O, I']`` block of every rank and interleave so that row
+        ``j * P + r`` is rank ``r``'s ``j``-th query -- the dataset order of a strided
+        ``DistributedSampler`` (reference ``precondition.py:181-201``)."""
+        storage = self.module.storage
+        local = storage[PRECONDITIONED_GRADIENT_NAME]
+        if not dist.is_initialized() or local is None:
+            return
+        local = local.contiguous()
+        stacked = torch.empty((num_processes,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(stacked, local)
+        storage[PRECONDITIONED_GRADIENT_NAME] = stacked.transpose(0, 1).reshape(
+            num_processes * local.shape[0], local.shape[1], local.shape[2])
+
+    def truncate(self, keep_size: int) -> None:
+        storage = self.module.storage
+        storage[PRECONDITIONED_GRADIENT_NAME] = storage[PRECONDITIONED_GRADIENT_NAME][:keep_size].clone()
+
+    def accumulate_iterations(self) -> None:
+        storage = self.module.storage
+        held, new = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME], storage[PRECONDITIONED_GRADIENT_NAME]
+        if new is None:
+            return
+        storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
+            new.contiguous() if held is None else torch.cat((held, new), dim=0).contiguous())
+        storage[PRECONDITIONED_GRADIENT_NAME] = None
+
+    def release_memory(self) -> None:
+        self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
+        self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
+        self.clear_all_cache()

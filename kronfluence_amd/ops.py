@@ -1,0 +1,293 @@
+"""Tensor-level entry points of the hot path: thin, allocation-light wrappers that hand raw device
+pointers and the current HIP stream to the C ABI (``include/kronfluence_hip.h``).
+
+Nothing here computes on the host; every function raises ``KfError`` if its tensors are not on an
+MI355X.  Accumulators are fp32 device tensors owned by the caller (the trackers); workspaces come
+from PyTorch's caching allocator.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import math
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from kronfluence_amd import _native as nat
+from kronfluence_amd._native import kf_view
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _contig(t: torch.Tensor) -> torch.Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def view(t: torch.Tensor, batch_stride: int, row_stride: int, k_stride: int, rows: int, depth: int,
+         ones_row: bool = False, ones_k: bool = False, square: bool = False) -> kf_view:
+    """Strided operand view over the STORAGE of ``t`` (strides in elements); ``t`` must be contiguous."""
+    assert t.is_contiguous(), "kf_view describes raw storage; pass a contiguous tensor"
+    return kf_view(t.data_ptr(), nat.dtype_code(t.dtype), batch_stride, row_stride, k_stride, rows, depth,
+                   int(ones_row), int(ones_k), int(square))
+
+
+# ---------------------------------------------------------------------------------------------
+# Stage 1: covariance
+# ---------------------------------------------------------------------------------------------
+def syrk_accum(cov: torch.Tensor, x: torch.Tensor, n_rows: int, d_in: int, rows_inner: int, outer_stride: int,
+               row_stride: int, col_stride: int, mask: Optional[torch.Tensor] = None, append_ones: bool = False,
+               alpha: float = 1.0, count: Optional[torch.Tensor] = None) -> None:
+    """``cov += alpha * X'^T X'`` (kf_syrk_accum).  ``cov``: fp32 ``[d, d]`` device tensor."""
+    nat.require_device(cov, "cov")
+    nat.require_device(x, "x")
+    assert cov.dtype == torch.float32 and cov.is_contiguous()
+    if mask is not None:
+        nat.require_device(mask, "mask")
+        mask = _contig(mask)
+        assert mask.numel() == n_rows
+    if count is not None:
+        nat.require_device(count, "count")
+        assert count.dtype == torch.int64
+    nat.check(
+        nat.lib().kf_syrk_accum(cov.data_ptr(), cov.shape[1], x.data_ptr(), nat.dtype_code(x.dtype), n_rows, d_in,
+                                rows_inner, outer_stride, row_stride, col_stride, _ptr(mask),
+                                nat.dtype_code(mask.dtype) if mask is not None else 0, int(append_ones), alpha,
+                                _ptr(count), nat.stream_ptr(x.device)),
+        "kf_syrk_accum",
+    )
+
+
+def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor],
+                          has_bias: bool) -> None:
+    """Flatten + mask + ones column + ``addmm_`` of module/linear.py:30-46 and tracker/factor.py:58, fused."""
+    x = _contig(x)
+    d_in = x.shape[-1]
+    n = x.numel() // d_in
+    if mask is not None and mask.numel() != n:
+        mask = None  # linear.py:33 -- the mask applies only when it matches the row count
+    syrk_accum(cov, x, n, d_in, max(n, 1), 0, d_in, 1, mask, has_bias, 1.0, count)
+
+
+def linear_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, mask: Optional[torch.Tensor],
+                        alpha: float = 1.0) -> None:
+    """module/linear.py:48-54 + tracker/factor.py:93: gradient rows are never masked; the count is."""
+    g = _contig(g)
+    d = g.shape[-1]
+    n = g.numel() // d
+    syrk_accum(cov, g, n, d, max(n, 1), 0, d, 1, None, False, alpha, None)
+    if mask is not None and mask.numel() == n:
+        count.add_(mask.sum().to(torch.int64))
+    else:
+        count.add_(n)
+
+
+def conv_geometry(conv: nn.Conv2d) -> Tuple[int, int, int, int, int, int, int, int]:
+    """Resolves string paddings like module/conv2d.py:46-53 (unequal padding is unsupported there too)."""
+    from kronfluence_amd.utils.exceptions import UnsupportableModuleError
+
+    k1, k2 = conv.kernel_size
+    s1, s2 = conv.stride
+    d1, d2 = conv.dilation
+    padding = conv.padding
+    if isinstance(padding, str):
+        pads = []
+        for k, d in ((k1, d1), (k2, d2)):
+            if padding == "valid":
+                left = right = 0
+            else:
+                total = d * (k - 1)
+                left, right = total // 2, total - total // 2
+            if left != right:
+                raise UnsupportableModuleError("Unequal padding not supported in unfold.")
+            pads.append(left)
+        p1, p2 = pads
+    else:
+        p1, p2 = padding
+    return k1, k2, s1, s2, p1, p2, d1, d2
+
+
+def im2col(x: torch.Tensor, conv: nn.Conv2d, append_ones: bool, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """Patches ``[b, P, I']`` of module/conv2d.py:15-64 (+ ones column), via kf_im2col."""
+    nat.require_device(x, "x")
+    x = _contig(x)
+    b, c, h, w = x.shape
+    k1, k2, s1, s2, p1, p2, d1, d2 = conv_geometry(conv)
+    o1 = (h + 2 * p1 - d1 * (k1 - 1) - 1) // s1 + 1
+    o2 = (w + 2 * p2 - d2 * (k2 - 1) - 1) // s2 + 1
+    ip = (c // conv.groups) * k1 * k2 + int(append_ones)
+    out = torch.empty((b, o1 * o2, ip), dtype=out_dtype, device=x.device)
+    nat.check(
+        nat.lib().kf_im2col(out.data_ptr(), nat.dtype_code(out_dtype), x.data_ptr(), nat.dtype_code(x.dtype), b, c, h, w,
+                            k1, k2, s1, s2, p1, p2, d1, d2, conv.groups, int(append_ones), nat.stream_ptr(x.device)),
+        "kf_im2col",
+    )
+    return out
+
+
+def conv_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d) -> None:
+    """module/conv2d.py:106-128 + tracker/factor.py:58."""
+    patches = im2col(x, conv, conv.bias is not None, x.dtype if x.dtype != torch.float64 else torch.float32)
+    n, d = patches.shape[0] * patches.shape[1], patches.shape[2]
+    syrk_accum(cov, patches, n, d, max(n, 1), 0, d, 1, None, False, 1.0, count)
+
+
+def conv_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, alpha: float = 1.0) -> None:
+    """module/conv2d.py:130-132 (``b c o1 o2 -> (b o1 o2) c``) + tracker/factor.py:93, without the transpose copy."""
+    g = _contig(g)
+    b, o, h, w = g.shape
+    p = h * w
+    syrk_accum(cov, g, b * p, o, p, o * p, 1, p, None, False, alpha, count)
+
+
+# ---------------------------------------------------------------------------------------------
+# GEMM building block
+# ---------------------------------------------------------------------------------------------
+def gemm(c: torch.Tensor, ldc: int, c_batch_stride: int, a: kf_view, b: kf_view, batch: int = 1, alpha: float = 1.0,
+         beta: float = 0.0, mul: Optional[torch.Tensor] = None) -> None:
+    nat.require_device(c, "c")
+    assert c.dtype == torch.float32
+    nat.check(
+        nat.lib().kf_gemm(c.data_ptr(), ldc, c_batch_stride, ctypes.byref(a), ctypes.byref(b), batch, alpha, beta,
+                          _ptr(mul), mul.shape[-1] if mul is not None else 0, nat.stream_ptr(c.device)),
+        "kf_gemm",
+    )
+
+
+def matmul_nn(x: torch.Tensor, w: torch.Tensor, append_ones: bool = False) -> torch.Tensor:
+    """``[x, 1] @ w`` for ``x: [n, d]`` (any float dtype), ``w: [d', m]`` fp32 -> fp32 ``[n, m]``."""
+    x, w = _contig(x), _contig(w)
+    n, d = x.shape
+    out = torch.empty((n, w.shape[1]), dtype=torch.float32, device=x.device)
+    gemm(out, w.shape[1], 0, view(x, 0, d, 1, n, d, ones_k=append_ones), view(w, 0, 1, w.shape[1], w.shape[1], w.shape[0]))
+    return out
+
+
+def per_sample_gradient(g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> torch.Tensor:
+    """``einsum("b...i,b...o->bio", g, [a,1])`` of module/linear.py:72 / conv2d.py:176: ``g: [b,R,O]``, ``a: [b,R,I]``."""
+    g, a = _contig(g), _contig(a)
+    b, r, o = g.shape
+    i = a.shape[2]
+    ip = i + int(append_ones)
+    out = torch.empty((b, o, ip), dtype=torch.float32, device=g.device)
+    gemm(out, ip, o * ip, view(g, r * o, 1, o, o, r), view(a, r * i, 1, i, i, r, ones_row=append_ones), batch=b)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Stage 2: eigendecomposition, Lambda
+# ---------------------------------------------------------------------------------------------
+def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0) -> Tuple[torch.Tensor, torch.Tensor, int]:
+    """fp64 ``eigh(0.5 (cov + cov^T) / count)`` (factor/eigen.py:193-205) -> (evals, evecs, sweeps)."""
+    nat.require_device(cov, "cov")
+    assert cov.dim() == 2 and cov.shape[0] == cov.shape[1] and cov.dtype in (torch.float32, torch.float64)
+    cov = _contig(cov)
+    d = cov.shape[0]
+    evals = torch.empty(d, dtype=torch.float64, device=cov.device)
+    evecs = torch.empty((d, d), dtype=torch.float64, device=cov.device)
+    ws_bytes = nat.lib().kf_eigh_workspace_bytes(d)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cov.device)
+    sweeps = ctypes.c_int(0)
+    nat.check(
+        nat.lib().kf_eigh_f64(cov.data_ptr(), nat.dtype_code(cov.dtype), float(count), d, evals.data_ptr(), evecs.data_ptr(),
+                              ws.data_ptr(), ws_bytes, max_sweeps, ctypes.byref(sweeps), nat.stream_ptr(cov.device)),
+        "kf_eigh_f64",
+    )
+    return evals, evecs, sweeps.value
+
+
+def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, r: int, scale: float = 1.0) -> None:
+    """``lam += sum_b (Gt_b^T At_b)^2`` with rotated factors (kf_lambda_accum; tracker/factor.py:218-226)."""
+    nat.require_device(lam, "lam")
+    assert lam.dtype == gt.dtype == at.dtype == torch.float32 and gt.is_contiguous() and at.is_contiguous()
+    o, ip = lam.shape
+    assert gt.numel() == b * r * o and at.numel() == b * r * ip
+    nat.check(
+        nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), b, r, o, ip, scale,
+                                  nat.stream_ptr(lam.device)),
+        "kf_lambda_accum",
+    )
+
+
+# ---------------------------------------------------------------------------------------------
+# Stage 3: preconditioning and pairwise scores
+# ---------------------------------------------------------------------------------------------
+def inv_lambda(lam: torch.Tensor, n_lambda: float, damping: Optional[float]) -> torch.Tensor:
+    """``1 / (lam / n + damping)`` in fp64 (factor/config.py:331-338); ``None`` -> 0.1 * mean heuristic."""
+    nat.require_device(lam, "lam")
+    lam = _contig(lam.to(torch.float32))
+    out = torch.empty_like(lam)
+    ws = torch.empty(2, dtype=torch.float64, device=lam.device)
+    nat.check(
+        nat.lib().kf_inv_lambda(out.data_ptr(), lam.data_ptr(), lam.numel(), float(n_lambda),
+                                -1.0 if damping is None else float(damping), ws.data_ptr(), nat.stream_ptr(lam.device)),
+        "kf_inv_lambda",
+    )
+    return out
+
+
+def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch.Tensor, q_a: torch.Tensor,
+                 lam_inv: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """EK-FAC preconditioned per-sample gradient ``[q, O, I']`` from ``g: [q,R,O]`` and ``a: [q,R,I]``
+    (tracker/precondition.py:102-123 + factor/config.py:341-353)."""
+    nat.require_device(g, "g")
+    g, a = _contig(g), _contig(a)
+    q, r, o = g.shape
+    i = a.shape[2]
+    ip = i + int(append_ones)
+    assert q_g.shape == (o, o) and q_a.shape == (ip, ip) and lam_inv.shape == (o, ip)
+    assert q_g.dtype == q_a.dtype == lam_inv.dtype == torch.float32 and g.dtype == a.dtype
+    q_g, q_a, lam_inv = _contig(q_g), _contig(q_a), _contig(lam_inv)  # keep the contiguous copies alive
+    out = torch.empty((q, o, ip), dtype=torch.float32, device=g.device)
+    ws_bytes = nat.lib().kf_precondition_workspace_bytes(q, r, o, ip)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    nat.check(
+        nat.lib().kf_precondition(out.data_ptr(), g.data_ptr(), a.data_ptr(), nat.dtype_code(g.dtype), q, r, o, i,
+                                  int(append_ones), q_g.data_ptr(), q_a.data_ptr(), lam_inv.data_ptr(), scale,
+                                  ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
+        "kf_precondition",
+    )
+    return out
+
+
+def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: torch.Tensor, a: torch.Tensor,
+                   append_ones: bool, scale: float = 1.0) -> None:
+    """``scores[:, col_offset:col_offset+b] += scale * <P_q, g_n>`` (kf_pairwise_score).
+
+    ``scores``: fp32 ``[Q, N]`` device buffer shared by all layers and all train batches of a shard."""
+    nat.require_device(scores, "scores")
+    nat.require_device(p, "p")
+    assert scores.dtype == p.dtype == torch.float32 and scores.is_contiguous() and p.is_contiguous()
+    g, a = _contig(g), _contig(a)
+    assert g.dtype == a.dtype
+    b, r, o = g.shape
+    i = a.shape[2]
+    ip = i + int(append_ones)
+    q = p.shape[0]
+    assert p.shape[1] == o and p.shape[2] == ip and scores.shape[0] == q and col_offset + b <= scores.shape[1]
+    ws_bytes = nat.lib().kf_pairwise_workspace_bytes(b, r, o, ip)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    nat.check(
+        nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.data_ptr(), q, g.data_ptr(),
+                                    a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
+                                    ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
+        "kf_pairwise_score",
+    )
+
+
+def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """Device-side dtype conversion used when exporting fp32/fp64 accumulators in the factor dtype."""
+    nat.require_device(src, "src")
+    src = _contig(src)
+    if src.dtype == dtype:
+        return src.clone()
+    out = torch.empty(src.shape, dtype=dtype, device=src.device)
+    nat.check(
+        nat.lib().kf_cast(out.data_ptr(), nat.dtype_code(dtype), src.data_ptr(), nat.dtype_code(src.dtype), src.numel(),
+                          nat.stream_ptr(src.device)),
+        "kf_cast",
+    )
+    return out

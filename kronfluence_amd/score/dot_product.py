@@ -1,0 +1,80 @@
+"""Inner loop of pairwise scoring: one pass over the (sharded) train set for the query gradients
+currently held (reference ``score/dot_product.py:39-153``).
+
+All tracked layers accumulate into one ``[Q, N_shard]`` fp32 buffer in HBM; nothing crosses PCIe
+until the shard is done, then the per-rank blocks are gathered on rank 0 (C5).
+"""
+
+from __future__ import annotations
+
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+from torch import autocast, nn
+from torch.utils import data
+
+from kronfluence_amd.arguments import FactorArguments, ScoreArguments
+from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
+from kronfluence_amd.module.utils import finalize_all_iterations, finalize_iteration, set_mode, set_score_sink
+from kronfluence_amd.task import Task
+from kronfluence_amd.utils.constants import (
+    ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, ALL_MODULE_NAME, SCORE_TYPE,
+)
+from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
+from kronfluence_amd.utils.state import State, no_sync
+
+
+def gather_score_blocks(block: torch.Tensor, state: State, dataset_size: int) -> torch.Tensor:
+    """C5: rank 0 receives every rank's ``[Q, ceil(N/P)]`` block and concatenates them along the
+    train axis, dropping the wrap-around padding (reference ``dot_product.py:141-150``)."""
+    if not state.use_distributed:
+        return block[:, :dataset_size].cpu()
+    gather_list = [torch.empty_like(block) for _ in range(state.num_processes)] if state.is_main_process else None
+    dist.gather(block, gather_list, dst=0)
+    if state.is_main_process:
+        return torch.cat(gather_list, dim=1)[:, :dataset_size].cpu()
+    return block.cpu()
+
+
+def compute_dot_products_with_loader(model: nn.Module, task: Task, state: State, train_loader: data.DataLoader,
+                                     factor_args: FactorArguments, score_args: ScoreArguments,
+                                     tracked_module_names: List[str], loss_scale: float = 1.0,
+                                     disable_tqdm: bool = False) -> SCORE_TYPE:
+    del disable_tqdm
+    model.zero_grad(set_to_none=True)
+    set_mode(model, ModuleMode.PAIRWISE_SCORE, tracked_module_names, release_memory=False)
+    modules = [m for m in model.modules() if isinstance(m, TrackedModule) and m.name in tracked_module_names]
+    num_queries = modules[0].storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME].shape[0]
+    shard_size = len(train_loader.sampler) if hasattr(train_loader, "sampler") else len(train_loader.dataset)
+    dataset_size = len(train_loader.dataset)
+
+    keys = [m.name for m in modules] if score_args.compute_per_module_scores else [ALL_MODULE_NAME]
+    buffers: Dict[str, torch.Tensor] = {
+        key: torch.zeros((num_queries, shard_size), dtype=torch.float32, device=state.device) for key in keys
+    }
+    enable_amp = score_args.amp_dtype is not None
+    offset = 0
+    for batch in train_loader:
+        batch = send_to_device(batch, state.device)
+        for m in modules:
+            m.score_sink = (buffers[m.name if score_args.compute_per_module_scores else ALL_MODULE_NAME], offset)
+        with no_sync(model, state):
+            model.zero_grad(set_to_none=True)
+            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                loss = task.compute_train_loss(batch=batch, model=model, sample=False)
+            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+        if factor_args.has_shared_parameters:
+            finalize_iteration(model, tracked_module_names)
+        offset += find_batch_size(batch)
+        del loss
+    model.zero_grad(set_to_none=True)
+    set_score_sink(model, None, tracked_module_names)
+    finalize_all_iterations(model, tracked_module_names)
+    set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=False)
+
+    total_scores: SCORE_TYPE = {}
+    for key, block in buffers.items():
+        total_scores[key] = gather_score_blocks(block.to(score_args.score_dtype), state, dataset_size)
+    state.wait_for_everyone()
+    return total_scores

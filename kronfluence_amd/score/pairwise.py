@@ -1,0 +1,112 @@
+"""Stage 3 outer loop: preconditioned query gradients, then train passes (reference
+``score/pairwise.py:133-293``), plus the scores' safetensors layout (``:38-130``)."""
+
+from __future__ import annotations
+
+from pathlib import Path
+from typing import Dict, List, Optional
+
+import torch
+from safetensors.torch import load_file, save_file
+from torch import autocast, nn
+from torch.utils import data
+
+from kronfluence_amd.arguments import FactorArguments, ScoreArguments, unsupported_score_options
+from kronfluence_amd.factor.covariance import _loss_scale
+from kronfluence_amd.module.tracked_module import ModuleMode
+from kronfluence_amd.module.utils import (
+    accumulate_iterations, finalize_all_iterations, finalize_iteration, get_tracked_module_names, prepare_modules,
+    set_factors, set_gradient_scale, set_mode, synchronize_modules, truncate, update_factor_args, update_score_args,
+)
+from kronfluence_amd.score.dot_product import compute_dot_products_with_loader
+from kronfluence_amd.task import Task
+from kronfluence_amd.utils.constants import FACTOR_TYPE, SCORE_TYPE
+from kronfluence_amd.utils.dataset import send_to_device
+from kronfluence_amd.utils.state import State, no_sync
+
+
+def pairwise_scores_save_path(output_dir: Path, partition=None) -> Path:
+    if partition is not None:
+        return output_dir / f"pairwise_scores_data_partition{partition[0]}_module_partition{partition[1]}.safetensors"
+    return output_dir / "pairwise_scores.safetensors"
+
+
+def save_pairwise_scores(output_dir: Path, scores: SCORE_TYPE, partition=None, metadata: Optional[Dict[str, str]] = None) -> None:
+    save_file(tensors={k: v.contiguous() for k, v in scores.items()},
+              filename=str(pairwise_scores_save_path(output_dir, partition)), metadata=metadata)
+
+
+def load_pairwise_scores(output_dir: Path, partition=None) -> SCORE_TYPE:
+    return load_file(filename=str(pairwise_scores_save_path(output_dir, partition)))
+
+
+def pairwise_scores_exist(output_dir: Path, partition=None) -> bool:
+    return pairwise_scores_save_path(output_dir, partition).exists()
+
+
+def compute_pairwise_scores_with_loaders(loaded_factors: FACTOR_TYPE, model: nn.Module, state: State, task: Task,
+                                         query_loader: data.DataLoader, per_device_query_batch_size: int,
+                                         train_loader: data.DataLoader, score_args: ScoreArguments,
+                                         factor_args: FactorArguments, tracked_module_names: Optional[List[str]],
+                                         disable_tqdm: bool = False) -> SCORE_TYPE:
+    flagged = unsupported_score_options(score_args)
+    if flagged:
+        raise NotImplementedError(
+            f"ScoreArguments options {flagged} are outside the MI355X pairwise hot path (SURVEY.md section 8f)."
+        )
+    update_factor_args(model, factor_args)
+    update_score_args(model, score_args)
+    if tracked_module_names is None:
+        tracked_module_names = get_tracked_module_names(model)
+    set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=True)
+    for name in loaded_factors:
+        set_factors(model, name, loaded_factors[name], clone=True)
+    prepare_modules(model, tracked_module_names, state.device)
+
+    chunks: Dict[str, List[torch.Tensor]] = {}
+    total_query_batch_size = per_device_query_batch_size * state.num_processes
+    query_remainder = len(query_loader.dataset) % total_query_batch_size
+    num_batches = len(query_loader)
+    enable_amp = score_args.amp_dtype is not None
+    scale = _loss_scale(factor_args) if (enable_amp and factor_args.amp_dtype == torch.float16) else 1.0
+    if scale != 1.0:
+        set_gradient_scale(model, 1.0 / scale)
+
+    held = 0
+    for query_index, query_batch in enumerate(query_loader):
+        query_batch = send_to_device(query_batch, state.device)
+        with no_sync(model, state):
+            model.zero_grad(set_to_none=True)
+            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                measurement = task.compute_measurement(batch=query_batch, model=model)
+            (measurement * scale if scale != 1.0 else measurement).backward()
+        if factor_args.has_shared_parameters:
+            finalize_iteration(model, tracked_module_names)
+        if state.use_distributed:
+            synchronize_modules(model, tracked_module_names, num_processes=state.num_processes)  # C4
+            if query_index == num_batches - 1 and query_remainder > 0:
+                truncate(model, tracked_module_names, keep_size=query_remainder)
+        accumulate_iterations(model, tracked_module_names)
+        del query_batch, measurement
+        held += 1
+        if held < score_args.query_gradient_accumulation_steps and query_index != num_batches - 1:
+            continue
+        scores = compute_dot_products_with_loader(model=model, state=state, task=task, train_loader=train_loader,
+                                                  factor_args=factor_args, score_args=score_args,
+                                                  tracked_module_names=tracked_module_names, loss_scale=scale)
+        if state.is_main_process:
+            for key, value in scores.items():
+                chunks.setdefault(key, []).append(value)
+        del scores
+        state.wait_for_everyone()
+        held = 0
+
+    total: SCORE_TYPE = {}
+    if state.is_main_process:
+        total = {key: torch.cat(parts, dim=0) for key, parts in chunks.items()}
+    model.zero_grad(set_to_none=True)
+    set_gradient_scale(model, 1.0)
+    finalize_all_iterations(model, tracked_module_names)
+    set_mode(model, ModuleMode.DEFAULT, release_memory=True)
+    state.wait_for_everyone()
+    return total

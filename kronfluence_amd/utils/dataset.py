@@ -1,0 +1,119 @@
+"""Dataset plumbing: loader kwargs, index partitions, and the two samplers that define how the
+training set is sharded over ranks (reference ``utils/dataset.py:104-199``).
+
+* ``DistributedEvalSampler``: strided shard ``rank, rank+P, ...`` with NO padding -- used for factor
+  fitting so that counts are exact.
+* ``DistributedSamplerWithStack``: contiguous chunk of ``ceil(N/P)`` per rank, wrap-around padded --
+  used for the train side of pairwise scoring so that rank blocks concatenate in dataset order.
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+from torch.utils import data
+
+
+@dataclass
+class DataLoaderKwargs:
+    num_workers: int = 0
+    collate_fn: Optional[Callable] = None
+    pin_memory: bool = False
+    timeout: int = 0
+    worker_init_fn: Optional[Callable] = None
+    multiprocessing_context: Optional[Any] = None
+    generator: Optional[torch.Generator] = None
+    prefetch_factor: Optional[int] = None
+    persistent_workers: bool = False
+    pin_memory_device: str = ""
+
+    def to_dict(self) -> Dict[str, Any]:
+        return dict(vars(self))
+
+
+def make_indices_partition(total_data_examples: int, partition_size: int) -> List[Tuple[int, int]]:
+    """``[start, end)`` ranges of near-equal size; the last one absorbs the remainder."""
+    if total_data_examples < partition_size:
+        raise ValueError("The total data examples must be equal to or greater than the partition size.")
+    base = total_data_examples // partition_size
+    bounds = [(i * base, (i + 1) * base) for i in range(partition_size)]
+    bounds[-1] = (bounds[-1][0], total_data_examples)
+    return bounds
+
+
+def find_batch_size(batch: Any) -> int:
+    """Leading dimension of the first tensor found in a (possibly nested) batch."""
+    if isinstance(batch, torch.Tensor):
+        return batch.shape[0]
+    if isinstance(batch, dict):
+        for value in batch.values():
+            size = find_batch_size(value)
+            if size is not None:
+                return size
+    if isinstance(batch, (list, tuple)):
+        for value in batch:
+            size = find_batch_size(value)
+            if size is not None:
+                return size
+    return None
+
+
+def send_to_device(batch: Any, device: torch.device) -> Any:
+    if isinstance(batch, torch.Tensor):
+        return batch.to(device, non_blocking=True)
+    if isinstance(batch, dict):
+        return type(batch)({k: send_to_device(v, device) for k, v in batch.items()})
+    if isinstance(batch, (list, tuple)):
+        return type(batch)(send_to_device(v, device) for v in batch)
+    return batch
+
+
+def _resolve(num_replicas: Optional[int], rank: Optional[int]) -> Tuple[int, int]:
+    if num_replicas is None or rank is None:
+        if not (dist.is_available() and dist.is_initialized()):
+            raise RuntimeError("Requires an initialised torch.distributed process group.")
+        num_replicas = dist.get_world_size() if num_replicas is None else num_replicas
+        rank = dist.get_rank() if rank is None else rank
+    if not 0 <= rank < num_replicas:
+        raise ValueError(f"Invalid rank {rank}, rank should be in the interval [0, {num_replicas - 1}].")
+    return num_replicas, rank
+
+
+class DistributedEvalSampler(data.Sampler):
+    """Every ``P``-th example starting at ``rank``; shards are disjoint and cover the dataset once."""
+
+    def __init__(self, dataset: data.Dataset, num_replicas: Optional[int] = None, rank: Optional[int] = None,
+                 seed: int = 0) -> None:
+        self.num_replicas, self.rank = _resolve(num_replicas, rank)
+        self.dataset, self.seed = dataset, seed
+        self.total_size = len(dataset)
+        self.num_samples = len(range(self.rank, self.total_size, self.num_replicas))
+
+    def __iter__(self) -> Iterator[int]:
+        return iter(range(self.rank, self.total_size, self.num_replicas))
+
+    def __len__(self) -> int:
+        return self.num_samples
+
+
+class DistributedSamplerWithStack(data.Sampler):
+    """Rank ``r`` gets the contiguous block ``[r*c, (r+1)*c)`` of the wrap-padded index list, ``c = ceil(N/P)``."""
+
+    def __init__(self, dataset: data.Dataset, num_replicas: Optional[int] = None, rank: Optional[int] = None,
+                 seed: int = 0) -> None:
+        self.num_replicas, self.rank = _resolve(num_replicas, rank)
+        self.dataset, self.seed, self.epoch = dataset, seed, 0
+        self.num_samples = math.ceil(len(dataset) / self.num_replicas)
+        self.total_size = self.num_samples * self.num_replicas
+
+    def __iter__(self) -> Iterator[int]:
+        n = len(self.dataset)
+        start = self.rank * self.num_samples
+        return iter([(start + j) % n for j in range(self.num_samples)])
+
+    def __len__(self) -> int:
+        return self.num_samples

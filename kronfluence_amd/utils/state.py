@@ -1,0 +1,89 @@
+"""Process / device state: one process per MI355X, ``torch.distributed`` over RCCL (backend string
+"nccl" on ROCm) when launched by ``torchrun``.  Counterpart of the reference's ``utils/state.py``
+(rank, device, barrier) without the accelerate dependency."""
+
+from __future__ import annotations
+
+import contextlib
+import gc
+import os
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+
+class State:
+    """Shared (Borg) view of the launch environment."""
+
+    _shared: dict = {}
+
+    def __init__(self, cpu: bool = False) -> None:
+        self.__dict__ = State._shared
+        if getattr(self, "initialized", False):
+            if cpu and self.device.type != "cpu":
+                raise ValueError("State was already initialised on a GPU; cannot switch to `cpu=True`.")
+            return
+        self.cpu = cpu
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "-1"))
+        if dist.is_available() and dist.is_initialized():
+            self.num_processes, self.process_index = dist.get_world_size(), dist.get_rank()
+            self.local_process_index = max(local_rank, 0)
+        elif world > 1 and local_rank >= 0:
+            backend = "gloo" if cpu or not torch.cuda.is_available() else "nccl"  # "nccl" == RCCL on ROCm
+            if backend == "nccl":
+                torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend=backend)
+            self.num_processes, self.process_index = dist.get_world_size(), dist.get_rank()
+            self.local_process_index = local_rank
+        else:
+            self.num_processes, self.process_index, self.local_process_index = 1, 0, 0
+        if cpu or not torch.cuda.is_available():
+            self.device = torch.device("cpu")
+        else:
+            self.device = torch.device("cuda", self.local_process_index if self.num_processes > 1 else torch.cuda.current_device())
+            torch.cuda.set_device(self.device)
+        self.initialized = True
+
+    def __repr__(self) -> str:
+        return (f"State(num_processes={self.num_processes}, process_index={self.process_index}, "
+                f"local_process_index={self.local_process_index}, device={self.device})")
+
+    @classmethod
+    def _reset_state(cls) -> None:
+        cls._shared.clear()
+
+    @property
+    def use_distributed(self) -> bool:
+        return self.num_processes > 1
+
+    @property
+    def is_main_process(self) -> bool:
+        return self.process_index == 0
+
+    @property
+    def is_local_main_process(self) -> bool:
+        return self.local_process_index == 0
+
+    def wait_for_everyone(self) -> None:
+        if self.use_distributed:
+            dist.barrier()
+
+
+def release_memory() -> None:
+    gc.collect()
+    if torch.cuda.is_available():
+        torch.cuda.empty_cache()
+
+
+@contextlib.contextmanager
+def no_sync(model: torch.nn.Module, state: Optional[State] = None):
+    """Every parameter is frozen (``prepare_model``), so a DDP wrapper never has gradients to
+    all-reduce; kept for API symmetry with the reference (utils/state.py:142-165)."""
+    ctx = getattr(model, "no_sync", None)
+    if callable(ctx):
+        with ctx():
+            yield
+    else:
+        yield

@@ -1,0 +1,221 @@
+"""GPU parity of every C-ABI entry point against the CPU oracle on identical seeded inputs.
+
+Tolerances (stated per the north star): fp32 factors/scores ``rel_F <= 2e-5`` against the oracle run
+in fp64 on the same (fp32-representable) inputs; bf16/fp16 inputs are converted exactly to fp32
+by the kernels, so the same bound applies against the oracle fed the up-cast inputs.
+"""
+
+import math
+
+import pytest
+import torch
+from torch import nn
+
+from oracle import ekfac_ref as ref
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = 2e-5
+
+
+def rel(a: torch.Tensor, b: torch.Tensor) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-300))
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from kronfluence_amd import ops as _ops
+
+    return _ops
+
+
+def _rand(*shape, dtype=torch.float32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g).to(dtype)
+
+
+# ---- stage 1 -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,bias", [(1, 1, False), (37, 5, True), (300, 129, True), (1000, 785, True), (513, 256, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_linear_activation_cov(ops, n, d, bias, dtype):
+    x = _rand(n, d, dtype=dtype)
+    want = torch.zeros(d + bias, d + bias, dtype=torch.float64)
+    flat, count = ref.linear_flat_activation(x.double(), None, bias)
+    ref.covariance_update(want, flat)
+    cov = torch.zeros(d + bias, d + bias, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for _ in range(2):  # accumulate twice: checks "+="
+        ops.linear_activation_cov(cov, cnt, x.to(DEV), None, bias)
+    assert rel(cov, 2 * want) <= TOL
+    assert int(cnt) == 2 * count
+    assert rel(cov, cov.t()) <= 1e-6  # split-K atomics: symmetric up to fp32 summation order
+
+
+@pytest.mark.parametrize("mask_dtype", [torch.int64, torch.float32, torch.bool])
+def test_linear_activation_cov_masked_sequence(ops, mask_dtype):
+    b, t, d = 7, 19, 33
+    x = _rand(b, t, d)
+    lengths = torch.randint(1, t + 1, (b,), generator=torch.Generator().manual_seed(3))
+    mask = (torch.arange(t)[None] < lengths[:, None]).to(mask_dtype)
+    flat, count = ref.linear_flat_activation(x.double(), mask.double(), True)
+    want = torch.zeros(d + 1, d + 1, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    cov = torch.zeros(d + 1, d + 1, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.linear_activation_cov(cov, cnt, x.to(DEV), mask.to(DEV), True)
+    assert rel(cov, want) <= TOL
+    assert int(cnt) == int(count)
+    # gradient side: rows un-masked, count masked (linear.py:48-54)
+    g = _rand(b, t, 11, seed=5)
+    gcov = torch.zeros(11, 11, device=DEV)
+    gcnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.linear_gradient_cov(gcov, gcnt, g.to(DEV), mask.to(DEV), alpha=4.0)
+    gflat, gcount = ref.linear_flat_gradient(g.double(), mask.double())
+    gwant = torch.zeros(11, 11, dtype=torch.float64)
+    ref.covariance_update(gwant, gflat, alpha=4.0)
+    assert rel(gcov, gwant) <= TOL and int(gcnt) == int(gcount)
+
+
+CONVS = [
+    dict(cin=3, cout=4, k=3, stride=1, padding=1, dilation=1, groups=1, bias=False, hw=(8, 8)),
+    dict(cin=4, cout=8, k=5, stride=2, padding=2, dilation=1, groups=1, bias=True, hw=(9, 7)),
+    dict(cin=8, cout=6, k=3, stride=1, padding=1, dilation=2, groups=2, bias=True, hw=(8, 8)),
+    dict(cin=6, cout=6, k=(3, 2), stride=(2, 1), padding=(0, 1), dilation=1, groups=1, bias=False, hw=(10, 6)),
+    dict(cin=4, cout=4, k=3, stride=1, padding="same", dilation=1, groups=1, bias=True, hw=(6, 6)),
+]
+
+
+def _conv(c):
+    return nn.Conv2d(c["cin"], c["cout"], c["k"], stride=c["stride"], padding=c["padding"], dilation=c["dilation"],
+                     groups=c["groups"], bias=c["bias"])
+
+
+@pytest.mark.parametrize("c", CONVS)
+def test_conv_covariances(ops, c):
+    conv = _conv(c).double()
+    b = 5
+    x = _rand(b, c["cin"], *c["hw"])
+    flat, count = ref.conv_flat_activation(x.double(), conv)
+    d = flat.shape[1]
+    want = torch.zeros(d, d, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    patches = ops.im2col(x.to(DEV), conv, conv.bias is not None)
+    assert rel(patches.reshape(-1, d), flat) <= 1e-6
+    cov = torch.zeros(d, d, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.conv_activation_cov(cov, cnt, x.to(DEV), conv)
+    assert rel(cov, want) <= TOL and int(cnt) == count
+
+    out = conv(x.double())
+    g = _rand(*out.shape, seed=9)
+    gflat, gcount = ref.conv_flat_gradient(g.double())
+    gwant = torch.zeros(c["cout"], c["cout"], dtype=torch.float64)
+    ref.covariance_update(gwant, gflat)
+    gcov = torch.zeros(c["cout"], c["cout"], device=DEV)
+    gcnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.conv_gradient_cov(gcov, gcnt, g.to(DEV))
+    assert rel(gcov, gwant) <= TOL and int(gcnt) == gcount
+
+
+# ---- GEMM building block -------------------------------------------------------------------------
+@pytest.mark.parametrize("n,d,m,ones", [(5, 7, 3, False), (300, 129, 130, True), (1000, 1024, 1025, True)])
+def test_matmul_nn_asymmetric(ops, n, d, m, ones):
+    x, w = _rand(n, d), _rand(d + ones, m, seed=1)
+    xx = torch.cat([x, torch.ones(n, 1)], 1) if ones else x
+    got = ops.matmul_nn(x.to(DEV), w.to(DEV), append_ones=ones)
+    assert rel(got, xx.double() @ w.double()) <= TOL
+
+
+@pytest.mark.parametrize("b,r,o,i,bias", [(3, 1, 5, 7, True), (4, 9, 33, 17, True), (2, 200, 130, 64, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_per_sample_gradient(ops, b, r, o, i, bias, dtype):
+    g, a = _rand(b, r, o, dtype=dtype), _rand(b, r, i, dtype=dtype, seed=1)
+    want = ref.linear_per_sample_gradient(a.double(), g.double(), bias)
+    got = ops.per_sample_gradient(g.to(DEV), a.to(DEV), bias)
+    assert got.shape == want.shape and rel(got, want) <= TOL
+
+
+# ---- stage 2 -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,n", [(1, 5), (2, 9), (17, 100), (64, 40), (129, 1000), (300, 150)])
+def test_eigh_invariants_and_values(ops, d, n):
+    x = _rand(n, d).double()
+    cov = (x.t() @ x).float()
+    evals, evecs, sweeps = ops.eigh(cov.to(DEV), float(n))
+    count = torch.tensor([n])
+    inv = ref.eigh_invariants(cov, count, evals.cpu(), evecs.cpu())
+    assert inv["orthogonality"] < 1e-12 and inv["reconstruction"] < 1e-12 and inv["ascending"] == 0.0, (inv, sweeps)
+    want, _ = ref.eigendecompose(cov.double(), count)
+    scale = want.abs().max()
+    assert float((evals.cpu() - want).abs().max() / scale) < 1e-10
+
+
+def test_eigh_fp64_input_and_asymmetric_noise(ops):
+    x = _rand(50, 20).double()
+    cov = x.t() @ x
+    cov[3, 7] += 1e-3  # the reference symmetrises (eigen.py:201-203)
+    evals, evecs, _ = ops.eigh(cov.to(DEV), 50.0)
+    want, _ = ref.eigendecompose(cov, torch.tensor([50]))
+    assert float((evals.cpu() - want).abs().max() / want.abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("b,r,o,i", [(6, 1, 16, 13), (5, 7, 33, 130), (3, 40, 129, 65), (300, 1, 200, 257)])
+def test_lambda_accum(ops, b, r, o, i):
+    g, a = _rand(b, r, o), _rand(b, r, i, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0]
+    q_a = torch.linalg.qr(_rand(i, i, seed=3).double())[0]
+    psg = ref.linear_per_sample_gradient(a.double(), g.double(), False) * 0.5
+    want = torch.zeros(o, i, dtype=torch.float64)
+    ref.lambda_update(want, psg, q_a, q_g)
+    gt = ops.matmul_nn(g.reshape(b * r, o).to(DEV), q_g.float().to(DEV))
+    at = ops.matmul_nn(a.reshape(b * r, i).to(DEV), q_a.float().to(DEV))
+    lam = torch.zeros(o, i, device=DEV)
+    ops.lambda_accum(lam, gt, at, b, r, scale=0.5)
+    assert rel(lam, want) <= 5e-5
+
+
+# ---- stage 3 -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("damping", [1e-8, None, 1e-3])
+def test_inv_lambda(ops, damping):
+    lam = _rand(37, 53).abs() * 100
+    want = ref.ekfac_inverse_lambda(lam, torch.tensor([40]), damping, torch.float32)
+    got = ops.inv_lambda(lam.to(DEV), 40.0, damping)
+    assert rel(got, want) <= 1e-6
+
+
+@pytest.mark.parametrize("q,r,o,i,bias", [(3, 1, 16, 12, True), (4, 6, 33, 65, True), (2, 50, 129, 40, False)])
+def test_precondition(ops, q, r, o, i, bias):
+    ip = i + bias
+    g, a = _rand(q, r, o), _rand(q, r, i, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0]
+    q_a = torch.linalg.qr(_rand(ip, ip, seed=3).double())[0]
+    lam_inv = _rand(o, ip, seed=4).abs().double() + 0.1
+    psg = ref.linear_per_sample_gradient(a.double(), g.double(), bias)
+    want = ref.ekfac_precondition(psg, q_a, q_g, lam_inv) * 2.0
+    got = ops.precondition(g.to(DEV), a.to(DEV), bias, q_g.float().to(DEV), q_a.float().to(DEV), lam_inv.float().to(DEV), scale=2.0)
+    assert rel(got, want) <= TOL
+
+
+@pytest.mark.parametrize("q,b,r,o,i,bias", [(3, 5, 1, 16, 12, True), (100, 250, 1, 130, 257, True), (7, 9, 6, 33, 20, True),
+                                             (5, 3, 40, 65, 129, False)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pairwise_score(ops, q, b, r, o, i, bias, dtype):
+    p = _rand(q, o, i + bias, seed=7)
+    g, a = _rand(b, r, o, dtype=dtype), _rand(b, r, i, dtype=dtype, seed=1)
+    if r == 1:
+        want = ref.linear_pairwise_score(p.double(), a[:, 0].double(), g[:, 0].double(), bias)
+    else:
+        want = ref.linear_pairwise_score(p.double(), a.double(), g.double(), bias)
+    scores = torch.zeros(q, b + 4, device=DEV)
+    ops.pairwise_score(scores, 2, p.to(DEV), g.to(DEV), a.to(DEV), bias, scale=1.0)
+    ops.pairwise_score(scores, 2, p.to(DEV), g.to(DEV), a.to(DEV), bias, scale=0.5)  # "+=" across layers
+    assert rel(scores[:, 2:2 + b], 1.5 * want) <= TOL
+    assert float(scores[:, :2].abs().max()) == 0.0 and float(scores[:, 2 + b:].abs().max()) == 0.0
+
+
+def test_cpu_tensors_fail_loudly(ops):
+    from kronfluence_amd._native import KfError
+
+    with pytest.raises(KfError):
+        ops.eigh(torch.eye(3), 1.0)
