@@ -128,7 +128,7 @@ int kf_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view* A, con
  * syevd).  evals[d] ascending, evecs[d,d] row-major with eigenvectors in COLUMNS (torch
  * convention), both fp64; the host casts back to the covariance dtype (eigen.py:214-219).
  * cov is fp32 or fp64 [d,d]; count is a host value.  workspace: device, at least
- * kf_eigh_workspace_bytes(d) bytes.  max_sweeps <= 0 selects the default (30).
+ * kf_eigh_workspace_bytes(d) bytes.  max_sweeps <= 0 selects the default (100).
  * One-sided (Hestenes) Jacobi with a round-robin pair schedule; this call synchronises `stream`
  * once per sweep to read the convergence flag.
  */

@@ -11,6 +11,8 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -48,7 +50,7 @@ __global__ void eigh_init_kernel(double* Wt, double* Vt, const void* cov, int is
 // One round of the tournament: block k rotates the pair (p, q) of round `round`.
 // npl = number of "players" (d rounded up to even); player npl-1 may be a bye when d is odd.
 __global__ __launch_bounds__(EB) void jacobi_round_kernel(double* Wt, double* Vt, int64_t d, int npl, int round,
-                                                          double tol, int* rotated) {
+                                                          double tol, double null2, int* rotated) {
     __shared__ double scratch[4];
     const int k = blockIdx.x;
     int p, q;
@@ -68,11 +70,15 @@ __global__ __launch_bounds__(EB) void jacobi_round_kernel(double* Wt, double* Vt
     gamma = block_sum(gamma, scratch);
     const double lim = tol * sqrt(alpha) * sqrt(beta);
     if (!(fabs(gamma) > lim)) return;  // uniform across the block (also catches NaN and zero columns)
+    // A column with |S v| <= eps-level * ||S||_F already IS a null vector of S to working precision
+    // (V stays orthonormal whatever we do): rotating noise against anything only burns sweeps.
+    if (alpha <= null2 || beta <= null2) return;
     const double zeta = (beta - alpha) / (2.0 * gamma);
     const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
     const double c = 1.0 / sqrt(1.0 + t * t), s = c * t;
     double* vp = Vt + static_cast<int64_t>(p) * d;
     double* vq = Vt + static_cast<int64_t>(q) * d;
+    // (No de Rijk column swap: combined with the parallel round-robin order it stalls -- measured.)
     for (int64_t i = threadIdx.x; i < d; i += EB) {
         const double x = wp[i], y = wq[i];
         wp[i] = c * x - s * y; wq[i] = s * x + c * y;
@@ -80,6 +86,15 @@ __global__ __launch_bounds__(EB) void jacobi_round_kernel(double* Wt, double* Vt
         vp[i] = c * u - s * v; vq[i] = s * u + c * v;
     }
     if (threadIdx.x == 0) atomicAdd(rotated, 1);
+}
+
+// out[0] = ||W||_F^2 (single block)
+__global__ __launch_bounds__(EB) void frob2_kernel(double* out, const double* W, int64_t total) {
+    __shared__ double scratch[4];
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < total; i += EB) s += W[i] * W[i];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
 }
 
 // lambda_j = v_j . w_j
@@ -138,7 +153,7 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
     if (workspace_bytes < kf_eigh_workspace_bytes(d)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (d >= (1 << 24)) return KF_ERR_INVALID_ARGUMENT;
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-    if (max_sweeps <= 0) max_sweeps = 30;
+    if (max_sweeps <= 0) max_sweeps = 100;
     double* Wt = reinterpret_cast<double*>(workspace);
     double* Vt = Wt + d * d;
     double* lam = Vt + d * d;
@@ -148,18 +163,28 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
     const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((d * d + 255) / 256, 4096)));
     hipLaunchKernelGGL(eigh_init_kernel, dim3(g), dim3(256), 0, st, Wt, Vt, cov, cov_dtype == KF_F64 ? 1 : 0, count, d);
 
+    // ||S||_F^2 -> threshold below which a column of W = S V counts as numerically null
+    hipLaunchKernelGGL(frob2_kernel, dim3(1), dim3(EB), 0, st, lam, Wt, d * d);
+    double frob2 = 0.0;
+    if (hipMemcpyAsync(&frob2, lam, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    const double eps = 2.220446049250313e-16;
+    const double null2 = frob2 * (eps * eps) * static_cast<double>(d);
+
     const int npl = static_cast<int>(d + (d & 1));
     const int pairs = npl / 2, rounds = npl - 1;
     const double tol = 4.0 * 2.220446049250313e-16 * sqrt(static_cast<double>(d));
     int sweeps = 0, status = KF_ERR_NOT_CONVERGED;
+    const bool verbose = getenv("KF_EIGH_VERBOSE") != nullptr;
     if (d == 1) { status = KF_OK; }
     for (; d > 1 && sweeps < max_sweeps; ++sweeps) {
         if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
         for (int r = 0; r < rounds; ++r)
-            hipLaunchKernelGGL(jacobi_round_kernel, dim3(pairs), dim3(EB), 0, st, Wt, Vt, d, npl, r, tol, flag);
+            hipLaunchKernelGGL(jacobi_round_kernel, dim3(pairs), dim3(EB), 0, st, Wt, Vt, d, npl, r, tol, null2, flag);
         int host_flag = 1;
         if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
         if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        if (verbose) fprintf(stderr, "[kf_eigh] d=%lld sweep %d: %d rotations\n", static_cast<long long>(d), sweeps, host_flag);
         if (host_flag == 0) { status = KF_OK; ++sweeps; break; }
     }
     if (sweeps_done) *sweeps_done = sweeps;

@@ -37,25 +37,73 @@ __device__ __forceinline__ float load_f32(const void* p, int dtype, int64_t idx)
     }
 }
 
-// Strided 2-D operand view for one batch index: element (r, k).
+// Compile-time dtype loads: no branch in the instruction stream, so the FETCH loads of a k-step
+// stay in one basic block and are issued back to back under a single s_waitcnt.
+template <int DT> __device__ __forceinline__ float load_t(const void* p, int64_t idx);
+template <> __device__ __forceinline__ float load_t<F32>(const void* p, int64_t idx) {
+    return reinterpret_cast<const float*>(p)[idx];
+}
+template <> __device__ __forceinline__ float load_t<BF16>(const void* p, int64_t idx) {
+    return __uint_as_float(static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(p)[idx]) << 16);
+}
+template <> __device__ __forceinline__ float load_t<F16>(const void* p, int64_t idx) {
+    return static_cast<float>(reinterpret_cast<const _Float16*>(p)[idx]);
+}
+template <> __device__ __forceinline__ float load_t<I64>(const void* p, int64_t idx) {
+    return static_cast<float>(reinterpret_cast<const int64_t*>(p)[idx]);
+}
+template <> __device__ __forceinline__ float load_t<U8>(const void* p, int64_t idx) {
+    return static_cast<float>(reinterpret_cast<const uint8_t*>(p)[idx]);
+}
+
+// Raw (unconverted) loads: the mainloop issues them at the top of a k-step and converts / masks
+// them only when staging into LDS, after the MFMA block, so HBM/L2 latency hides under the MFMAs.
+template <int DT> struct RawOf { typedef uint32_t type; };
+template <> struct RawOf<BF16> { typedef uint16_t type; };
+template <> struct RawOf<F16> { typedef uint16_t type; };
+template <> struct RawOf<I64> { typedef int64_t type; };
+template <> struct RawOf<U8> { typedef uint8_t type; };
+template <int DT> __device__ __forceinline__ typename RawOf<DT>::type load_raw(const void* p, int64_t idx) {
+    return reinterpret_cast<const typename RawOf<DT>::type*>(p)[idx];
+}
+template <int DT> __device__ __forceinline__ float raw_to_f32(typename RawOf<DT>::type v);
+template <> __device__ __forceinline__ float raw_to_f32<F32>(uint32_t v) { return __uint_as_float(v); }
+template <> __device__ __forceinline__ float raw_to_f32<BF16>(uint16_t v) { return __uint_as_float(static_cast<uint32_t>(v) << 16); }
+template <> __device__ __forceinline__ float raw_to_f32<F16>(uint16_t v) {
+    _Float16 h;
+    __builtin_memcpy(&h, &v, 2);
+    return static_cast<float>(h);
+}
+template <> __device__ __forceinline__ float raw_to_f32<I64>(int64_t v) { return static_cast<float>(v); }
+template <> __device__ __forceinline__ float raw_to_f32<U8>(uint8_t v) { return static_cast<float>(v); }
+
+// Strided 2-D operand view for one batch index: element (r, k).  Out-of-range indices are read
+// from a clamped (always valid) address and replaced by a select -- never by a branch.
+// Requires rows_total >= 1 and depth >= 1 (checked on the host); `rows` is tile-relative and may
+// be 0 for the tile that holds only the virtual ones row (the clamp then reads row -1, which is
+// the last real row of the matrix).
+template <int DT>
 struct StridedLoader {
     const void* p;
-    int dtype;
     int64_t row_stride, k_stride;
     int rows, depth;       // real extents; indices beyond (plus the optional ones) read 0
     int ones_row, ones_k;  // virtual index rows / depth reads 1.0 (un-masked bias column)
     int square;
     int contig_k;          // memory is contiguous along k (else along rows): picks the lane mapping
 
-    __device__ __forceinline__ float get(int r, int k) const {
+    typedef typename RawOf<DT>::type Raw;
+
+    __device__ __forceinline__ Raw fetch(int r, int k) const {
+        const int rc = r < rows ? r : rows - 1, kc = k < depth ? k : depth - 1;
+        return load_raw<DT>(p, static_cast<int64_t>(rc) * row_stride + static_cast<int64_t>(kc) * k_stride);
+    }
+    __device__ __forceinline__ float value(Raw raw, int r, int k) const {
         const bool r_real = r < rows, k_real = k < depth;
-        if (r_real && k_real) {
-            const float x = load_f32(p, dtype, static_cast<int64_t>(r) * row_stride + static_cast<int64_t>(k) * k_stride);
-            return square ? x * x : x;
-        }
+        float x = raw_to_f32<DT>(raw);
+        x = square ? x * x : x;
         const bool r_one = ones_row && r == rows, k_one = ones_k && k == depth;
-        if ((r_one && (k_real || k_one)) || (k_one && r_real)) return 1.0f;
-        return 0.0f;
+        const bool one = (r_one && (k_real || k_one)) || (k_one && r_real);
+        return (r_real && k_real) ? x : (one ? 1.0f : 0.0f);
     }
 };
 
@@ -96,26 +144,31 @@ __device__ __forceinline__ void mainloop(const LA& la, const LB& lb, int k_begin
         if (lb.contig_k) { bk[j] = tid % BK; br[j] = tid / BK + (NTHREADS / BK) * j; }
         else             { br[j] = tid % BN; bk[j] = tid / BN + (NTHREADS / BN) * j; }
     }
-    float ra[FETCH], rb[FETCH];
+    typename LA::Raw ra[FETCH];
+    typename LB::Raw rb[FETCH];
+    // fetch: raw loads only (clamped addresses, no branch, no consumer) -- issued back to back
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int j = 0; j < FETCH; ++j) {
-            const int ka = kt + ak[j], kb = kt + bk[j];
-            ra[j] = ka < k_end ? la.get(ar[j], ka) : 0.0f;
-            rb[j] = kb < k_end ? lb.get(br[j], kb) : 0.0f;
+            ra[j] = la.fetch(ar[j], min(kt + ak[j], k_end - 1));
+            rb[j] = lb.fetch(br[j], min(kt + bk[j], k_end - 1));
         }
     };
-    auto stash = [&](int buf) {
+    // stash: convert / mask / zero-fill the raw values of k-tile `kt` and stage them in LDS
+    auto stash = [&](int buf, int kt) {
 #pragma unroll
         for (int j = 0; j < FETCH; ++j) {
-            sA[(buf * BK + ak[j]) * LDT + ar[j]] = ra[j];
-            sB[(buf * BK + bk[j]) * LDT + br[j]] = rb[j];
+            const int ka = kt + ak[j], kb = kt + bk[j];
+            const float va = la.value(ra[j], ar[j], min(ka, k_end - 1));
+            const float vb = lb.value(rb[j], br[j], min(kb, k_end - 1));
+            sA[(buf * BK + ak[j]) * LDT + ar[j]] = ka < k_end ? va : 0.0f;
+            sB[(buf * BK + bk[j]) * LDT + br[j]] = kb < k_end ? vb : 0.0f;
         }
     };
 
     if (k_begin >= k_end) return;
     fetch(k_begin);
-    stash(0);
+    stash(0, k_begin);
     __syncthreads();
     int buf = 0;
     for (int kt = k_begin; kt < k_end; kt += BK) {
@@ -132,7 +185,7 @@ __device__ __forceinline__ void mainloop(const LA& la, const LB& lb, int k_begin
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-        if (more) stash(buf ^ 1);
+        if (more) stash(buf ^ 1, kt + BK);
         __syncthreads();
         buf ^= 1;
     }

@@ -59,13 +59,13 @@ struct GemmArgs {
     int atomic;         // accumulate with atomicAdd (split-K or batch-summing); beta pre-applied
 };
 
-__device__ __forceinline__ StridedLoader make_loader(const kf_view& v, int64_t z, int row0, int contig_k) {
-    StridedLoader l;
-    l.dtype = v.dtype;
+template <int DT>
+__device__ __forceinline__ StridedLoader<DT> make_loader(const kf_view& v, int64_t z, int row0, int contig_k) {
+    StridedLoader<DT> l;
     l.row_stride = v.row_stride;
     l.k_stride = v.k_stride;
     const int64_t off = z * v.batch_stride + static_cast<int64_t>(row0) * v.row_stride;
-    l.p = reinterpret_cast<const char*>(v.p) + off * (v.dtype == F32 ? 4 : (v.dtype == F64 ? 8 : 2));
+    l.p = reinterpret_cast<const char*>(v.p) + off * (DT == F32 ? 4 : 2);
     l.rows = static_cast<int>(v.rows) - row0;  // >= 0: row0 <= rows whenever a tile exists
     l.depth = static_cast<int>(v.depth);
     l.ones_row = v.ones_row;
@@ -75,14 +75,15 @@ __device__ __forceinline__ StridedLoader make_loader(const kf_view& v, int64_t z
     return l;
 }
 
+template <int DTA, int DTB>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs a) {
     __shared__ float smem[SMEM_FLOATS];
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * BM;
     const int z = blockIdx.z / a.ksplit, ks = blockIdx.z % a.ksplit;
     const int k_begin = ks * a.kchunk;
     const int k_end = min(a.K, k_begin + a.kchunk);
-    StridedLoader la = make_loader(a.A, z, m0, a.A.k_stride == 1);
-    StridedLoader lb = make_loader(a.B, z, n0, a.B.k_stride == 1);
+    StridedLoader<DTA> la = make_loader<DTA>(a.A, z, m0, a.A.k_stride == 1);
+    StridedLoader<DTB> lb = make_loader<DTB>(a.B, z, n0, a.B.k_stride == 1);
     f32x16 acc[2][2];
     zero_acc(acc);
     mainloop(la, lb, k_begin, k_end, acc, smem);
@@ -119,8 +120,14 @@ __global__ void scale_matrix_kernel(float* C, int64_t ldc, int64_t batch_stride,
 int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
                 int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, hipStream_t st) {
     if (!C || !A.p || !B.p || batch < 0) return KF_ERR_INVALID_ARGUMENT;
-    if (!float_dtype(A.dtype) || !float_dtype(B.dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    // supported operand dtype pairs: (f32|bf16|f16, f32) and (x, x)
+    const bool a_ok = A.dtype == KF_F32 || A.dtype == KF_BF16 || A.dtype == KF_F16;
+    if (!a_ok || !(B.dtype == KF_F32 || B.dtype == A.dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
     if (A.depth + A.ones_k != B.depth + B.ones_k) return KF_ERR_INVALID_ARGUMENT;
+    if (A.rows < 1 || B.rows < 1 || A.depth < 1 || B.depth < 1) {
+        // degenerate (empty real extent): the clamped loads of the engine need >= 1 real row / column
+        return (A.rows + A.ones_row <= 0 || B.rows + B.ones_row <= 0 || batch == 0) ? KF_OK : KF_ERR_INVALID_ARGUMENT;
+    }
     const int64_t M = A.rows + A.ones_row, N = B.rows + B.ones_row, K = A.depth + A.ones_k;
     if (M <= 0 || N <= 0 || batch == 0) return KF_OK;
     if (M >= (1LL << 30) || N >= (1LL << 30) || K >= (1LL << 30)) return KF_ERR_INVALID_ARGUMENT;
@@ -149,46 +156,82 @@ int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A,
     a.ksplit = static_cast<int>(ksplit); a.kchunk = static_cast<int>(kchunk);
     a.alpha = alpha; a.beta = beta; a.mul = mul; a.ld_mul = ld_mul; a.atomic = atomic ? 1 : 0;
     dim3 grid(static_cast<unsigned>(cdiv(N, BN)), static_cast<unsigned>(cdiv(M, BM)), static_cast<unsigned>(batch * ksplit));
-    hipLaunchKernelGGL(gemm_kernel, grid, dim3(NTHREADS), 0, st, a);
+    if (A.dtype == KF_F32 && B.dtype == KF_F32) hipLaunchKernelGGL((gemm_kernel<F32, F32>), grid, dim3(NTHREADS), 0, st, a);
+    else if (A.dtype == KF_BF16 && B.dtype == KF_F32) hipLaunchKernelGGL((gemm_kernel<BF16, F32>), grid, dim3(NTHREADS), 0, st, a);
+    else if (A.dtype == KF_F16 && B.dtype == KF_F32) hipLaunchKernelGGL((gemm_kernel<F16, F32>), grid, dim3(NTHREADS), 0, st, a);
+    else if (A.dtype == KF_BF16) hipLaunchKernelGGL((gemm_kernel<BF16, BF16>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<F16, F16>), grid, dim3(NTHREADS), 0, st, a);
     return launch_status();
 }
 
 // ------------------------------------------------------------------------------------------------
 // Stage 1: covariance SYRK with fused flatten / mask / ones column
 // ------------------------------------------------------------------------------------------------
+template <int DT, int MDT>  // MDT: mask dtype, -1 = no mask
 struct SyrkLoader {
+    const void* p;
+    int64_t n_rows, rows_inner, outer_stride, row_stride, col_stride;
+    const void* mask;
+    int d_in, d, col0;   // features [col0, col0+128) of X'
+    int contig_k;
+    // "row" r = feature index (tile-relative), k = sample row.  Branch-free: clamped loads + selects.
+    struct Raw { typename RawOf<DT>::type x; typename RawOf<(MDT >= 0 ? MDT : F32)>::type m; };
+
+    __device__ __forceinline__ Raw fetch(int r, int k) const {
+        const int c = col0 + r;
+        const uint32_t nc = static_cast<uint32_t>(k < n_rows ? k : static_cast<int>(n_rows) - 1);
+        const int cc = c < d_in ? c : d_in - 1;
+        Raw raw;
+        raw.m = 0;
+        if constexpr (MDT >= 0) raw.m = load_raw<MDT>(mask, nc);
+        int64_t off;
+        if (rows_inner >= n_rows) {
+            off = static_cast<int64_t>(nc) * row_stride;
+        } else {
+            const uint32_t inner = static_cast<uint32_t>(rows_inner);
+            const uint32_t hi = nc / inner, lo = nc - hi * inner;
+            off = static_cast<int64_t>(hi) * outer_stride + static_cast<int64_t>(lo) * row_stride;
+        }
+        raw.x = load_raw<DT>(p, off + static_cast<int64_t>(cc) * col_stride);
+        return raw;
+    }
+    __device__ __forceinline__ float value(const Raw& raw, int r, int k) const {
+        const int c = col0 + r;
+        const bool ok = c < d && k < n_rows;
+        float mk = 1.0f;
+        if constexpr (MDT >= 0) mk = raw_to_f32<MDT>(raw.m);
+        const float x = raw_to_f32<DT>(raw.x);
+        const float v = (c == d_in) ? mk : mk * x;  // c == d_in: the ones column (d == d_in + 1)
+        return ok ? v : 0.0f;
+    }
+};
+
+struct SyrkBase {
     const void* p; int dtype;
     int64_t n_rows, rows_inner, outer_stride, row_stride, col_stride;
     const void* mask; int mask_dtype;
-    int d_in, d, col0;   // features [col0, col0+128) of X'
-    int contig_k;
-    // "row" r = feature index (tile-relative), k = sample row
-    __device__ __forceinline__ float get(int r, int k) const {
-        const int c = col0 + r;
-        if (c >= d || k >= n_rows) return 0.0f;
-        const float mk = mask ? load_f32(mask, mask_dtype, k) : 1.0f;
-        if (c == d_in) return mk;  // ones column (only reachable when d == d_in + 1)
-        int64_t off;
-        if (rows_inner >= n_rows) off = static_cast<int64_t>(k) * row_stride;
-        else off = (k / rows_inner) * outer_stride + (k % rows_inner) * row_stride;
-        return mk * load_f32(p, dtype, off + static_cast<int64_t>(c) * col_stride);
-    }
+    int d_in, d, contig_k;
 };
 
 struct SyrkArgs {
     float* C; int64_t ldc;
-    SyrkLoader base;
+    SyrkBase base;
     int tiles, ksplit; int64_t kchunk;
     float alpha; int atomic;
 };
 
+template <int DT, int MDT>
 __global__ __launch_bounds__(NTHREADS) void syrk_kernel(SyrkArgs a) {
     __shared__ float smem[SMEM_FLOATS];
     // upper-triangular tile pair (ti <= tj) from the linear block index
     int t = blockIdx.x, ti = 0;
     while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
     const int tj = ti + t;
-    SyrkLoader la = a.base, lb = a.base;
+    SyrkLoader<DT, MDT> la;
+    la.p = a.base.p; la.n_rows = a.base.n_rows; la.rows_inner = a.base.rows_inner; la.outer_stride = a.base.outer_stride;
+    la.row_stride = a.base.row_stride; la.col_stride = a.base.col_stride; la.mask = a.base.mask;
+    la.d_in = a.base.d_in; la.d = a.base.d; la.contig_k = a.base.contig_k;
+    SyrkLoader<DT, MDT> lb = la;
     la.col0 = ti * BM;
     lb.col0 = tj * BN;
     const int64_t k_begin = static_cast<int64_t>(blockIdx.y) * a.kchunk;
@@ -288,8 +331,8 @@ __global__ __launch_bounds__(NTHREADS) void lambda_kernel(LambdaArgs a) {
     f32x16 sq[2][2];
     zero_acc(sq);
     for (int z = z_begin; z < z_end; ++z) {
-        StridedLoader la, lb;
-        la.p = a.Gt + (static_cast<int64_t>(z) * a.R) * a.O + m0; la.dtype = F32;
+        StridedLoader<F32> la, lb;
+        la.p = a.Gt + (static_cast<int64_t>(z) * a.R) * a.O + m0;
         la.row_stride = 1; la.k_stride = a.O; la.rows = max(a.O - m0, 0); la.depth = a.R;
         la.ones_row = la.ones_k = la.square = 0; la.contig_k = 0;
         lb = la;
@@ -358,16 +401,18 @@ struct ScoreArgs {
     int Q, b, O, I, Ip, append_ones, tiles_per_q; float scale;
 };
 
+template <int DT>
 __global__ __launch_bounds__(NTHREADS) void score_r1_kernel(ScoreArgs a) {
     __shared__ float smem[SMEM_FLOATS];
     const int n0 = blockIdx.x * BN;
     const int q = blockIdx.y / a.tiles_per_q, o0 = (blockIdx.y % a.tiles_per_q) * BM;
-    StridedLoader la, lb;
-    la.p = a.P + (static_cast<int64_t>(q) * a.O + o0) * a.Ip; la.dtype = F32;
+    StridedLoader<F32> la;
+    StridedLoader<DT> lb;
+    la.p = a.P + (static_cast<int64_t>(q) * a.O + o0) * a.Ip;
     la.row_stride = a.Ip; la.k_stride = 1; la.rows = a.O - o0; la.depth = a.Ip;
     la.ones_row = la.ones_k = la.square = 0; la.contig_k = 1;
-    lb.p = reinterpret_cast<const char*>(a.A) + static_cast<int64_t>(n0) * a.I * (a.in_dtype == F32 ? 4 : 2);
-    lb.dtype = a.in_dtype; lb.row_stride = a.I; lb.k_stride = 1; lb.rows = max(a.b - n0, 0); lb.depth = a.I;
+    lb.p = reinterpret_cast<const char*>(a.A) + static_cast<int64_t>(n0) * a.I * (DT == F32 ? 4 : 2);
+    lb.row_stride = a.I; lb.k_stride = 1; lb.rows = max(a.b - n0, 0); lb.depth = a.I;
     lb.ones_row = 0; lb.ones_k = a.append_ones; lb.square = 0; lb.contig_k = 1;
     f32x16 acc[2][2];
     zero_acc(acc);
@@ -379,16 +424,18 @@ __global__ __launch_bounds__(NTHREADS) void score_r1_kernel(ScoreArgs a) {
 #pragma unroll
     for (int tj = 0; tj < 2; ++tj) {
         const int n = n0 + acc_col(wn, tj, lane);
-        if (n < a.b) {
+        const int nc = n < a.b ? n : a.b - 1;  // clamped loads + selects keep the 32 G loads in one batch
 #pragma unroll
-            for (int ti = 0; ti < 2; ++ti)
+        for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int o = o0 + acc_row(wm, ti, r, lane);
-                    if (o < a.O)
-                        colsum[tj] += acc[ti][tj][r] * load_f32(a.G, a.in_dtype, static_cast<int64_t>(n) * a.O + o);
-                }
-        }
+            for (int r = 0; r < 16; ++r) {
+                const int o = o0 + acc_row(wm, ti, r, lane);
+                const int oc = o < a.O ? o : a.O - 1;
+                // multiply by a 0/1 weight (not a select) so the load is unconditional and all 32 batch up
+                const float gv = load_t<DT>(a.G, static_cast<int64_t>(nc) * a.O + oc);
+                const float w = (n < a.b && o < a.O) ? 1.0f : 0.0f;
+                colsum[tj] = fmaf(acc[ti][tj][r] * w, gv, colsum[tj]);
+            }
     }
     // lanes l and l+32 hold the two row halves of the same column
 #pragma unroll
@@ -406,6 +453,12 @@ __global__ __launch_bounds__(NTHREADS) void score_r1_kernel(ScoreArgs a) {
                           a.scale * (colsum[tj] + smem[wn * 64 + tj * 32 + lane]));
         }
     }
+}
+
+void launch_score_r1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
+    if (a.in_dtype == KF_F32) hipLaunchKernelGGL((score_r1_kernel<F32>), grid, dim3(NTHREADS), 0, st, a);
+    else if (a.in_dtype == KF_BF16) hipLaunchKernelGGL((score_r1_kernel<BF16>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((score_r1_kernel<F16>), grid, dim3(NTHREADS), 0, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -463,7 +516,8 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
                   int64_t rows_inner, int64_t outer_stride, int64_t row_stride, int64_t col_stride,
                   const void* mask, int mask_dtype, int append_ones, float alpha, int64_t* count, void* stream) {
     if (!C || !X || n_rows < 0 || d_in <= 0 || rows_inner <= 0) return KF_ERR_INVALID_ARGUMENT;
-    if (!float_dtype(in_dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (in_dtype != KF_F32 && in_dtype != KF_BF16 && in_dtype != KF_F16) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (mask && mask_dtype != KF_F32 && mask_dtype != KF_I64 && mask_dtype != KF_U8) return KF_ERR_UNSUPPORTED_DTYPE;
     if (n_rows >= (1LL << 31) - BK) return KF_ERR_INVALID_ARGUMENT;
     hipStream_t st = as_stream(stream);
     const int64_t d = d_in + (append_ones ? 1 : 0);
@@ -474,10 +528,10 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
     if (n_rows == 0) return launch_status();
     SyrkArgs a;
     a.C = C; a.ldc = ldc;
-    a.base.p = X; a.base.dtype = in_dtype; a.base.n_rows = n_rows; a.base.rows_inner = rows_inner;
+    a.base.p = X; a.base.n_rows = n_rows; a.base.rows_inner = rows_inner;
     a.base.outer_stride = outer_stride; a.base.row_stride = row_stride; a.base.col_stride = col_stride;
-    a.base.mask = mask; a.base.mask_dtype = mask_dtype; a.base.d_in = static_cast<int>(d_in);
-    a.base.d = static_cast<int>(d); a.base.col0 = 0;
+    a.base.mask = mask; a.base.mask_dtype = mask_dtype; a.base.d_in = static_cast<int>(d_in); a.base.dtype = in_dtype;
+    a.base.d = static_cast<int>(d);
     a.base.contig_k = (col_stride != 1);  // lanes walk the contiguous memory direction
     a.tiles = static_cast<int>(cdiv(d, BM));
     const int64_t pairs = static_cast<int64_t>(a.tiles) * (a.tiles + 1) / 2;
@@ -489,7 +543,21 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
     a.ksplit = static_cast<int>(ksplit);
     a.alpha = alpha; a.atomic = ksplit > 1;
     if (ksplit > 65535) return KF_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(syrk_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(ksplit)), dim3(NTHREADS), 0, st, a);
+    const dim3 grid(static_cast<unsigned>(pairs), static_cast<unsigned>(ksplit));
+    const int md = mask ? mask_dtype : -1;
+#define KF_SYRK_CASE(DT, MDT) hipLaunchKernelGGL((syrk_kernel<DT, MDT>), grid, dim3(NTHREADS), 0, st, a)
+#define KF_SYRK_MASKS(DT)                                   \
+    do {                                                    \
+        if (md == -1) KF_SYRK_CASE(DT, -1);                 \
+        else if (md == KF_F32) KF_SYRK_CASE(DT, F32);       \
+        else if (md == KF_I64) KF_SYRK_CASE(DT, I64);       \
+        else KF_SYRK_CASE(DT, U8);                          \
+    } while (0)
+    if (in_dtype == KF_F32) KF_SYRK_MASKS(F32);
+    else if (in_dtype == KF_BF16) KF_SYRK_MASKS(BF16);
+    else KF_SYRK_MASKS(F16);
+#undef KF_SYRK_MASKS
+#undef KF_SYRK_CASE
     return launch_status();
 }
 
@@ -619,11 +687,11 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t 
                 ScoreArgs s = a;
                 s.Q = static_cast<int>(std::min<int64_t>(qs, Q - q0));
                 s.P = P + q0 * O * Ip; s.scores = scores + q0 * ld_scores;
-                hipLaunchKernelGGL(score_r1_kernel, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(s.Q * a.tiles_per_q)), dim3(NTHREADS), 0, st, s);
+                launch_score_r1(s, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(s.Q * a.tiles_per_q)), st);
             }
             return launch_status();
         }
-        hipLaunchKernelGGL(score_r1_kernel, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(gy)), dim3(NTHREADS), 0, st, a);
+        launch_score_r1(a, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(gy)), st);
         return launch_status();
     }
     if (!workspace || workspace_bytes < kf_pairwise_workspace_bytes(b, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;

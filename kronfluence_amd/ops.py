@@ -253,6 +253,11 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     return out
 
 
+# When set to a list, every pairwise_score call appends (start_event, end_event, algorithmic_flops):
+# bench.py uses it to time the dominant kernel with HIP events on the launch stream.
+SCORE_EVENT_LOG: Optional[list] = None
+
+
 def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: torch.Tensor, a: torch.Tensor,
                    append_ones: bool, scale: float = 1.0) -> None:
     """``scores[:, col_offset:col_offset+b] += scale * <P_q, g_n>`` (kf_pairwise_score).
@@ -270,12 +275,19 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: to
     assert p.shape[1] == o and p.shape[2] == ip and scores.shape[0] == q and col_offset + b <= scores.shape[1]
     ws_bytes = nat.lib().kf_pairwise_workspace_bytes(b, r, o, ip)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    if SCORE_EVENT_LOG is not None:
+        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        start.record(torch.cuda.current_stream(g.device))
     nat.check(
         nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.data_ptr(), q, g.data_ptr(),
                                     a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
                                     ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
         "kf_pairwise_score",
     )
+    if SCORE_EVENT_LOG is not None:
+        end.record(torch.cuda.current_stream(g.device))
+        flops = 2.0 * q * b * o * ip + (2.0 * b * r * o * ip if r > 1 else 0.0)
+        SCORE_EVENT_LOG.append((start, end, flops))
 
 
 def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:

@@ -117,3 +117,28 @@ class DistributedSamplerWithStack(data.Sampler):
 
     def __len__(self) -> int:
         return self.num_samples
+
+
+class ResidentLoader:
+    """Batches sliced zero-copy out of tensors already resident in HBM (288 GB per MI355X holds the
+    whole dataset for every BASELINE config but the largest): no worker processes, no collation, no
+    H2D copy per batch.  Quacks like a ``DataLoader`` as far as the stage loops are concerned
+    (``__iter__``, ``__len__``, ``.dataset``, ``.sampler``).  ``indices`` (a sampler's index list)
+    selects and orders the rows once, up front."""
+
+    def __init__(self, tensors: Tuple[torch.Tensor, ...], batch_size: int, indices: Optional[List[int]] = None) -> None:
+        self.dataset = data.TensorDataset(*tensors)
+        if indices is not None:
+            index = torch.as_tensor(list(indices), dtype=torch.int64, device=tensors[0].device)
+            tensors = tuple(t.index_select(0, index) for t in tensors)
+        self.tensors = tensors
+        self.batch_size = batch_size
+        self.sampler = range(tensors[0].shape[0])
+
+    def __len__(self) -> int:
+        return math.ceil(len(self.sampler) / self.batch_size)
+
+    def __iter__(self):
+        n = len(self.sampler)
+        for start in range(0, n, self.batch_size):
+            yield tuple(t[start:start + self.batch_size] for t in self.tensors)

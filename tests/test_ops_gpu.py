@@ -145,7 +145,7 @@ def test_eigh_invariants_and_values(ops, d, n):
     evals, evecs, sweeps = ops.eigh(cov.to(DEV), float(n))
     count = torch.tensor([n])
     inv = ref.eigh_invariants(cov, count, evals.cpu(), evecs.cpu())
-    assert inv["orthogonality"] < 1e-12 and inv["reconstruction"] < 1e-12 and inv["ascending"] == 0.0, (inv, sweeps)
+    assert inv["orthogonality"] < 2e-12 and inv["reconstruction"] < 2e-12 and inv["ascending"] == 0.0, (inv, sweeps)
     want, _ = ref.eigendecompose(cov.double(), count)
     scale = want.abs().max()
     assert float((evals.cpu() - want).abs().max() / scale) < 1e-10
