@@ -22,7 +22,7 @@ from kronfluence_amd.utils.constants import (
     ACTIVATION_COVARIANCE_MATRIX_NAME, COVARIANCE_FACTOR_NAMES, FACTOR_TYPE, GRADIENT_COVARIANCE_MATRIX_NAME,
 )
 from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
-from kronfluence_amd.utils.state import State, no_sync
+from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
 def covariance_matrices_save_path(output_dir: Path, factor_name: str, partition=None) -> Path:
@@ -56,7 +56,7 @@ def _loss_scale(factor_args: FactorArguments) -> float:
     return 1.0
 
 
-def fit_covariance_matrices_with_loader(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
+def _fit_covariance_matrices_with_loader_impl(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
                                         factor_args: FactorArguments, tracked_module_names: Optional[List[str]] = None,
                                         disable_tqdm: bool = False) -> Tuple[torch.Tensor, FACTOR_TYPE]:
     del disable_tqdm
@@ -98,3 +98,10 @@ def fit_covariance_matrices_with_loader(model: nn.Module, state: State, task: Ta
     set_mode(model, ModuleMode.DEFAULT, release_memory=True)
     state.wait_for_everyone()
     return num_data_processed, saved
+
+
+def fit_covariance_matrices_with_loader(*args, **kwargs) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+    """Stage entry point (signature of ``_fit_covariance_matrices_with_loader_impl``); runs the loop
+    with the cyclic GC paused (see ``utils.state.paused_gc``)."""
+    with paused_gc():
+        return _fit_covariance_matrices_with_loader_impl(*args, **kwargs)

@@ -28,7 +28,7 @@ from kronfluence_amd.utils.constants import (
     NUM_GRADIENT_COVARIANCE_PROCESSED,
 )
 from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
-from kronfluence_amd.utils.state import State, no_sync
+from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
 def eigendecomposition_save_path(output_dir: Path, factor_name: str) -> Path:
@@ -116,7 +116,7 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
     return out
 
 
-def fit_lambda_matrices_with_loader(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
+def _fit_lambda_matrices_with_loader_impl(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
                                     factor_args: FactorArguments, eigen_factors: Optional[FACTOR_TYPE] = None,
                                     tracked_module_names: Optional[List[str]] = None,
                                     disable_tqdm: bool = False) -> Tuple[torch.Tensor, FACTOR_TYPE]:
@@ -159,3 +159,9 @@ def fit_lambda_matrices_with_loader(model: nn.Module, state: State, task: Task, 
     set_mode(model, ModuleMode.DEFAULT, release_memory=True)
     state.wait_for_everyone()
     return num_data_processed, saved
+
+
+def fit_lambda_matrices_with_loader(*args, **kwargs) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+    """Stage entry point (signature of ``_fit_lambda_matrices_with_loader_impl``), cyclic GC paused."""
+    with paused_gc():
+        return _fit_lambda_matrices_with_loader_impl(*args, **kwargs)

@@ -93,10 +93,12 @@ class PreconditionTracker(BaseTracker):
         if not dist.is_initialized() or local is None:
             return
         local = local.contiguous()
-        stacked = torch.empty((num_processes,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(stacked, local)
+        q = local.shape[0]
+        gathered = torch.empty((num_processes * q,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(gathered, local)  # rank-major concatenation (layout both RCCL and gloo accept)
+        stacked = gathered.reshape((num_processes, q) + tuple(local.shape[1:]))
         storage[PRECONDITIONED_GRADIENT_NAME] = stacked.transpose(0, 1).reshape(
-            num_processes * local.shape[0], local.shape[1], local.shape[2])
+            num_processes * q, local.shape[1], local.shape[2])
 
     def truncate(self, keep_size: int) -> None:
         storage = self.module.storage

@@ -22,7 +22,7 @@ from kronfluence_amd.score.dot_product import compute_dot_products_with_loader
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import FACTOR_TYPE, SCORE_TYPE
 from kronfluence_amd.utils.dataset import send_to_device
-from kronfluence_amd.utils.state import State, no_sync
+from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
 def pairwise_scores_save_path(output_dir: Path, partition=None) -> Path:
@@ -44,7 +44,7 @@ def pairwise_scores_exist(output_dir: Path, partition=None) -> bool:
     return pairwise_scores_save_path(output_dir, partition).exists()
 
 
-def compute_pairwise_scores_with_loaders(loaded_factors: FACTOR_TYPE, model: nn.Module, state: State, task: Task,
+def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, model: nn.Module, state: State, task: Task,
                                          query_loader: data.DataLoader, per_device_query_batch_size: int,
                                          train_loader: data.DataLoader, score_args: ScoreArguments,
                                          factor_args: FactorArguments, tracked_module_names: Optional[List[str]],
@@ -110,3 +110,9 @@ def compute_pairwise_scores_with_loaders(loaded_factors: FACTOR_TYPE, model: nn.
     set_mode(model, ModuleMode.DEFAULT, release_memory=True)
     state.wait_for_everyone()
     return total
+
+
+def compute_pairwise_scores_with_loaders(*args, **kwargs) -> SCORE_TYPE:
+    """Stage entry point (signature of ``_compute_pairwise_scores_with_loaders_impl``), cyclic GC paused."""
+    with paused_gc():
+        return _compute_pairwise_scores_with_loaders_impl(*args, **kwargs)

@@ -1,0 +1,146 @@
+"""World-size-2 (gloo, CPU) tests of the N > 1 exchange steps of the hot path:
+bucketed factor all-reduce (C1-C3), query-gradient all-gather + interleave (C4), score-block
+gather (C5).  The arithmetic on the shards needs a GPU, so shard-local results are synthesised
+here; what is tested is that the exchange reproduces the single-process result."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import fixtures as fx
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, fn_name: str, out_dir: str) -> None:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        globals()[fn_name](rank, world, out_dir)
+    finally:
+        dist.destroy_process_group()
+
+
+def _run(fn_name: str, tmp_path, world: int = 2) -> None:
+    mp.spawn(_worker, args=(world, _free_port(), fn_name, str(tmp_path)), nprocs=world, join=True)
+
+
+class _T:
+    def compute_train_loss(self, batch, model, sample=False): ...
+    def compute_measurement(self, batch, model): ...
+
+
+def _model():
+    from kronfluence_amd import Task, prepare_model
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return model(batch[0]).sum()
+
+        def compute_measurement(self, batch, model):
+            return model(batch[0]).sum()
+
+    return prepare_model(fx.make_model("mlp"), T())
+
+
+# ---- C1-C3 -------------------------------------------------------------------------------------
+def _factor_allreduce(rank, world, out_dir):
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.module.utils import get_tracked_module_names, synchronize_factors
+    from kronfluence_amd.utils.constants import COVARIANCE_FACTOR_NAMES, LAMBDA_FACTOR_NAMES
+
+    model = _model()
+    mods = [m for m in model.modules() if isinstance(m, TrackedModule)]
+    gen = torch.Generator().manual_seed(100 + rank)
+    for i, m in enumerate(mods):
+        m.storage["activation_covariance"] = torch.randn(4 + i, 4 + i, generator=gen)
+        m.storage["gradient_covariance"] = torch.randn(3 + i, 3 + i, generator=gen)
+        m.storage["num_activation_covariance_processed"] = torch.tensor([10 * (rank + 1) + i])
+        m.storage["num_gradient_covariance_processed"] = torch.tensor([7 * (rank + 1) + i])
+        m.storage["lambda_matrix"] = torch.randn(3 + i, 4 + i, generator=gen)
+        m.storage["num_lambda_processed"] = torch.tensor([5 + rank])
+    seen = torch.tensor([11 + rank])
+    names = get_tracked_module_names(model)
+    synchronize_factors(model, COVARIANCE_FACTOR_NAMES, names, torch.device("cpu"), extra=[seen])
+    synchronize_factors(model, LAMBDA_FACTOR_NAMES, names, torch.device("cpu"))
+    state = {f"{m.name}/{k}": m.storage[k] for m in mods for k in COVARIANCE_FACTOR_NAMES + LAMBDA_FACTOR_NAMES}
+    state["seen"] = seen
+    torch.save(state, os.path.join(out_dir, f"rank{rank}.pt"))
+
+
+def test_bucketed_factor_allreduce_matches_sum(tmp_path):
+    _run("_factor_allreduce", tmp_path)
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
+    # every rank holds the SUM (all-reduce, not reduce-to-0), and it equals the sum of the two locals
+    for key in got[0]:
+        assert torch.equal(got[0][key], got[1][key]), key
+    want = {}
+    for rank in range(2):
+        gen = torch.Generator().manual_seed(100 + rank)
+        for i, name in enumerate(["0", "2", "4"]):
+            for key, shape in (("activation_covariance", (4 + i, 4 + i)), ("gradient_covariance", (3 + i, 3 + i))):
+                want[f"{name}/{key}"] = want.get(f"{name}/{key}", 0) + torch.randn(*shape, generator=gen)
+            want[f"{name}/lambda_matrix"] = want.get(f"{name}/lambda_matrix", 0) + torch.randn(3 + i, 4 + i, generator=gen)
+    for key, tensor in want.items():
+        assert torch.allclose(got[0][key], tensor, atol=1e-6), key
+    assert int(got[0]["0/num_activation_covariance_processed"]) == 10 + 20
+    assert int(got[0]["4/num_gradient_covariance_processed"]) == 7 + 14 + 4
+    assert int(got[0]["2/num_lambda_processed"]) == 5 + 6
+    assert int(got[0]["seen"]) == 11 + 12
+
+
+# ---- C4 ----------------------------------------------------------------------------------------
+def _query_allgather(rank, world, out_dir):
+    from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
+    from torch.utils.data import DistributedSampler
+
+    model = _model()
+    m = [x for x in model.modules() if isinstance(x, TrackedModule)][0]
+    m.current_mode = ModuleMode.PRECONDITION_GRADIENT
+    n_query, per_rank = 5, 3
+    idx = list(DistributedSampler(range(n_query), world, rank, shuffle=False, drop_last=False))[:per_rank]
+    # the "preconditioned gradient" of query i is a [2,3] matrix filled with i
+    m.storage["preconditioned_gradient"] = torch.stack([torch.full((2, 3), float(i)) for i in idx])
+    m.synchronize(num_processes=world)
+    m.truncate(keep_size=n_query % (per_rank * world) or per_rank * world)
+    m.accumulate_iterations()
+    torch.save(m.storage["accumulated_preconditioned_gradient"], os.path.join(out_dir, f"rank{rank}.pt"))
+
+
+def test_query_allgather_restores_dataset_order(tmp_path):
+    _run("_query_allgather", tmp_path)
+    for rank in range(2):
+        got = torch.load(os.path.join(tmp_path, f"rank{rank}.pt"))
+        assert got.shape == (5, 2, 3)
+        assert got[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
+# ---- C5 ----------------------------------------------------------------------------------------
+def _score_gather(rank, world, out_dir):
+    from kronfluence_amd.score.dot_product import gather_score_blocks
+    from kronfluence_amd.utils.dataset import DistributedSamplerWithStack
+    from kronfluence_amd.utils.state import State
+
+    State._reset_state()
+    state = State(cpu=True)
+    n_train, q = 7, 3
+    idx = list(DistributedSamplerWithStack(range(n_train), world, rank))
+    block = torch.tensor([[100.0 * qi + t for t in idx] for qi in range(q)])
+    total = gather_score_blocks(block, state, n_train)
+    torch.save(total, os.path.join(out_dir, f"rank{rank}.pt"))
+
+
+def test_score_block_gather_concatenates_in_dataset_order(tmp_path):
+    _run("_score_gather", tmp_path)
+    got = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    want = torch.tensor([[100.0 * qi + t for t in range(7)] for qi in range(3)])
+    assert torch.equal(got, want)

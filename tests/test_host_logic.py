@@ -1,0 +1,142 @@
+"""Host-side logic that needs no GPU: arguments, samplers, partitions, wrapper installation, mode
+switching, storage keys.  Mirrors the behaviour the reference's CPU tests pin (SURVEY.md section 4:
+tests/test_dataset_utils.py, tests/modules/test_modules.py, arguments validation)."""
+
+import pytest
+import torch
+from torch import nn
+
+import fixtures as fx
+from kronfluence_amd import FactorArguments, ScoreArguments, Task, prepare_model
+from kronfluence_amd.arguments import unsupported_score_options
+from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
+from kronfluence_amd.module.utils import (
+    get_tracked_module_names, make_modules_partition, set_mode, wrap_tracked_modules,
+)
+from kronfluence_amd.utils import constants as C
+from kronfluence_amd.utils.dataset import (
+    DistributedEvalSampler, DistributedSamplerWithStack, ResidentLoader, find_batch_size, make_indices_partition,
+)
+from kronfluence_amd.utils.exceptions import IllegalTaskConfigurationError
+
+
+class _Task(Task):
+    def __init__(self, names=None):
+        self.names = names
+
+    def compute_train_loss(self, batch, model, sample=False):
+        return model(batch[0]).sum()
+
+    def compute_measurement(self, batch, model):
+        return model(batch[0]).sum()
+
+    def get_influence_tracked_modules(self):
+        return self.names
+
+
+def test_argument_validation_matches_reference_rules():
+    with pytest.raises(ValueError):
+        FactorArguments(covariance_max_examples=0)
+    with pytest.raises(ValueError):
+        FactorArguments(lambda_data_partitions=0)
+    with pytest.raises(ValueError):
+        ScoreArguments(damping_factor=-1.0)
+    with pytest.raises(ValueError):
+        ScoreArguments(query_gradient_accumulation_steps=0)
+    with pytest.raises(ValueError):
+        ScoreArguments(query_gradient_low_rank=0)
+    args = FactorArguments()
+    assert args.strategy == "ekfac" and args.eigendecomposition_dtype == torch.float64
+    assert args.to_dict()["lambda_dtype"] == "torch.float32"
+    assert ScoreArguments().damping_factor == 1e-8
+    assert unsupported_score_options(ScoreArguments(query_gradient_low_rank=8)) == {"query_gradient_low_rank": 8}
+    assert unsupported_score_options(ScoreArguments()) == {}
+
+
+def test_storage_keys_and_file_names_are_the_references():
+    assert C.COVARIANCE_FACTOR_NAMES == ["activation_covariance", "gradient_covariance",
+                                         "num_activation_covariance_processed", "num_gradient_covariance_processed"]
+    assert C.EIGENDECOMPOSITION_FACTOR_NAMES == ["activation_eigenvectors", "activation_eigenvalues",
+                                                 "gradient_eigenvectors", "gradient_eigenvalues"]
+    assert C.LAMBDA_FACTOR_NAMES == ["lambda_matrix", "num_lambda_processed"]
+    assert C.ALL_MODULE_NAME == "all_modules" and C.FACTOR_SAVE_PREFIX == "factors_" and C.SCORE_SAVE_PREFIX == "scores_"
+    assert C.HEURISTIC_DAMPING_SCALE == 0.1 and C.LAMBDA_DTYPE == torch.float64
+
+
+@pytest.mark.parametrize("n,world", [(10, 3), (7, 2), (5, 8), (64, 4), (1, 2)])
+def test_samplers_shard_like_the_reference(n, world):
+    dataset = list(range(n))
+    strided = [list(DistributedEvalSampler(dataset, world, r)) for r in range(world)]
+    assert sorted(sum(strided, [])) == dataset  # disjoint, complete, no padding
+    assert all(s == list(range(r, n, world)) for r, s in enumerate(strided))
+    stacked = [list(DistributedSamplerWithStack(dataset, world, r)) for r in range(world)]
+    chunk = -(-n // world)
+    assert all(len(s) == chunk for s in stacked)
+    assert sum(stacked, [])[:n] == dataset  # contiguous blocks concatenate in dataset order
+    with pytest.raises(ValueError):
+        DistributedEvalSampler(dataset, world, world)
+
+
+def test_partitions_and_batch_size_helpers():
+    assert make_indices_partition(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    with pytest.raises(ValueError):
+        make_indices_partition(2, 3)
+    assert make_modules_partition(["a", "b", "c", "d", "e"], 2) == [["a", "b"], ["c", "d", "e"]]
+    assert find_batch_size({"x": torch.zeros(4, 2)}) == 4 and find_batch_size([torch.zeros(3), 1]) == 3
+    loader = ResidentLoader((torch.arange(10), torch.arange(10) * 2), 4, indices=[9, 1, 3])
+    batches = list(loader)
+    assert len(loader) == 1 and len(loader.dataset) == 10 and len(loader.sampler) == 3
+    assert batches[0][0].tolist() == [9, 1, 3] and batches[0][1].tolist() == [18, 2, 6]
+
+
+def test_prepare_model_wraps_supported_leaves_and_freezes():
+    model = prepare_model(fx.make_model("conv"), _Task())
+    names = get_tracked_module_names(model)
+    assert names == ["0", "2", "4", "7"]
+    assert all(not p.requires_grad for n, p in model.named_parameters() if "_constant" not in n)
+    assert not model.training
+    kinds = [type(m).__name__ for m in model.modules() if isinstance(m, TrackedModule)]
+    assert kinds == ["TrackedConv2d", "TrackedConv2d", "TrackedConv2d", "TrackedLinear"]
+    # wrapper is transparent in DEFAULT mode and keeps autograd alive through frozen weights
+    x = torch.randn(2, 3, 8, 8)
+    out = model(x)
+    assert out.requires_grad
+    assert torch.allclose(out, fx.make_model("conv").eval()(x), atol=1e-6)
+
+
+def test_task_selected_modules_and_errors():
+    model = prepare_model(fx.make_model("mlp"), _Task(names=["0", "4"]))
+    assert get_tracked_module_names(model) == ["0", "4"]
+    with pytest.raises(IllegalTaskConfigurationError):
+        prepare_model(fx.make_model("mlp"), _Task(names=["0", "nope"]))
+    with pytest.raises(IllegalTaskConfigurationError):
+        prepare_model(nn.Sequential(nn.ReLU()), _Task())
+    with pytest.raises(ValueError):
+        wrap_tracked_modules(nn.DataParallel(fx.make_model("mlp")), _Task())
+
+
+def test_mode_switch_registers_and_releases_hooks():
+    model = prepare_model(fx.make_model("mlp"), _Task())
+    mods = [m for m in model.modules() if isinstance(m, TrackedModule)]
+    assert all(len(m._forward_hooks) == 0 for m in mods)
+    set_mode(model, ModuleMode.COVARIANCE)
+    assert all(len(m._forward_hooks) == 1 and m.current_mode == "covariance" for m in mods)
+    set_mode(model, ModuleMode.LAMBDA, release_memory=True)
+    assert all(len(m._forward_hooks) == 1 and m.current_mode == "lambda" for m in mods)
+    set_mode(model, ModuleMode.DEFAULT)
+    assert all(len(m._forward_hooks) == 0 for m in mods)
+    with pytest.raises(NotImplementedError):
+        set_mode(model, ModuleMode.SELF_SCORE)
+    for m in mods:  # storage holds exactly the reference's keys
+        assert set(m.storage) >= set(C.COVARIANCE_FACTOR_NAMES + C.EIGENDECOMPOSITION_FACTOR_NAMES + C.LAMBDA_FACTOR_NAMES)
+
+
+def test_hooks_fail_loudly_without_gpu():
+    if torch.cuda.is_available():
+        pytest.skip("GPU box")
+    from kronfluence_amd._native import KfError
+
+    model = prepare_model(fx.make_model("mlp"), _Task())
+    set_mode(model, ModuleMode.COVARIANCE)
+    with pytest.raises(KfError):
+        model(torch.randn(4, 12)).sum().backward()
