@@ -41,6 +41,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16); AMD's 5 PF figure is 2:1 sparse
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -170,7 +171,11 @@ def main() -> None:
     query = synth(spec, n_query, 2, dev)
     amp = spec["amp"]
     fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=amp)
-    sargs = ScoreArguments(amp_dtype=amp)
+    per_dev_q = max(1, min(spec["query_batch"], -(-n_query // world)))
+    # hold every preconditioned query gradient resident in HBM (P: n_query x D) -> ONE train pass per step
+    accumulate = -(-n_query // (per_dev_q * world))
+    sargs = ScoreArguments(amp_dtype=amp, query_gradient_accumulation_steps=accumulate,
+                           score_dtype=torch.bfloat16 if amp == torch.bfloat16 else torch.float32)
     layers = tracked_shapes(model)
     D = sum(o * ip for o, ip in layers)
 
@@ -201,8 +206,6 @@ def main() -> None:
         idx = list(DistributedSamplerWithStack(range(n_train), world, rank)) if world > 1 else None
         loader = ResidentLoader(train, spec["train_batch"], idx)
         return loader
-
-    per_dev_q = max(1, min(spec["query_batch"], -(-n_query // world)))
 
     def query_loader():
         if world > 1:
@@ -312,19 +315,21 @@ def main() -> None:
 
     if rank == 0:
         achieved = kernel_flops / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        peak = PEAK_BF16_MFMA_TFLOPS if sargs.score_dtype == torch.bfloat16 else PEAK_FP32_MFMA_TFLOPS
         line = {
             "metric": "pairwise_influence_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
             "step_ms": [round(x, 2) for x in step_ms], "hipmalloc_segments_in_timed_region": new_segments,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if amp == torch.bfloat16 else "f32", "data": "synthetic",
             "config": {"workload": args.workload, "n_train": n_train, "n_query": n_query, "tracked_layers": len(layers),
                        "D": D, "input_dtype": "bf16-autocast" if amp is not None else "f32",
+                       "score_dtype": str(sargs.score_dtype), "query_gradient_accumulation_steps": accumulate,
                        "train_batch": spec["train_batch"], "query_batch": per_dev_q,
                        "parallelism": f"train-shard-dp{world}"},
             "roofline": {
-                "bound": "mfma", "kernel": "kf_pairwise_score (score_r1_kernel / gemm_kernel)",
-                "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                "bound": "mfma", "kernel": "kf_pairwise_score (score_r1_kernel | gemm_kernel + gemm_nt_bf16_kernel)",
+                "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                "frac": achieved / peak, "traffic": None,
                 "launches": launches, "avg_launch_ms": kernel_ms / max(launches, 1),
                 "algorithmic_flops_per_launch": kernel_flops / max(launches, 1),
                 "kernel_share_of_step": (kernel_ms * 1e-3) / elapsed if elapsed > 0 else None,

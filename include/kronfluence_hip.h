@@ -167,11 +167,13 @@ int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambd
  * factor/config.py:341-353 (four matmuls + mul_).  The forward rotation is done on the factors
  * (G Qg, A' Qa) instead of on the [O,I'] gradient.
  * G: [q,R,O], A: [q,R,I] (in_dtype, contiguous), Qg [O,O], Qa [I',I'], inv_lambda [O,I'] fp32.
+ * P: [q,O,I'] in out_dtype (KF_F32, or KF_BF16 = ScoreArguments.score_dtype of the reference's
+ * low-precision presets; all arithmetic and the staging of intermediate results stay fp32).
  * workspace (device): kf_precondition_workspace_bytes(q,R,O,I') bytes.
  */
 int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip);
-int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_t q, int64_t R,
-                    int64_t O, int64_t I, int append_ones, const float* Qg, const float* Qa,
+int kf_precondition(void* P, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q,
+                    int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg, const float* Qa,
                     const float* inv_lambda, float scale, void* workspace, int64_t workspace_bytes,
                     void* stream);
 
@@ -180,15 +182,17 @@ int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_
  * Replaces module/linear.py:112-122 and module/conv2d.py:199-209 (three-operand einsum),
  * module/tracker/pairwise_score.py:41-45 and the per-layer add_ of score/dot_product.py:105-117:
  * every layer accumulates into the same [Q, ld_scores] device buffer, one D2H per shard.
- * P: [Q,O,I'] fp32 contiguous.  G: [b,R,O], A: [b,R,I] (in_dtype, contiguous); A' = [A,1] if
- * append_ones.  R == 1 never materialises the per-sample gradient; R > 1 forms it in
- * `workspace` (kf_pairwise_workspace_bytes) and contracts it with P on the MFMA engine.
+ * P: [Q,O,I'] contiguous, p_dtype KF_F32 or KF_BF16.  G: [b,R,O], A: [b,R,I] (in_dtype,
+ * contiguous); A' = [A,1] if append_ones.  R == 1 never materialises the per-sample gradient;
+ * R > 1 forms it in `workspace` (kf_pairwise_workspace_bytes) in P's dtype and contracts it with
+ * P on the MFMA engine: v_mfma_f32_32x32x16_bf16 (fp32 accumulate) for bf16 P when O*I' is a
+ * multiple of 8, v_mfma_f32_32x32x2_f32 otherwise.
  */
 int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip);
-int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t Q, const void* G,
-                      const void* A, int in_dtype, int64_t b, int64_t R, int64_t O, int64_t I,
-                      int append_ones, float scale, void* workspace, int64_t workspace_bytes,
-                      void* stream);
+int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dtype, int64_t Q,
+                      const void* G, const void* A, int in_dtype, int64_t b, int64_t R, int64_t O,
+                      int64_t I, int append_ones, float scale, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 /* Elementwise helper: dst[i] = (out_dtype) src[i] -- export of fp32 accumulators in the factor dtype. */
 int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream);

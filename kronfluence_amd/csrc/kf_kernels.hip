@@ -11,6 +11,7 @@
 
 #include "../../include/kronfluence_hip.h"
 #include "kf_engine.h"
+#include "kf_engine_bf16.h"
 
 using namespace kf;
 
@@ -48,7 +49,8 @@ __device__ __forceinline__ void store_as(void* p, int dtype, int64_t idx, float 
 // Generic strided batched GEMM
 // ------------------------------------------------------------------------------------------------
 struct GemmArgs {
-    float* C;
+    void* C;
+    int c_dtype;        // F32, or BF16 for plain (non-atomic, beta == 0) stores
     int64_t ldc, c_batch_stride;
     kf_view A, B;
     int M, N, K;        // extents including the virtual ones row / k
@@ -89,7 +91,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs a) {
     mainloop(la, lb, k_begin, k_end, acc, smem);
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    float* C = a.C + static_cast<int64_t>(z) * a.c_batch_stride;
+    const int64_t cz = static_cast<int64_t>(z) * a.c_batch_stride;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -100,9 +102,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs a) {
                 if (m < a.M && n < a.N) {
                     float v = a.alpha * acc[ti][tj][r];
                     if (a.mul) v *= a.mul[static_cast<int64_t>(m) * a.ld_mul + n];
-                    float* dst = C + static_cast<int64_t>(m) * a.ldc + n;
-                    if (a.atomic) atomicAdd(dst, v);
-                    else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
+                    const int64_t idx = cz + static_cast<int64_t>(m) * a.ldc + n;
+                    if (a.c_dtype == BF16) {
+                        store_as(a.C, BF16, idx, v);
+                    } else {
+                        float* dst = reinterpret_cast<float*>(a.C) + idx;
+                        if (a.atomic) atomicAdd(dst, v);
+                        else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
+                    }
                 }
             }
 }
@@ -117,9 +124,47 @@ __global__ void scale_matrix_kernel(float* C, int64_t ldc, int64_t batch_stride,
     }
 }
 
-int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
-                int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, hipStream_t st) {
+bool bf16_nt_eligible(const kf_view& A, const kf_view& B, int64_t batch, const float* mul, int c_dtype) {
+    auto ok = [](const kf_view& v) {
+        return v.dtype == KF_BF16 && v.k_stride == 1 && !v.ones_row && !v.ones_k && !v.square && v.depth % 8 == 0 &&
+               v.row_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
+    };
+    return batch == 1 && !mul && c_dtype == KF_F32 && ok(A) && ok(B) && A.depth >= HBK;
+}
+
+int launch_gemm_nt_bf16(float* C, int64_t ldc, const kf_view& A, const kf_view& B, float alpha, float beta, hipStream_t st) {
+    static bool configured = false;
+    if (!configured) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HSMEM_BYTES) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        configured = true;
+    }
+    const int64_t M = A.rows, N = B.rows, K = A.depth;
+    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), ksteps = cdiv(K, HBK);
+    int64_t ksplit = 1;
+    if (tiles < 1024 && ksteps >= 8) ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), ksteps / 4));
+    const int64_t kchunk = cdiv(ksteps, ksplit) * HBK;
+    ksplit = cdiv(K, kchunk);
+    if (ksplit > 65535) return KF_ERR_INVALID_ARGUMENT;
+    const bool atomic = ksplit > 1;
+    if (atomic && beta != 1.0f)
+        hipLaunchKernelGGL(scale_matrix_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(M * N, 256), 4096)), 1), dim3(256), 0, st,
+                           C, ldc, 0, static_cast<int>(M), static_cast<int>(N), beta);
+    HalfGemmArgs h;
+    h.C = C; h.ldc = ldc; h.A = reinterpret_cast<const uint16_t*>(A.p); h.B = reinterpret_cast<const uint16_t*>(B.p);
+    h.lda = A.row_stride; h.ldb = B.row_stride; h.M = static_cast<int>(M); h.N = static_cast<int>(N); h.K = static_cast<int>(K);
+    h.kchunk = static_cast<int>(kchunk); h.alpha = alpha; h.atomic = atomic ? 1 : 0; h.beta = beta;
+    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(static_cast<unsigned>(cdiv(N, 128)), static_cast<unsigned>(cdiv(M, 128)), static_cast<unsigned>(ksplit)),
+                       dim3(NTHREADS), HSMEM_BYTES, st, h);
+    return launch_status();
+}
+
+int launch_gemm(void* Cv, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
+                int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, hipStream_t st,
+                int c_dtype = KF_F32) {
+    float* C = reinterpret_cast<float*>(Cv);
     if (!C || !A.p || !B.p || batch < 0) return KF_ERR_INVALID_ARGUMENT;
+    if (c_dtype != KF_F32 && c_dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
     // supported operand dtype pairs: (f32|bf16|f16, f32) and (x, x)
     const bool a_ok = A.dtype == KF_F32 || A.dtype == KF_BF16 || A.dtype == KF_F16;
     if (!a_ok || !(B.dtype == KF_F32 || B.dtype == A.dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
@@ -130,6 +175,7 @@ int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A,
     }
     const int64_t M = A.rows + A.ones_row, N = B.rows + B.ones_row, K = A.depth + A.ones_k;
     if (M <= 0 || N <= 0 || batch == 0) return KF_OK;
+    if (bf16_nt_eligible(A, B, batch, mul, c_dtype)) return launch_gemm_nt_bf16(C, ldc, A, B, alpha, beta, st);
     if (M >= (1LL << 30) || N >= (1LL << 30) || K >= (1LL << 30)) return KF_ERR_INVALID_ARGUMENT;
     const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
     const bool batch_sum = (c_batch_stride == 0 && batch > 1);
@@ -144,6 +190,10 @@ int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A,
     int64_t kchunk = cdiv(ksteps, ksplit) * BK;
     ksplit = cdiv(K, kchunk);
     if (K == 0) { ksplit = 1; kchunk = BK; }
+    if (c_dtype == KF_BF16) {  // low-precision outputs are plain stores: no split-K, no accumulation
+        if (batch_sum || beta != 0.0f) return KF_ERR_INVALID_ARGUMENT;
+        ksplit = 1; kchunk = cdiv(ksteps, 1) * BK;
+    }
     const bool atomic = batch_sum || ksplit > 1;
     if (batch * ksplit > 65535) return KF_ERR_INVALID_ARGUMENT;
     if (atomic && beta != 1.0f) {
@@ -151,7 +201,7 @@ int launch_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view& A,
         hipLaunchKernelGGL(scale_matrix_kernel, g, dim3(256), 0, st, C, ldc, c_batch_stride, static_cast<int>(M), static_cast<int>(N), beta);
     }
     GemmArgs a;
-    a.C = C; a.ldc = ldc; a.c_batch_stride = c_batch_stride; a.A = A; a.B = B;
+    a.C = C; a.c_dtype = c_dtype; a.ldc = ldc; a.c_batch_stride = c_batch_stride; a.A = A; a.B = B;
     a.M = static_cast<int>(M); a.N = static_cast<int>(N); a.K = static_cast<int>(K);
     a.ksplit = static_cast<int>(ksplit); a.kchunk = static_cast<int>(kchunk);
     a.alpha = alpha; a.beta = beta; a.mul = mul; a.ld_mul = ld_mul; a.atomic = atomic ? 1 : 0;
@@ -397,18 +447,18 @@ __global__ void inv_lambda_kernel(float* out, const float* L, int64_t n, double 
 // G-weighted reduction over the tile's o rows in registers / LDS, one atomicAdd per (q, n).
 // ------------------------------------------------------------------------------------------------
 struct ScoreArgs {
-    float* scores; int64_t ld_scores; const float* P; const void* G; const void* A; int in_dtype;
+    float* scores; int64_t ld_scores; const void* P; int p_dtype; const void* G; const void* A; int in_dtype;
     int Q, b, O, I, Ip, append_ones, tiles_per_q; float scale;
 };
 
-template <int DT>
+template <int DTP, int DT>
 __global__ __launch_bounds__(NTHREADS) void score_r1_kernel(ScoreArgs a) {
     __shared__ float smem[SMEM_FLOATS];
     const int n0 = blockIdx.x * BN;
     const int q = blockIdx.y / a.tiles_per_q, o0 = (blockIdx.y % a.tiles_per_q) * BM;
-    StridedLoader<F32> la;
+    StridedLoader<DTP> la;
     StridedLoader<DT> lb;
-    la.p = a.P + (static_cast<int64_t>(q) * a.O + o0) * a.Ip;
+    la.p = reinterpret_cast<const char*>(a.P) + (static_cast<int64_t>(q) * a.O + o0) * a.Ip * (DTP == F32 ? 4 : 2);
     la.row_stride = a.Ip; la.k_stride = 1; la.rows = a.O - o0; la.depth = a.Ip;
     la.ones_row = la.ones_k = la.square = 0; la.contig_k = 1;
     lb.p = reinterpret_cast<const char*>(a.A) + static_cast<int64_t>(n0) * a.I * (DT == F32 ? 4 : 2);
@@ -456,9 +506,15 @@ __global__ __launch_bounds__(NTHREADS) void score_r1_kernel(ScoreArgs a) {
 }
 
 void launch_score_r1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
-    if (a.in_dtype == KF_F32) hipLaunchKernelGGL((score_r1_kernel<F32>), grid, dim3(NTHREADS), 0, st, a);
-    else if (a.in_dtype == KF_BF16) hipLaunchKernelGGL((score_r1_kernel<BF16>), grid, dim3(NTHREADS), 0, st, a);
-    else hipLaunchKernelGGL((score_r1_kernel<F16>), grid, dim3(NTHREADS), 0, st, a);
+#define KF_SCORE_CASE(DTP)                                                                                         \
+    do {                                                                                                           \
+        if (a.in_dtype == KF_F32) hipLaunchKernelGGL((score_r1_kernel<DTP, F32>), grid, dim3(NTHREADS), 0, st, a);   \
+        else if (a.in_dtype == KF_BF16) hipLaunchKernelGGL((score_r1_kernel<DTP, BF16>), grid, dim3(NTHREADS), 0, st, a); \
+        else hipLaunchKernelGGL((score_r1_kernel<DTP, F16>), grid, dim3(NTHREADS), 0, st, a);                       \
+    } while (0)
+    if (a.p_dtype == KF_BF16) KF_SCORE_CASE(BF16);
+    else KF_SCORE_CASE(F32);
+#undef KF_SCORE_CASE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -491,7 +547,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 1; }
+int kf_abi_version(void) { return 2; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -627,14 +683,15 @@ int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambd
 }
 
 int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip) {
-    return static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ip + q * O * Ip);
+    // Gt, At, T and (for low-precision outputs) the fp32 staging copy of the rotated gradient
+    return static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ip + 2 * q * O * Ip);
 }
 
-int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O, int64_t I,
-                    int append_ones, const float* Qg, const float* Qa, const float* inv_lambda, float scale,
+int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O,
+                    int64_t I, int append_ones, const float* Qg, const float* Qa, const float* inv_lambda, float scale,
                     void* workspace, int64_t workspace_bytes, void* stream) {
-    if (!P || !G || !A || !Qg || !Qa || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
-    if (!float_dtype(in_dtype)) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (!Pout || !G || !A || !Qg || !Qa || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!float_dtype(in_dtype) || (out_dtype != KF_F32 && out_dtype != KF_BF16)) return KF_ERR_UNSUPPORTED_DTYPE;
     const int64_t Ip = I + (append_ones ? 1 : 0);
     if (!workspace || workspace_bytes < kf_precondition_workspace_bytes(q, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (q == 0) return KF_OK;
@@ -642,6 +699,8 @@ int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_
     float* Gt = reinterpret_cast<float*>(workspace);
     float* At = Gt + q * R * O;
     float* T = At + q * R * Ip;
+    // fp32 staging of the rotated gradient: the caller's buffer when it is fp32, else workspace
+    float* P = out_dtype == KF_F32 ? reinterpret_cast<float*>(Pout) : T + q * O * Ip;
     int rc;
     // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']
     rc = launch_gemm(Gt, O, 0, make_view(G, in_dtype, 0, O, 1, q * R, O), make_view(Qg, KF_F32, 0, 1, O, O, O), 1, 1.0f, 0.0f, nullptr, 0, st);
@@ -656,7 +715,8 @@ int kf_precondition(float* P, const void* G, const void* A, int in_dtype, int64_
     rc = launch_gemm(T, Ip, 0, make_view(P, KF_F32, 0, Ip, 1, q * O, Ip), make_view(Qa, KF_F32, 0, Ip, 1, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
     if (rc != KF_OK) return rc;
     // P[q][m, n] = scale * sum_o Qg[m, o] T[q][o, n]
-    rc = launch_gemm(P, Ip, O * Ip, make_view(Qg, KF_F32, 0, O, 1, O, O), make_view(T, KF_F32, O * Ip, 1, Ip, Ip, O), q, scale, 0.0f, nullptr, 0, st);
+    rc = launch_gemm(Pout, Ip, O * Ip, make_view(Qg, KF_F32, 0, O, 1, O, O), make_view(T, KF_F32, O * Ip, 1, Ip, Ip, O), q, scale, 0.0f,
+                     nullptr, 0, st, out_dtype);
     return rc;
 }
 
@@ -665,17 +725,18 @@ int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip)
     return static_cast<int64_t>(sizeof(float)) * b * O * Ip;
 }
 
-int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t Q, const void* G, const void* A,
+int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dtype, int64_t Q, const void* G, const void* A,
                       int in_dtype, int64_t b, int64_t R, int64_t O, int64_t I, int append_ones, float scale,
                       void* workspace, int64_t workspace_bytes, void* stream) {
     if (!scores || !P || !G || !A || Q < 0 || b < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
     if (in_dtype != KF_F32 && in_dtype != KF_BF16 && in_dtype != KF_F16) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (p_dtype != KF_F32 && p_dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
     if (Q == 0 || b == 0) return KF_OK;
     hipStream_t st = as_stream(stream);
     const int64_t Ip = I + (append_ones ? 1 : 0);
     if (R == 1) {
         ScoreArgs a;
-        a.scores = scores; a.ld_scores = ld_scores; a.P = P; a.G = G; a.A = A; a.in_dtype = in_dtype;
+        a.scores = scores; a.ld_scores = ld_scores; a.P = P; a.p_dtype = p_dtype; a.G = G; a.A = A; a.in_dtype = in_dtype;
         a.Q = static_cast<int>(Q); a.b = static_cast<int>(b); a.O = static_cast<int>(O); a.I = static_cast<int>(I);
         a.Ip = static_cast<int>(Ip); a.append_ones = append_ones ? 1 : 0;
         a.tiles_per_q = static_cast<int>(cdiv(O, BM)); a.scale = scale;
@@ -686,7 +747,7 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t 
             for (int64_t q0 = 0; q0 < Q; q0 += qs) {
                 ScoreArgs s = a;
                 s.Q = static_cast<int>(std::min<int64_t>(qs, Q - q0));
-                s.P = P + q0 * O * Ip; s.scores = scores + q0 * ld_scores;
+                s.P = reinterpret_cast<const char*>(P) + q0 * O * Ip * dtype_size(p_dtype); s.scores = scores + q0 * ld_scores;
                 launch_score_r1(s, dim3(static_cast<unsigned>(cdiv(b, BN)), static_cast<unsigned>(s.Q * a.tiles_per_q)), st);
             }
             return launch_status();
@@ -695,14 +756,15 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const float* P, int64_t 
         return launch_status();
     }
     if (!workspace || workspace_bytes < kf_pairwise_workspace_bytes(b, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
-    float* psg = reinterpret_cast<float*>(workspace);
-    // psg[n][o, i] = sum_r G[n,r,o] A'[n,r,i]
+    // psg[n][o, i] = sum_r G[n,r,o] A'[n,r,i], stored in P's dtype: with bf16 P the contraction below runs on
+    // the bf16 MFMA engine (fp32 accumulation), otherwise on the fp32 one.
+    void* psg = workspace;
     int rc = launch_gemm(psg, Ip, O * Ip, make_view(G, in_dtype, R * O, 1, O, O, R),
-                         make_view(A, in_dtype, R * I, 1, I, I, R, append_ones ? 1 : 0, 0), b, 1.0f, 0.0f, nullptr, 0, st);
+                         make_view(A, in_dtype, R * I, 1, I, I, R, append_ones ? 1 : 0, 0), b, 1.0f, 0.0f, nullptr, 0, st, p_dtype);
     if (rc != KF_OK) return rc;
     // scores[q, n] += scale * sum_d P[q, d] psg[n, d]
-    return launch_gemm(scores, ld_scores, 0, make_view(P, KF_F32, 0, O * Ip, 1, Q, O * Ip),
-                       make_view(psg, KF_F32, 0, O * Ip, 1, b, O * Ip), 1, scale, 1.0f, nullptr, 0, st);
+    return launch_gemm(scores, ld_scores, 0, make_view(P, p_dtype, 0, O * Ip, 1, Q, O * Ip),
+                       make_view(psg, p_dtype, 0, O * Ip, 1, b, O * Ip), 1, scale, 1.0f, nullptr, 0, st);
 }
 
 int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream) {

@@ -102,7 +102,9 @@ class TrackedConv2d(TrackedModule, module_type=nn.Conv2d):
     def compute_pairwise_score(self, preconditioned_gradient: torch.Tensor, input_activation: torch.Tensor,
                                output_gradient: torch.Tensor) -> torch.Tensor:
         g, a, ones = self.gradient_factors(input_activation, output_gradient)
-        p = preconditioned_gradient.to(torch.float32).contiguous()
+        p = preconditioned_gradient.contiguous()
+        if p.dtype not in (torch.float32, torch.bfloat16):
+            p = p.to(torch.float32)
         scores = torch.zeros((p.shape[0], g.shape[0]), dtype=torch.float32, device=g.device)
         ops.pairwise_score(scores, 0, p, g, a, ones)
         return scores

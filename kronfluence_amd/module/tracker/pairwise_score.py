@@ -42,7 +42,7 @@ class PairwiseScoreTracker(BaseTracker):
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
-            if preconditioned.dtype != torch.float32:
+            if preconditioned.dtype not in (torch.float32, torch.bfloat16):
                 preconditioned = preconditioned.to(torch.float32)
             batch = output_gradient.shape[0]
             if module.score_sink is not None:
@@ -60,6 +60,7 @@ class PairwiseScoreTracker(BaseTracker):
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()
+                preconditioned = preconditioned.to(torch.float32)
                 b, o, ip = psg.shape
                 q = preconditioned.shape[0]
                 ops.gemm(scores[:, offset:offset + b], scores.shape[1], 0,

@@ -27,7 +27,14 @@ from kronfluence_amd.utils.constants import (
 
 
 class PreconditionTracker(BaseTracker):
+    def _out_dtype(self) -> torch.dtype:
+        """``score_dtype`` of the reference (precondition.py:73): bf16 keeps P in bf16 for the bf16 MFMA
+        score contraction; everything else is held in fp32."""
+        return torch.bfloat16 if self.module.score_args.score_dtype == torch.bfloat16 else torch.float32
+
     def _store(self, preconditioned: torch.Tensor) -> None:
+        if preconditioned.dtype != self._out_dtype():
+            preconditioned = preconditioned.to(self._out_dtype())
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = preconditioned
 
     def register_hooks(self) -> None:
@@ -49,7 +56,7 @@ class PreconditionTracker(BaseTracker):
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 self._store(ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
                                              storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
-                                             scale=module.gradient_scale))
+                                             scale=module.gradient_scale, out_dtype=self._out_dtype()))
             else:
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
                 out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(psg, storage)

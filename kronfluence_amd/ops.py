@@ -230,7 +230,7 @@ def inv_lambda(lam: torch.Tensor, n_lambda: float, damping: Optional[float]) -> 
 
 
 def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch.Tensor, q_a: torch.Tensor,
-                 lam_inv: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+                 lam_inv: torch.Tensor, scale: float = 1.0, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """EK-FAC preconditioned per-sample gradient ``[q, O, I']`` from ``g: [q,R,O]`` and ``a: [q,R,I]``
     (tracker/precondition.py:102-123 + factor/config.py:341-353)."""
     nat.require_device(g, "g")
@@ -241,11 +241,13 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     assert q_g.shape == (o, o) and q_a.shape == (ip, ip) and lam_inv.shape == (o, ip)
     assert q_g.dtype == q_a.dtype == lam_inv.dtype == torch.float32 and g.dtype == a.dtype
     q_g, q_a, lam_inv = _contig(q_g), _contig(q_a), _contig(lam_inv)  # keep the contiguous copies alive
-    out = torch.empty((q, o, ip), dtype=torch.float32, device=g.device)
+    assert out_dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty((q, o, ip), dtype=out_dtype, device=g.device)
     ws_bytes = nat.lib().kf_precondition_workspace_bytes(q, r, o, ip)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
     nat.check(
-        nat.lib().kf_precondition(out.data_ptr(), g.data_ptr(), a.data_ptr(), nat.dtype_code(g.dtype), q, r, o, i,
+        nat.lib().kf_precondition(out.data_ptr(), nat.dtype_code(out_dtype), g.data_ptr(), a.data_ptr(),
+                                  nat.dtype_code(g.dtype), q, r, o, i,
                                   int(append_ones), q_g.data_ptr(), q_a.data_ptr(), lam_inv.data_ptr(), scale,
                                   ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
         "kf_precondition",
@@ -265,7 +267,8 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: to
     ``scores``: fp32 ``[Q, N]`` device buffer shared by all layers and all train batches of a shard."""
     nat.require_device(scores, "scores")
     nat.require_device(p, "p")
-    assert scores.dtype == p.dtype == torch.float32 and scores.is_contiguous() and p.is_contiguous()
+    assert scores.dtype == torch.float32 and p.dtype in (torch.float32, torch.bfloat16)
+    assert scores.is_contiguous() and p.is_contiguous()
     g, a = _contig(g), _contig(a)
     assert g.dtype == a.dtype
     b, r, o = g.shape
@@ -279,7 +282,8 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: to
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(g.device))
     nat.check(
-        nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.data_ptr(), q, g.data_ptr(),
+        nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.data_ptr(),
+                                    nat.dtype_code(p.dtype), q, g.data_ptr(),
                                     a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
                                     ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
         "kf_pairwise_score",

@@ -219,3 +219,42 @@ def test_cpu_tensors_fail_loudly(ops):
 
     with pytest.raises(KfError):
         ops.eigh(torch.eye(3), 1.0)
+
+
+# ---- bf16 MFMA engine ------------------------------------------------------------------------------
+@pytest.mark.parametrize("m,n,k", [(100, 250, 1728), (128, 128, 64), (257, 129, 20000), (1000, 999, 2304 * 16)])
+def test_gemm_nt_bf16_engine(ops, m, n, k):
+    a, b = _rand(m, k, dtype=torch.bfloat16), _rand(n, k, dtype=torch.bfloat16, seed=1)
+    want = a.double() @ b.double().t()
+    c = torch.full((m, n), 3.0, device=DEV)
+    ad, bd = a.to(DEV), b.to(DEV)
+    ops.gemm(c, n, 0, ops.view(ad, 0, k, 1, m, k), ops.view(bd, 0, k, 1, n, k), alpha=0.5, beta=1.0)
+    assert rel(c, 0.5 * want + 3.0) <= 2e-5  # exact bf16 products, fp32 accumulation (split-K atomics)
+
+
+@pytest.mark.parametrize("q,b,r,o,i,bias", [(100, 250, 1, 130, 257, True), (7, 9, 6, 32, 20, False), (40, 33, 50, 64, 127, True),
+                                             (5, 3, 40, 65, 129, False)])
+def test_pairwise_score_bf16_queries(ops, q, b, r, o, i, bias):
+    """bf16 preconditioned gradients (reference score_dtype=bf16): R == 1 reads P in bf16; R > 1 stores
+    the per-sample gradient in bf16 (one extra rounding, 2^-9 relative) and uses the bf16 MFMA engine."""
+    p = _rand(q, o, i + bias, seed=7).to(torch.bfloat16)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    if r == 1:
+        want = ref.linear_pairwise_score(p.double(), a[:, 0].double(), g[:, 0].double(), bias)
+    else:
+        want = ref.linear_pairwise_score(p.double(), a.double(), g.double(), bias)
+    scores = torch.zeros(q, b, device=DEV)
+    ops.pairwise_score(scores, 0, p.to(DEV), g.to(DEV), a.to(DEV), bias)
+    assert rel(scores, want) <= (2e-5 if r == 1 else 4e-3)
+
+
+def test_precondition_bf16_output(ops):
+    q, r, o, i = 4, 6, 33, 64
+    g, a = _rand(q, r, o), _rand(q, r, i, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].contiguous()
+    q_a = torch.linalg.qr(_rand(i + 1, i + 1, seed=3).double())[0].contiguous()
+    lam_inv = _rand(o, i + 1, seed=4).abs().double() + 0.1
+    want = ref.ekfac_precondition(ref.linear_per_sample_gradient(a.double(), g.double(), True), q_a, q_g, lam_inv)
+    got = ops.precondition(g.to(DEV), a.to(DEV), True, q_g.float().to(DEV), q_a.float().to(DEV), lam_inv.float().to(DEV),
+                           out_dtype=torch.bfloat16)
+    assert got.dtype == torch.bfloat16 and rel(got, want) <= 4e-3
