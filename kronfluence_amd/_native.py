@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libkronfluence_hip.so"
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 KF_F32, KF_BF16, KF_F16, KF_F64, KF_I64, KF_I32, KF_U8 = range(7)
 
@@ -35,6 +35,7 @@ class kf_view(ctypes.Structure):
         ("batch_stride", ctypes.c_int64), ("row_stride", ctypes.c_int64), ("k_stride", ctypes.c_int64),
         ("rows", ctypes.c_int64), ("depth", ctypes.c_int64),
         ("ones_row", ctypes.c_int), ("ones_k", ctypes.c_int), ("square", ctypes.c_int),
+        ("k_tile_stride", ctypes.c_int64),
     ]
 
 
@@ -55,7 +56,7 @@ SIGNATURES = {
     "kf_precondition_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "kf_precondition": (_i, [_p, _i, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _f, _p, _i64, _p]),
     "kf_pairwise_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
-    "kf_pairwise_score": (_i, [_p, _i64, _p, _i, _i64, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
+    "kf_pairwise_score": (_i, [_p, _i64, _p, _i, _i64, _i64, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
     "kf_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
 }
 

@@ -59,6 +59,7 @@ struct GemmArgs {
     const float* mul;
     int64_t ld_mul;
     int atomic;         // accumulate with atomicAdd (split-K or batch-summing); beta pre-applied
+    int64_t c_tile_stride;  // see HalfGemmArgs::c_tile_stride
 };
 
 template <int DT>
@@ -102,7 +103,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(GemmArgs a) {
                 if (m < a.M && n < a.N) {
                     float v = a.alpha * acc[ti][tj][r];
                     if (a.mul) v *= a.mul[static_cast<int64_t>(m) * a.ld_mul + n];
-                    const int64_t idx = cz + static_cast<int64_t>(m) * a.ldc + n;
+                    int64_t idx = cz + static_cast<int64_t>(m) * a.ldc + n;
+                    if (a.c_tile_stride) {
+                        const int64_t d = static_cast<int64_t>(m) * a.ldc + n;
+                        idx = (d >> 6) * a.c_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
+                    }
                     if (a.c_dtype == BF16) {
                         store_as(a.C, BF16, idx, v);
                     } else {
@@ -124,44 +129,69 @@ __global__ void scale_matrix_kernel(float* C, int64_t ldc, int64_t batch_stride,
     }
 }
 
-bool bf16_nt_eligible(const kf_view& A, const kf_view& B, int64_t batch, const float* mul, int c_dtype) {
-    auto ok = [](const kf_view& v) {
-        return v.dtype == KF_BF16 && v.k_stride == 1 && !v.ones_row && !v.ones_k && !v.square && v.depth % 8 == 0 &&
-               v.row_stride % 8 == 0 && (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
+// bf16 MFMA engine eligibility: 0 = no, 1 = NT (both K-contiguous), 2 = TN (both K-strided, rows contiguous)
+int bf16_engine_mode(const kf_view& A, const kf_view& B, const float* mul) {
+    auto plain = [](const kf_view& v) {
+        return v.dtype == KF_BF16 && !v.ones_row && !v.ones_k && !v.square && v.batch_stride % 8 == 0 &&
+               (reinterpret_cast<uintptr_t>(v.p) & 15) == 0;
     };
-    return batch == 1 && !mul && c_dtype == KF_F32 && ok(A) && ok(B) && A.depth >= HBK;
+    if (mul || !plain(A) || !plain(B)) return 0;
+    auto nt = [](const kf_view& v) {
+        return v.k_stride == 1 && v.row_stride % 8 == 0 && v.depth % 8 == 0 &&
+               (v.k_tile_stride == 0 || (v.depth % 64 == 0 && v.k_tile_stride % 8 == 0));
+    };
+    auto tn = [](const kf_view& v) { return v.row_stride == 1 && v.k_stride % 8 == 0 && v.rows % 8 == 0 && v.k_tile_stride == 0; };
+    if (nt(A) && nt(B) && A.depth >= HBK) return 1;
+    if (tn(A) && tn(B) && A.rows > 1 && B.rows > 1) return 2;
+    return 0;
 }
 
-int launch_gemm_nt_bf16(float* C, int64_t ldc, const kf_view& A, const kf_view& B, float alpha, float beta, hipStream_t st) {
+int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
+                     int64_t batch, float alpha, float beta, hipStream_t st, int64_t c_tile_stride) {
     static bool configured = false;
     if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                HSMEM_BYTES) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HSMEM_BYTES) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                HSMEM_BYTES) != hipSuccess)
+            return KF_ERR_LAUNCH_FAILED;
         configured = true;
     }
     const int64_t M = A.rows, N = B.rows, K = A.depth;
-    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128), ksteps = cdiv(K, HBK);
+    const bool batch_sum = (c_batch_stride == 0 && batch > 1 && c_tile_stride == 0);
+    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128) * batch, ksteps = cdiv(K, HBK);
     int64_t ksplit = 1;
-    if (tiles < 1024 && ksteps >= 8) ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), ksteps / 4));
+    if (c_dtype == KF_F32 && tiles < 1024 && ksteps >= 8) ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), ksteps / 4));
     const int64_t kchunk = cdiv(ksteps, ksplit) * HBK;
     ksplit = cdiv(K, kchunk);
-    if (ksplit > 65535) return KF_ERR_INVALID_ARGUMENT;
-    const bool atomic = ksplit > 1;
+    const bool atomic = ksplit > 1 || batch_sum;
+    if (c_dtype == KF_BF16 && (atomic || beta != 0.0f)) return KF_ERR_INVALID_ARGUMENT;
     if (atomic && beta != 1.0f)
-        hipLaunchKernelGGL(scale_matrix_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(M * N, 256), 4096)), 1), dim3(256), 0, st,
-                           C, ldc, 0, static_cast<int>(M), static_cast<int>(N), beta);
+        hipLaunchKernelGGL(scale_matrix_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(M * N, 256), 4096)), batch_sum ? 1 : static_cast<unsigned>(batch)),
+                           dim3(256), 0, st, reinterpret_cast<float*>(C), ldc, c_batch_stride, static_cast<int>(M), static_cast<int>(N), beta);
     HalfGemmArgs h;
-    h.C = C; h.ldc = ldc; h.A = reinterpret_cast<const uint16_t*>(A.p); h.B = reinterpret_cast<const uint16_t*>(B.p);
-    h.lda = A.row_stride; h.ldb = B.row_stride; h.M = static_cast<int>(M); h.N = static_cast<int>(N); h.K = static_cast<int>(K);
-    h.kchunk = static_cast<int>(kchunk); h.alpha = alpha; h.atomic = atomic ? 1 : 0; h.beta = beta;
-    hipLaunchKernelGGL(gemm_nt_bf16_kernel, dim3(static_cast<unsigned>(cdiv(N, 128)), static_cast<unsigned>(cdiv(M, 128)), static_cast<unsigned>(ksplit)),
-                       dim3(NTHREADS), HSMEM_BYTES, st, h);
+    h.C = C; h.c_dtype = c_dtype; h.ldc = ldc; h.c_batch_stride = c_batch_stride;
+    h.A.p = reinterpret_cast<const uint16_t*>(A.p); h.A.batch_stride = A.batch_stride; h.A.rows = static_cast<int>(A.rows); h.A.depth = static_cast<int>(A.depth);
+    h.B.p = reinterpret_cast<const uint16_t*>(B.p); h.B.batch_stride = B.batch_stride; h.B.rows = static_cast<int>(B.rows); h.B.depth = static_cast<int>(B.depth);
+    h.A.ld = mode == 1 ? A.row_stride : A.k_stride;
+    h.B.ld = mode == 1 ? B.row_stride : B.k_stride;
+    h.A.kt_stride = A.k_tile_stride ? A.k_tile_stride : 64;
+    h.B.kt_stride = B.k_tile_stride ? B.k_tile_stride : 64;
+    h.c_tile_stride = c_tile_stride;
+    h.M = static_cast<int>(M); h.N = static_cast<int>(N); h.K = static_cast<int>(K);
+    h.ksplit = static_cast<int>(ksplit); h.kchunk = static_cast<int>(kchunk); h.alpha = alpha; h.beta = beta; h.atomic = atomic ? 1 : 0;
+    h.tiles_m = static_cast<int>(cdiv(M, 128)); h.tiles_n = static_cast<int>(cdiv(N, 128)); h.chunks = static_cast<int>(batch * ksplit);
+    const int64_t nblocks = 8 * cdiv(batch * ksplit, 8) * h.tiles_m * h.tiles_n;
+    if (nblocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+    const dim3 grid(static_cast<unsigned>(nblocks));
+    if (mode == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
     return launch_status();
 }
 
 int launch_gemm(void* Cv, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
                 int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, hipStream_t st,
-                int c_dtype = KF_F32) {
+                int c_dtype = KF_F32, int64_t c_tile_stride = 0) {
     float* C = reinterpret_cast<float*>(Cv);
     if (!C || !A.p || !B.p || batch < 0) return KF_ERR_INVALID_ARGUMENT;
     if (c_dtype != KF_F32 && c_dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
@@ -175,10 +205,15 @@ int launch_gemm(void* Cv, int64_t ldc, int64_t c_batch_stride, const kf_view& A,
     }
     const int64_t M = A.rows + A.ones_row, N = B.rows + B.ones_row, K = A.depth + A.ones_k;
     if (M <= 0 || N <= 0 || batch == 0) return KF_OK;
-    if (bf16_nt_eligible(A, B, batch, mul, c_dtype)) return launch_gemm_nt_bf16(C, ldc, A, B, alpha, beta, st);
+    if (const int mode = bf16_engine_mode(A, B, mul)) {
+        const bool accumulates = (c_batch_stride == 0 && batch > 1 && c_tile_stride == 0) || beta != 0.0f;
+        if (!(c_dtype == KF_BF16 && accumulates))
+            return launch_gemm_bf16(mode, Cv, c_dtype, ldc, c_batch_stride, A, B, batch, alpha, beta, st, c_tile_stride);
+    }
+    if (A.k_tile_stride || B.k_tile_stride) return KF_ERR_INVALID_ARGUMENT;  // tiled operands: bf16 NT engine only
     if (M >= (1LL << 30) || N >= (1LL << 30) || K >= (1LL << 30)) return KF_ERR_INVALID_ARGUMENT;
     const int64_t tiles = cdiv(M, BM) * cdiv(N, BN);
-    const bool batch_sum = (c_batch_stride == 0 && batch > 1);
+    const bool batch_sum = (c_batch_stride == 0 && batch > 1 && c_tile_stride == 0);
     // split-K so that small-output / deep-K contractions still fill 256 CUs
     int64_t ksplit = 1;
     const int64_t ksteps = cdiv(K, BK);
@@ -205,6 +240,7 @@ int launch_gemm(void* Cv, int64_t ldc, int64_t c_batch_stride, const kf_view& A,
     a.M = static_cast<int>(M); a.N = static_cast<int>(N); a.K = static_cast<int>(K);
     a.ksplit = static_cast<int>(ksplit); a.kchunk = static_cast<int>(kchunk);
     a.alpha = alpha; a.beta = beta; a.mul = mul; a.ld_mul = ld_mul; a.atomic = atomic ? 1 : 0;
+    a.c_tile_stride = c_tile_stride;
     dim3 grid(static_cast<unsigned>(cdiv(N, BN)), static_cast<unsigned>(cdiv(M, BM)), static_cast<unsigned>(batch * ksplit));
     if (A.dtype == KF_F32 && B.dtype == KF_F32) hipLaunchKernelGGL((gemm_kernel<F32, F32>), grid, dim3(NTHREADS), 0, st, a);
     else if (A.dtype == KF_BF16 && B.dtype == KF_F32) hipLaunchKernelGGL((gemm_kernel<BF16, F32>), grid, dim3(NTHREADS), 0, st, a);
@@ -537,6 +573,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
     kf_view v;
     v.p = p; v.dtype = dtype; v.batch_stride = bs; v.row_stride = rs; v.k_stride = ks;
     v.rows = rows; v.depth = depth; v.ones_row = ones_row; v.ones_k = ones_k; v.square = square;
+    v.k_tile_stride = 0;
     return v;
 }
 
@@ -547,7 +584,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 2; }
+int kf_abi_version(void) { return 3; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -725,15 +762,17 @@ int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip)
     return static_cast<int64_t>(sizeof(float)) * b * O * Ip;
 }
 
-int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dtype, int64_t Q, const void* G, const void* A,
-                      int in_dtype, int64_t b, int64_t R, int64_t O, int64_t I, int append_ones, float scale,
-                      void* workspace, int64_t workspace_bytes, void* stream) {
+int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dtype, int64_t p_k_tile_stride, int64_t Q,
+                      const void* G, const void* A, int in_dtype, int64_t b, int64_t R, int64_t O, int64_t I, int append_ones,
+                      float scale, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!scores || !P || !G || !A || Q < 0 || b < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
     if (in_dtype != KF_F32 && in_dtype != KF_BF16 && in_dtype != KF_F16) return KF_ERR_UNSUPPORTED_DTYPE;
     if (p_dtype != KF_F32 && p_dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
     if (Q == 0 || b == 0) return KF_OK;
     hipStream_t st = as_stream(stream);
     const int64_t Ip = I + (append_ones ? 1 : 0);
+    if (p_k_tile_stride != 0 && (R == 1 || p_dtype != KF_BF16 || (O * Ip) % 64 != 0 || p_k_tile_stride != Q * 64))
+        return KF_ERR_INVALID_ARGUMENT;
     if (R == 1) {
         ScoreArgs a;
         a.scores = scores; a.ld_scores = ld_scores; a.P = P; a.p_dtype = p_dtype; a.G = G; a.A = A; a.in_dtype = in_dtype;
@@ -759,12 +798,17 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dty
     // psg[n][o, i] = sum_r G[n,r,o] A'[n,r,i], stored in P's dtype: with bf16 P the contraction below runs on
     // the bf16 MFMA engine (fp32 accumulation), otherwise on the fp32 one.
     void* psg = workspace;
-    int rc = launch_gemm(psg, Ip, O * Ip, make_view(G, in_dtype, R * O, 1, O, O, R),
-                         make_view(A, in_dtype, R * I, 1, I, I, R, append_ones ? 1 : 0, 0), b, 1.0f, 0.0f, nullptr, 0, st, p_dtype);
+    const int64_t D = O * Ip;
+    const bool tiled = p_k_tile_stride != 0;  // both big-K operands k-tile-major: [D/64][rows][64]
+    int rc = launch_gemm(psg, Ip, tiled ? 0 : D, make_view(G, in_dtype, R * O, 1, O, O, R),
+                         make_view(A, in_dtype, R * I, 1, I, I, R, append_ones ? 1 : 0, 0), b, 1.0f, 0.0f, nullptr, 0, st, p_dtype,
+                         tiled ? b * 64 : 0);
     if (rc != KF_OK) return rc;
     // scores[q, n] += scale * sum_d P[q, d] psg[n, d]
-    return launch_gemm(scores, ld_scores, 0, make_view(P, p_dtype, 0, O * Ip, 1, Q, O * Ip),
-                       make_view(psg, p_dtype, 0, O * Ip, 1, b, O * Ip), 1, scale, 1.0f, nullptr, 0, st);
+    kf_view vp = make_view(P, p_dtype, 0, tiled ? 64 : D, 1, Q, D);
+    kf_view vg = make_view(psg, p_dtype, 0, tiled ? 64 : D, 1, b, D);
+    if (tiled) { vp.k_tile_stride = Q * 64; vg.k_tile_stride = b * 64; }
+    return launch_gemm(scores, ld_scores, 0, vp, vg, 1, scale, 1.0f, nullptr, 0, st);
 }
 
 int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream) {

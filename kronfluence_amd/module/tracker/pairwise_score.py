@@ -25,6 +25,18 @@ from kronfluence_amd.utils.constants import (
 
 
 class PairwiseScoreTracker(BaseTracker):
+    _tiled = None  # (source tensor, k-tile-major bf16 copy) of the held query gradients
+
+    def _tiled_queries(self, preconditioned: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool):
+        """k-tile-major copy of the bf16 query gradients, built once per train pass (see
+        ``ops.k_tile_major``); ``None`` when the fast layout does not apply."""
+        d = preconditioned.shape[1] * preconditioned.shape[2]
+        if preconditioned.dtype != torch.bfloat16 or g.shape[1] == 1 or d % 64 != 0 or g.dtype != torch.bfloat16:
+            return None
+        if self._tiled is None or self._tiled[0] is not preconditioned:
+            self._tiled = (preconditioned, ops.k_tile_major(preconditioned))
+        return self._tiled[1]
+
     def register_hooks(self) -> None:
         module = self.module
         storage = module.storage
@@ -56,7 +68,8 @@ class PairwiseScoreTracker(BaseTracker):
                 storage[PAIRWISE_SCORE_MATRIX_NAME] = scores
             if module.per_sample_gradient_process_fnc is None:
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
-                ops.pairwise_score(scores, offset, preconditioned, g, a, ones, scale=module.gradient_scale)
+                ops.pairwise_score(scores, offset, preconditioned, g, a, ones, scale=module.gradient_scale,
+                                   p_tiled=self._tiled_queries(preconditioned, g, a, ones))
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()
@@ -83,6 +96,7 @@ class PairwiseScoreTracker(BaseTracker):
         self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.module.score_sink = None
+        self._tiled = None
         self.clear_all_cache()
 
     def release_memory(self) -> None:

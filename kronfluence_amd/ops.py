@@ -28,11 +28,20 @@ def _contig(t: torch.Tensor) -> torch.Tensor:
 
 
 def view(t: torch.Tensor, batch_stride: int, row_stride: int, k_stride: int, rows: int, depth: int,
-         ones_row: bool = False, ones_k: bool = False, square: bool = False) -> kf_view:
+         ones_row: bool = False, ones_k: bool = False, square: bool = False, k_tile_stride: int = 0) -> kf_view:
     """Strided operand view over the STORAGE of ``t`` (strides in elements); ``t`` must be contiguous."""
     assert t.is_contiguous(), "kf_view describes raw storage; pass a contiguous tensor"
     return kf_view(t.data_ptr(), nat.dtype_code(t.dtype), batch_stride, row_stride, k_stride, rows, depth,
-                   int(ones_row), int(ones_k), int(square))
+                   int(ones_row), int(ones_k), int(square), k_tile_stride)
+
+
+def k_tile_major(p: torch.Tensor) -> torch.Tensor:
+    """``[rows, D] -> [D/64, rows, 64]`` (contiguous): the layout the bf16 score contraction streams best
+    (see ``kf_view.k_tile_stride``).  ``D`` must be a multiple of 64."""
+    rows = p.shape[0]
+    flat = p.reshape(rows, -1)
+    assert flat.shape[1] % 64 == 0
+    return flat.view(rows, flat.shape[1] // 64, 64).transpose(0, 1).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------
@@ -261,10 +270,11 @@ SCORE_EVENT_LOG: Optional[list] = None
 
 
 def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: torch.Tensor, a: torch.Tensor,
-                   append_ones: bool, scale: float = 1.0) -> None:
+                   append_ones: bool, scale: float = 1.0, p_tiled: Optional[torch.Tensor] = None) -> None:
     """``scores[:, col_offset:col_offset+b] += scale * <P_q, g_n>`` (kf_pairwise_score).
 
-    ``scores``: fp32 ``[Q, N]`` device buffer shared by all layers and all train batches of a shard."""
+    ``scores``: fp32 ``[Q, N]`` device buffer shared by all layers and all train batches of a shard.
+    ``p_tiled``: optional ``k_tile_major(p)`` copy (bf16, ``R > 1``, ``O*I' % 64 == 0``)."""
     nat.require_device(scores, "scores")
     nat.require_device(p, "p")
     assert scores.dtype == torch.float32 and p.dtype in (torch.float32, torch.bfloat16)
@@ -282,8 +292,9 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: to
         start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         start.record(torch.cuda.current_stream(g.device))
     nat.check(
-        nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.data_ptr(),
-                                    nat.dtype_code(p.dtype), q, g.data_ptr(),
+        nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1],
+                                    (p_tiled if p_tiled is not None else p).data_ptr(), nat.dtype_code(p.dtype),
+                                    q * 64 if p_tiled is not None else 0, q, g.data_ptr(),
                                     a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
                                     ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
         "kf_pairwise_score",

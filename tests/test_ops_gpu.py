@@ -258,3 +258,28 @@ def test_precondition_bf16_output(ops):
     got = ops.precondition(g.to(DEV), a.to(DEV), True, q_g.float().to(DEV), q_a.float().to(DEV), lam_inv.float().to(DEV),
                            out_dtype=torch.bfloat16)
     assert got.dtype == torch.bfloat16 and rel(got, want) <= 4e-3
+
+
+@pytest.mark.parametrize("b,r,o,i", [(3, 64, 64, 128), (5, 36, 128, 2304), (2, 1024, 64, 1600), (4, 7, 256, 1152), (3, 100, 8, 16)])
+def test_per_sample_gradient_bf16_tn_engine(ops, b, r, o, i):
+    """TN layout (k = position, strided): register-transposed staging of the bf16 engine; fp32 output."""
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    want = ref.linear_per_sample_gradient(a.double(), g.double(), False)
+    got = ops.per_sample_gradient(g.to(DEV), a.to(DEV), False)
+    assert got.shape == want.shape and rel(got, want) <= TOL
+
+
+@pytest.mark.parametrize("q,b,r,o,i", [(40, 33, 50, 64, 128), (100, 130, 36, 128, 2304), (9, 5, 7, 8, 27 * 8)])
+def test_pairwise_score_k_tile_major_layout(ops, q, b, r, o, i):
+    """bf16 P handed over k-tile-major ([D/64][Q][64]); per-sample gradients are written tiled too."""
+    p = _rand(q, o, i, seed=7).to(torch.bfloat16)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    want = ref.linear_pairwise_score(p.double(), a.double(), g.double(), False)
+    pd = p.to(DEV)
+    tiled = ops.k_tile_major(pd)
+    assert tiled.shape == (o * i // 64, q, 64)
+    scores = torch.zeros(q, b, device=DEV)
+    ops.pairwise_score(scores, 0, pd, g.to(DEV), a.to(DEV), False, p_tiled=tiled)
+    plain = torch.zeros(q, b, device=DEV)
+    ops.pairwise_score(plain, 0, pd, g.to(DEV), a.to(DEV), False)
+    assert rel(scores, want) <= 4e-3 and rel(scores, plain) <= 2e-5
