@@ -13,8 +13,9 @@ gather) and the job is timed barrier-to-barrier, MAX over ranks ("strong" scalin
 fixed as N grows).
 
 Workloads (synthetic random-weight models of the BASELINE.json layer shapes):
+  resnet9    configs[1] (DEFAULT): CIFAR-10 ResNet-9 (Conv2d tracked), 50 000 train x 1 000 query,
+             bf16 autocast, bf16 query gradients (the reference's all_low_precision preset)
   mnist_mlp  configs[0]: 784-1024-1024-1024-10 MLP, 1 000 train x 100 query, fp32
-  resnet9    configs[1]: CIFAR-10 ResNet-9 (Conv2d tracked), 50 000 x 1 000, bf16 autocast
 
 The ``roofline`` object times the dominant kernel launches (the pairwise-score contraction) with HIP
 events on the launch stream inside the timed region; ``cpu_baseline`` times the CPU oracle
@@ -140,7 +141,7 @@ def main() -> None:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default=os.environ.get("KF_BENCH_WORKLOAD", "mnist_mlp"), choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=os.environ.get("KF_BENCH_WORKLOAD", "resnet9"), choices=sorted(WORKLOADS))
     ap.add_argument("--n-train", type=int, default=None)
     ap.add_argument("--n-query", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
