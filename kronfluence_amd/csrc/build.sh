@@ -8,7 +8,12 @@ flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno
 mkdir -p "${here}/obj"
 pids=()
 for src in kf_kernels kf_eigh; do
-  if [[ ! -f "${here}/obj/${src}.o" || "${here}/${src}.hip" -nt "${here}/obj/${src}.o" || "${here}/kf_engine.h" -nt "${here}/obj/${src}.o" || "${here}/../../include/kronfluence_hip.h" -nt "${here}/obj/${src}.o" ]]; then
+  stale=0
+  [[ -f "${here}/obj/${src}.o" ]] || stale=1
+  for dep in "${here}/${src}.hip" "${here}"/*.h "${here}/../../include/kronfluence_hip.h"; do
+    [[ "${dep}" -nt "${here}/obj/${src}.o" ]] && stale=1
+  done
+  if [[ ${stale} -eq 1 ]]; then
     "${HIPCC}" "${flags[@]}" -c "${here}/${src}.hip" -o "${here}/obj/${src}.o" &
     pids+=($!)
   fi

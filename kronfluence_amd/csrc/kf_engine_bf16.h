@@ -50,6 +50,7 @@ struct HalfGemmArgs {
     float alpha, beta;
     int atomic;
     int tiles_m, tiles_n, chunks;   // XCD-aware 1-D grid: chunks = batch * ksplit
+    int symmetric;                  // TN only, A == B: upper-triangular tile pairs, both triangles written (SYRK)
     int64_t c_tile_stride;          // != 0: C[z] is one ROW (index z) of a k-tile-major matrix whose k index is
                                     // d = m*ldc + n:  element at (d/64)*c_tile_stride + z*64 + d%64
 };
@@ -88,12 +89,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
     // only): all output tiles of one (batch, k-chunk) slab go to the SAME XCD in consecutive order, so
     // the 8 m-tiles x 8 n-tiles that re-read the same A / B k-range hit in that XCD's 4 MB L2 instead
     // of each XCD pulling its own copy over the fabric.
-    const int tiles = a.tiles_m * a.tiles_n;
+    const int tiles = a.symmetric ? a.tiles_m * (a.tiles_m + 1) / 2 : a.tiles_m * a.tiles_n;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
     const int chunk = (j / tiles) * 8 + xcd;
     if (chunk >= a.chunks) return;
     const int tile = j % tiles;
-    const int n0 = (tile % a.tiles_n) * 128, m0 = (tile / a.tiles_n) * 128;
+    int tile_i = tile / a.tiles_n, tile_j = tile % a.tiles_n;
+    if (a.symmetric) {  // tile -> (tile_i <= tile_j) of the upper triangle
+        int t = tile;
+        tile_i = 0;
+        while (t >= a.tiles_m - tile_i) { t -= a.tiles_m - tile_i; ++tile_i; }
+        tile_j = tile_i + t;
+    }
+    const int n0 = tile_j * 128, m0 = tile_i * 128;
+    const bool mirror = a.symmetric && tile_i != tile_j;
     const int z = chunk / a.ksplit, ks = chunk % a.ksplit;
     const int k_begin = ks * a.kchunk;
     const int k_end = min(a.K, k_begin + a.kchunk);
@@ -215,6 +224,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
                         float* dst = reinterpret_cast<float*>(a.C) + idx;
                         if (a.atomic) atomicAdd(dst, v);
                         else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
+                        if (mirror) {  // off-diagonal tile pair: mirror into the lower triangle
+                            float* lo = reinterpret_cast<float*>(a.C) + cz + static_cast<int64_t>(n) * a.ldc + m;
+                            if (a.atomic) atomicAdd(lo, v);
+                            else *lo = (a.beta == 0.0f) ? v : v + a.beta * *lo;
+                        }
                     }
                 }
             }

@@ -147,7 +147,7 @@ int bf16_engine_mode(const kf_view& A, const kf_view& B, const float* mul) {
 }
 
 int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
-                     int64_t batch, float alpha, float beta, hipStream_t st, int64_t c_tile_stride) {
+                     int64_t batch, float alpha, float beta, hipStream_t st, int64_t c_tile_stride, bool symmetric = false) {
     static bool configured = false;
     if (!configured) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -159,7 +159,8 @@ int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batc
     }
     const int64_t M = A.rows, N = B.rows, K = A.depth;
     const bool batch_sum = (c_batch_stride == 0 && batch > 1 && c_tile_stride == 0);
-    const int64_t tiles = cdiv(M, 128) * cdiv(N, 128) * batch, ksteps = cdiv(K, HBK);
+    const int64_t tm = cdiv(M, 128), tn = cdiv(N, 128);
+    const int64_t tiles = (symmetric ? tm * (tm + 1) / 2 : tm * tn) * batch, ksteps = cdiv(K, HBK);
     int64_t ksplit = 1;
     if (c_dtype == KF_F32 && tiles < 1024 && ksteps >= 8) ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(1024, tiles), ksteps / 4));
     const int64_t kchunk = cdiv(ksteps, ksplit) * HBK;
@@ -180,8 +181,9 @@ int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batc
     h.c_tile_stride = c_tile_stride;
     h.M = static_cast<int>(M); h.N = static_cast<int>(N); h.K = static_cast<int>(K);
     h.ksplit = static_cast<int>(ksplit); h.kchunk = static_cast<int>(kchunk); h.alpha = alpha; h.beta = beta; h.atomic = atomic ? 1 : 0;
-    h.tiles_m = static_cast<int>(cdiv(M, 128)); h.tiles_n = static_cast<int>(cdiv(N, 128)); h.chunks = static_cast<int>(batch * ksplit);
-    const int64_t nblocks = 8 * cdiv(batch * ksplit, 8) * h.tiles_m * h.tiles_n;
+    h.tiles_m = static_cast<int>(tm); h.tiles_n = static_cast<int>(tn); h.chunks = static_cast<int>(batch * ksplit);
+    h.symmetric = symmetric ? 1 : 0;
+    const int64_t nblocks = 8 * cdiv(batch * ksplit, 8) * (symmetric ? tm * (tm + 1) / 2 : tm * tn);
     if (nblocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
     const dim3 grid(static_cast<unsigned>(nblocks));
     if (mode == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
@@ -619,6 +621,12 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
         else hipLaunchKernelGGL(add_count_kernel, dim3(1), dim3(1), 0, st, count, n_rows);
     }
     if (n_rows == 0) return launch_status();
+    // bf16 rows without mask / bias column: the TN bf16 MFMA engine in symmetric (upper-triangle) mode
+    if (in_dtype == KF_BF16 && !mask && !append_ones && rows_inner >= n_rows && col_stride == 1 && row_stride % 8 == 0 &&
+        d_in % 8 == 0 && d_in > 1 && (reinterpret_cast<uintptr_t>(X) & 15) == 0) {
+        kf_view v = make_view(X, KF_BF16, 0, 1, row_stride, d_in, n_rows);
+        return launch_gemm_bf16(2, C, KF_F32, ldc, 0, v, v, 1, alpha, 1.0f, st, 0, true);
+    }
     SyrkArgs a;
     a.C = C; a.ldc = ldc;
     a.base.p = X; a.base.n_rows = n_rows; a.base.rows_inner = rows_inner;

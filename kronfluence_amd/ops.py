@@ -149,6 +149,11 @@ def conv_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, a
     g = _contig(g)
     b, o, h, w = g.shape
     p = h * w
+    if g.dtype == torch.bfloat16 and o % 8 == 0 and o > 8:
+        # [b,P,O] rows feed the bf16 MFMA engine (k = row index strided, columns contiguous)
+        rows = g.flatten(2).transpose(1, 2).contiguous()
+        syrk_accum(cov, rows, b * p, o, max(b * p, 1), 0, o, 1, None, False, alpha, count)
+        return
     syrk_accum(cov, g, b * p, o, p, o * p, 1, p, None, False, alpha, count)
 
 

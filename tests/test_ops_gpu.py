@@ -283,3 +283,27 @@ def test_pairwise_score_k_tile_major_layout(ops, q, b, r, o, i):
     plain = torch.zeros(q, b, device=DEV)
     ops.pairwise_score(plain, 0, pd, g.to(DEV), a.to(DEV), False)
     assert rel(scores, want) <= 4e-3 and rel(scores, plain) <= 2e-5
+
+
+@pytest.mark.parametrize("n,d", [(300, 128), (5000, 1152), (1030, 264), (64, 16)])
+def test_syrk_bf16_symmetric_engine(ops, n, d):
+    """bf16 rows, no mask / bias column: upper-triangular tile pairs on the bf16 TN engine."""
+    x = _rand(n, d, dtype=torch.bfloat16)
+    want = x.double().t() @ x.double()
+    cov = torch.zeros(d, d, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for _ in range(2):
+        ops.linear_activation_cov(cov, cnt, x.to(DEV), None, False)
+    assert rel(cov, 2 * want) <= TOL and int(cnt) == 2 * n
+    assert rel(cov, cov.t()) <= 1e-6
+
+
+def test_conv_gradient_cov_bf16(ops):
+    g = _rand(6, 64, 5, 7, dtype=torch.bfloat16)
+    gflat, gcount = ref.conv_flat_gradient(g.double())
+    want = torch.zeros(64, 64, dtype=torch.float64)
+    ref.covariance_update(want, gflat)
+    cov = torch.zeros(64, 64, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.conv_gradient_cov(cov, cnt, g.to(DEV))
+    assert rel(cov, want) <= TOL and int(cnt) == gcount
