@@ -32,8 +32,9 @@ class State:
             self.local_process_index = max(local_rank, 0)
         elif world > 1 and local_rank >= 0:
             backend = "gloo" if cpu or not torch.cuda.is_available() else "nccl"  # "nccl" == RCCL on ROCm
-            if backend == "nccl":
-                torch.cuda.set_device(local_rank)
+            backend = os.environ.get("KF_DIST_BACKEND", backend)  # test hook: 2 ranks sharing one GPU need gloo
+            if torch.cuda.is_available() and not cpu:
+                torch.cuda.set_device(local_rank % torch.cuda.device_count())
             dist.init_process_group(backend=backend)
             self.num_processes, self.process_index = dist.get_world_size(), dist.get_rank()
             self.local_process_index = local_rank
@@ -42,7 +43,8 @@ class State:
         if cpu or not torch.cuda.is_available():
             self.device = torch.device("cpu")
         else:
-            self.device = torch.device("cuda", self.local_process_index if self.num_processes > 1 else torch.cuda.current_device())
+            index = self.local_process_index if self.num_processes > 1 else torch.cuda.current_device()
+            self.device = torch.device("cuda", index % torch.cuda.device_count())
             torch.cuda.set_device(self.device)
         self.initialized = True
 
