@@ -219,7 +219,7 @@ def main() -> None:
 
     # -- factor fit (cov + eigen + lambda), timed per sub-stage --------------------------------------
     fit_times = {"covariance": 0.0, "eigendecomposition": 0.0, "lambda": 0.0}
-    for _ in range(max(1, args.factor_reps) + 1):  # first pass = warm-up (allocator, kernel load)
+    for _ in range(args.factor_reps + 1 if args.factor_reps > 0 else 1):  # first pass = warm-up; --factor-reps 0: single cold pass
         t_cov, (_, cov) = timed(lambda: fit_covariance_matrices_with_loader(model, state, task, factor_loader(), fargs))
         if world > 1:  # the reference hands factors to the other ranks through the file system
             box = [cov]

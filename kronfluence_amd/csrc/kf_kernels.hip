@@ -404,6 +404,46 @@ __global__ void im2col_kernel(Im2colArgs a) {
     }
 }
 
+// 8 consecutive patch elements per thread, one 16-B store (2-byte output dtypes, I' % 8 == 0, groups == 1):
+// the (c, ky, kx) decomposition is done once per octet and advanced incrementally.
+__global__ void im2col_vec8_kernel(Im2colArgs a) {
+    const int P = static_cast<int>(a.O1 * a.O2), Ip = static_cast<int>(a.Ip), octs = Ip >> 3;
+    const int64_t total = a.b * P * octs;
+    const int H = static_cast<int>(a.H), W = static_cast<int>(a.W);
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int iv = static_cast<int>(e % octs);
+        const int64_t bp = e / octs;
+        const int p = static_cast<int>(bp % P);
+        const int64_t n = bp / P;
+        const int oy = p / static_cast<int>(a.O2), ox = p - oy * static_cast<int>(a.O2);
+        const int by = oy * a.s1 - a.p1, bx = ox * a.s2 - a.p2;
+        int i0 = iv * 8;
+        int kx = i0 % a.k2, ky = (i0 / a.k2) % a.k1, c = i0 / (a.k1 * a.k2);
+        const int64_t img = n * a.C * H * W;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int iy = by + ky * a.d1, ix = bx + kx * a.d2;
+            uint32_t bits = 0;
+            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
+                const int64_t src = img + (static_cast<int64_t>(c) * H + iy) * W + ix;
+                if (a.in_dtype == a.out_dtype) {
+                    bits = reinterpret_cast<const uint16_t*>(a.x)[src];
+                } else {
+                    uint16_t tmp;
+                    store_as(&tmp, a.out_dtype, 0, load_f32(a.x, a.in_dtype, src));
+                    bits = tmp;
+                }
+            }
+            if (j & 1) w[j >> 1] |= bits << 16; else w[j >> 1] = bits;
+            if (++kx == a.k2) { kx = 0; if (++ky == a.k1) { ky = 0; ++c; } }
+        }
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        reinterpret_cast<u32x4_t*>(a.out)[e] = u32x4_t{w[0], w[1], w[2], w[3]};
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Stage 2: Lambda for R > 1 -- per sample z: M_z = Gt_z^T At_z (K = R), Lambda += M_z^2
 // ------------------------------------------------------------------------------------------------
@@ -678,6 +718,11 @@ int kf_im2col(void* out, int out_dtype, const void* x, int in_dtype, int64_t b, 
     a.Ip = a.Cg * k1 * k2 + a.append_ones;
     const int64_t total = b * a.O1 * a.O2 * a.Ip;
     if (total == 0) return KF_OK;
+    const bool two_byte = out_dtype == KF_BF16 || out_dtype == KF_F16;
+    if (two_byte && groups == 1 && a.Ip % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && total < (1LL << 40)) {
+        hipLaunchKernelGGL(im2col_vec8_kernel, dim3(stream_grid(total / 8) * 4), dim3(256), 0, as_stream(stream), a);
+        return launch_status();
+    }
     hipLaunchKernelGGL(im2col_kernel, dim3(stream_grid(total)), dim3(256), 0, as_stream(stream), a);
     return launch_status();
 }

@@ -307,3 +307,17 @@ def test_conv_gradient_cov_bf16(ops):
     cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
     ops.conv_gradient_cov(cov, cnt, g.to(DEV))
     assert rel(cov, want) <= TOL and int(cnt) == gcount
+
+
+@pytest.mark.parametrize("c", [dict(cin=8, cout=16, k=3, stride=1, padding=1, dilation=1, groups=1, bias=False, hw=(9, 7)),
+                               dict(cin=16, cout=8, k=5, stride=2, padding=2, dilation=1, groups=1, bias=False, hw=(12, 12)),
+                               dict(cin=8, cout=8, k=(3, 3), stride=1, padding=0, dilation=2, groups=1, bias=False, hw=(10, 10))])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_im2col_vectorised_path(ops, c, dtype):
+    """I' % 8 == 0 and a 2-byte output dtype take the 16-B-store kernel; must equal unfold exactly."""
+    conv = _conv(c)
+    x = _rand(3, c["cin"], *c["hw"], dtype=dtype)
+    want = ref.conv_patches(x.float(), conv)
+    got = ops.im2col(x.to(DEV), conv, False, torch.bfloat16)
+    assert got.shape == want.shape
+    assert torch.equal(got.cpu().float(), want.to(torch.bfloat16).float())
