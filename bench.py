@@ -171,7 +171,10 @@ def main() -> None:
     train = synth(spec, n_train, 1, dev)
     query = synth(spec, n_query, 2, dev)
     amp = spec["amp"]
-    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=amp)
+    low = amp == torch.bfloat16  # the reference's all_low_precision preset: bf16 factors / gradients
+    # (covariances stay fp32: at least the reference's precision, and the fp64 eigensolver converges faster on them)
+    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=amp, **(dict(
+        per_sample_gradient_dtype=torch.bfloat16, lambda_dtype=torch.bfloat16) if low else {}))
     per_dev_q = max(1, min(spec["query_batch"], -(-n_query // world)))
     # hold every preconditioned query gradient resident in HBM (P: n_query x D) -> ONE train pass per step
     accumulate = -(-n_query // (per_dev_q * world))

@@ -124,6 +124,12 @@ typedef struct kf_view {
 int kf_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view* A, const kf_view* B,
             int64_t batch, float alpha, float beta, const float* mul, int64_t ld_mul, void* stream);
 
+/* As kf_gemm without accumulation, with the output stored in c_dtype (KF_F32 or KF_BF16):
+ * C[z,m,n] = alpha * sum_k A(z,m,k) B(z,n,k).  bf16 operands that are both K-contiguous (or both
+ * K-strided) with extents / strides multiples of 8 run on the bf16 MFMA engine. */
+int kf_gemm_out(void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const kf_view* A,
+                const kf_view* B, int64_t batch, float alpha, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 -- eigendecomposition and Lambda
  * ------------------------------------------------------------------------------------------- */
@@ -149,11 +155,13 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
  * into the eigenbasis (two kf_gemm calls).  Identical mathematics to
  * module/tracker/factor.py:218-226 (Qg^T (g_b Qa), square_, sum(0)) because
  * Qg^T (sum_r g_r a_r^T) Qa = (G Qg)^T (A' Qa); costs 2 R (I'^2 + O^2 + O I') instead of
- * 2 O I' (I' + O + R) flops per sample.  Gt: [b,R,O] fp32 contiguous, At: [b,R,I'] fp32 contiguous.
+ * 2 O I' (I' + O + R) flops per sample.  Gt: [b,R,O], At: [b,R,I'] contiguous, dtype KF_F32, or KF_BF16
+ * (FactorArguments.lambda_dtype = bf16 of the reference's low-precision preset: bf16 MFMA engine, fp32
+ * accumulation; needs R > 1, O % 8 == 0, I' % 8 == 0).
  * scale multiplies the per-sample gradient (gradient_scale, factor.py:269-270).
  */
-int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const float* Gt, const float* At, int64_t b,
-                    int64_t R, int64_t O, int64_t Ip, float scale, void* stream);
+int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gt, const void* At, int dtype,
+                    int64_t b, int64_t R, int64_t O, int64_t Ip, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Stage 3 -- preconditioning and pairwise scores

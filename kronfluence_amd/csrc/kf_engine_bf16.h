@@ -81,33 +81,11 @@ __device__ __forceinline__ void transpose8x8_b16(u32x4& r0, u32x4& r1, u32x4& r2
 #undef KF_T8_ROW
 #undef KF_T8_WORD
 
+// acc += (tile m0,n0 of) A B^T over k in [k_begin, k_end); all 256 threads; hsm: HSMEM_BYTES of LDS.
 template <bool TRANS>
-__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+__device__ __forceinline__ void bf16_tile_mainloop(const HalfGemmArgs& a, const uint16_t* Ab, const uint16_t* Bb, int m0, int n0,
+                                                   int k_begin, int k_end, f32x16 (&acc)[2][2], unsigned char* hsm) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    // XCD-aware block -> work mapping.  Workgroup L is dispatched to XCD L % 8 (observed, used for speed
-    // only): all output tiles of one (batch, k-chunk) slab go to the SAME XCD in consecutive order, so
-    // the 8 m-tiles x 8 n-tiles that re-read the same A / B k-range hit in that XCD's 4 MB L2 instead
-    // of each XCD pulling its own copy over the fabric.
-    const int tiles = a.symmetric ? a.tiles_m * (a.tiles_m + 1) / 2 : a.tiles_m * a.tiles_n;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int chunk = (j / tiles) * 8 + xcd;
-    if (chunk >= a.chunks) return;
-    const int tile = j % tiles;
-    int tile_i = tile / a.tiles_n, tile_j = tile % a.tiles_n;
-    if (a.symmetric) {  // tile -> (tile_i <= tile_j) of the upper triangle
-        int t = tile;
-        tile_i = 0;
-        while (t >= a.tiles_m - tile_i) { t -= a.tiles_m - tile_i; ++tile_i; }
-        tile_j = tile_i + t;
-    }
-    const int n0 = tile_j * 128, m0 = tile_i * 128;
-    const bool mirror = a.symmetric && tile_i != tile_j;
-    const int z = chunk / a.ksplit, ks = chunk % a.ksplit;
-    const int k_begin = ks * a.kchunk;
-    const int k_end = min(a.K, k_begin + a.kchunk);
-    const uint16_t* Ab = a.A.p + static_cast<int64_t>(z) * a.A.batch_stride;
-    const uint16_t* Bb = a.B.p + static_cast<int64_t>(z) * a.B.batch_stride;
     const u32x4 zero = {0u, 0u, 0u, 0u};
 
     // Eight named staging registers (no arrays, no lambdas: everything stays in VGPRs).
@@ -169,8 +147,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
         }                                                                                                   \
     } while (0)
 
-    f32x16 acc[2][2];
-    zero_acc(acc);
     if (k_begin < k_end) {
         KF_FETCH(k_begin);
         KF_STASH(0, k_begin);
@@ -203,7 +179,79 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
 #undef KF_FETCH
 #undef KF_TN_LOAD
 #undef KF_NT_LOAD
+}
+
+template <bool TRANS>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // XCD-aware block -> work mapping.  Workgroup L is dispatched to XCD L % 8 (observed, used for speed
+    // only): all output tiles of one (batch, k-chunk) slab go to the SAME XCD in consecutive order, so
+    // the 8 m-tiles x 8 n-tiles that re-read the same A / B k-range hit in that XCD's 4 MB L2 instead
+    // of each XCD pulling its own copy over the fabric.
+    const int tiles = a.symmetric ? a.tiles_m * (a.tiles_m + 1) / 2 : a.tiles_m * a.tiles_n;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int chunk = (j / tiles) * 8 + xcd;
+    if (chunk >= a.chunks) return;
+    const int tile = j % tiles;
+    int tile_i = tile / a.tiles_n, tile_j = tile % a.tiles_n;
+    if (a.symmetric) {  // tile -> (tile_i <= tile_j) of the upper triangle
+        int t = tile;
+        tile_i = 0;
+        while (t >= a.tiles_m - tile_i) { t -= a.tiles_m - tile_i; ++tile_i; }
+        tile_j = tile_i + t;
+    }
+    const int n0 = tile_j * 128, m0 = tile_i * 128;
+    const bool mirror = a.symmetric && tile_i != tile_j;
+    const int z = chunk / a.ksplit, ks = chunk % a.ksplit;
+    const int k_begin = ks * a.kchunk;
+    const int k_end = min(a.K, k_begin + a.kchunk);
+    const uint16_t* Ab = a.A.p + static_cast<int64_t>(z) * a.A.batch_stride;
+    const uint16_t* Bb = a.B.p + static_cast<int64_t>(z) * a.B.batch_stride;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    bf16_tile_mainloop<TRANS>(a, Ab, Bb, m0, n0, k_begin, k_end, acc, hsm);
     const int64_t cz = static_cast<int64_t>(z) * a.c_batch_stride;
+    if (a.c_dtype == BF16) {
+        // bf16 output: convert in registers, transpose through LDS (pitch 272 B) and write 16 B per lane --
+        // the direct fragment layout would issue 64 two-byte stores per lane (measured store-bound).
+        constexpr int OP = 272;
+        __syncthreads();  // the mainloop's LDS buffers are free
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = acc_row(wm, ti, r, lane), nl = acc_col(wn, tj, lane);
+                    uint32_t u = __float_as_uint(a.alpha * acc[ti][tj][r]);
+                    if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;
+                    else u += 0x7fffu + ((u >> 16) & 1u);
+                    *reinterpret_cast<uint16_t*>(hsm + ml * OP + nl * 2) = static_cast<uint16_t>(u >> 16);
+                }
+        __syncthreads();
+        uint16_t* Cb = reinterpret_cast<uint16_t*>(a.C);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int id = tid + 256 * it, ml = id >> 4, ch = id & 15;
+            const int m = m0 + ml, n = n0 + ch * 8;
+            if (m < a.M && n < a.N) {
+                const int64_t d = static_cast<int64_t>(m) * a.ldc + n;
+                const int64_t idx = a.c_tile_stride ? (d >> 6) * a.c_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63) : cz + d;
+                const unsigned char* src = hsm + ml * OP + ch * 16;
+                if (n + 8 <= a.N && (idx & 7) == 0) {
+                    *reinterpret_cast<u32x4*>(Cb + idx) = *reinterpret_cast<const u32x4*>(src);
+                } else {
+                    for (int e = 0; e < 8 && n + e < a.N; ++e) {
+                        const int64_t de = d + e;
+                        const int64_t ie = a.c_tile_stride ? (de >> 6) * a.c_tile_stride + static_cast<int64_t>(z) * 64 + (de & 63) : cz + de;
+                        Cb[ie] = reinterpret_cast<const uint16_t*>(src)[e];
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -212,25 +260,58 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + acc_row(wm, ti, r, lane), n = n0 + acc_col(wn, tj, lane);
                 if (m < a.M && n < a.N) {
-                    int64_t idx = cz + static_cast<int64_t>(m) * a.ldc + n;
-                    if (a.c_tile_stride) {
-                        const int64_t d = static_cast<int64_t>(m) * a.ldc + n;
-                        idx = (d >> 6) * a.c_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
-                    }
+                    const int64_t idx = cz + static_cast<int64_t>(m) * a.ldc + n;
                     const float v = a.alpha * acc[ti][tj][r];
-                    if (a.c_dtype == BF16) {
-                        bf16_store(a.C, idx, v);
-                    } else {
-                        float* dst = reinterpret_cast<float*>(a.C) + idx;
-                        if (a.atomic) atomicAdd(dst, v);
-                        else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
-                        if (mirror) {  // off-diagonal tile pair: mirror into the lower triangle
-                            float* lo = reinterpret_cast<float*>(a.C) + cz + static_cast<int64_t>(n) * a.ldc + m;
-                            if (a.atomic) atomicAdd(lo, v);
-                            else *lo = (a.beta == 0.0f) ? v : v + a.beta * *lo;
-                        }
+                    float* dst = reinterpret_cast<float*>(a.C) + idx;
+                    if (a.atomic) atomicAdd(dst, v);
+                    else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
+                    if (mirror) {  // off-diagonal tile pair: mirror into the lower triangle
+                        float* lo = reinterpret_cast<float*>(a.C) + cz + static_cast<int64_t>(n) * a.ldc + m;
+                        if (a.atomic) atomicAdd(lo, v);
+                        else *lo = (a.beta == 0.0f) ? v : v + a.beta * *lo;
                     }
                 }
+            }
+}
+
+// Lambda += scale2 * sum_z ( sum_k A[z][k,m] B[z][k,n] )^2 -- the EK-FAC corrected eigenvalues from bf16
+// rotated gradient factors (module/tracker/factor.py:218-226): TN tiles per sample, squared and summed in
+// registers over this workgroup's sample range, one fp32 atomic per output element at the end.
+struct HalfLambdaArgs {
+    HalfGemmArgs g;      // operands / shapes (C = Lambda fp32, ldc); batch handled by the z loop below
+    int batch, zchunk;
+    float scale2;
+};
+
+__global__ __launch_bounds__(NTHREADS) void lambda_bf16_kernel(HalfLambdaArgs la) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    const HalfGemmArgs& a = la.g;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    const int z_begin = blockIdx.z * la.zchunk, z_end = min(la.batch, z_begin + la.zchunk);
+    f32x16 sq[2][2];
+    zero_acc(sq);
+    for (int z = z_begin; z < z_end; ++z) {
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        bf16_tile_mainloop<true>(a, a.A.p + static_cast<int64_t>(z) * a.A.batch_stride, a.B.p + static_cast<int64_t>(z) * a.B.batch_stride,
+                                 m0, n0, 0, a.K, acc, hsm);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sq[i][j][r] = fmaf(acc[i][j][r], acc[i][j][r], sq[i][j][r]);
+    }
+    float* L = reinterpret_cast<float*>(a.C);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + acc_row(wm, i, r, lane), n = n0 + acc_col(wn, j, lane);
+                if (m < a.M && n < a.N) atomicAdd(L + static_cast<int64_t>(m) * a.ldc + n, la.scale2 * sq[i][j][r]);
             }
 }
 

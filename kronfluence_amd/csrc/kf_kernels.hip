@@ -626,7 +626,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 3; }
+int kf_abi_version(void) { return 4; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -733,11 +733,52 @@ int kf_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view* A, con
     return launch_gemm(C, ldc, c_batch_stride, *A, *B, batch, alpha, beta, mul, ld_mul, as_stream(stream));
 }
 
-int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const float* Gt, const float* At, int64_t b, int64_t R,
+int kf_gemm_out(void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const kf_view* A, const kf_view* B, int64_t batch,
+                float alpha, void* stream) {
+    if (!A || !B) return KF_ERR_INVALID_ARGUMENT;
+    if (c_batch_stride == 0 && batch > 1) return KF_ERR_INVALID_ARGUMENT;
+    return launch_gemm(C, ldc, c_batch_stride, *A, *B, batch, alpha, 0.0f, nullptr, 0, as_stream(stream), c_dtype);
+}
+
+int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gtv, const void* Atv, int dtype, int64_t b, int64_t R,
                     int64_t O, int64_t Ip, float scale, void* stream) {
-    if (!Lambda || !Gt || !At || b < 0 || R <= 0 || O <= 0 || Ip <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!Lambda || !Gtv || !Atv || b < 0 || R <= 0 || O <= 0 || Ip <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (dtype != KF_F32 && dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
     if (b == 0) return KF_OK;
     hipStream_t st = as_stream(stream);
+    if (dtype == KF_BF16) {
+        // bf16 rotated factors: TN tiles on the bf16 MFMA engine, squared + summed over samples in registers
+        if (R == 1 || O % 8 != 0 || Ip % 8 != 0 || ((reinterpret_cast<uintptr_t>(Gtv) | reinterpret_cast<uintptr_t>(Atv)) & 15) != 0)
+            return KF_ERR_INVALID_ARGUMENT;
+        static bool configured = false;
+        if (!configured) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    HSMEM_BYTES) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            configured = true;
+        }
+        HalfLambdaArgs la;
+        HalfGemmArgs& h = la.g;
+        h.C = Lambda; h.c_dtype = KF_F32; h.ldc = ld_lambda; h.c_batch_stride = 0;
+        h.A.p = reinterpret_cast<const uint16_t*>(Gtv); h.A.batch_stride = R * O; h.A.ld = O; h.A.kt_stride = 64;
+        h.A.rows = static_cast<int>(O); h.A.depth = static_cast<int>(R);
+        h.B.p = reinterpret_cast<const uint16_t*>(Atv); h.B.batch_stride = R * Ip; h.B.ld = Ip; h.B.kt_stride = 64;
+        h.B.rows = static_cast<int>(Ip); h.B.depth = static_cast<int>(R);
+        h.M = static_cast<int>(O); h.N = static_cast<int>(Ip); h.K = static_cast<int>(R);
+        h.ksplit = 1; h.kchunk = static_cast<int>(cdiv(R, HBK) * HBK); h.alpha = 1.0f; h.beta = 0.0f; h.atomic = 1;
+        h.tiles_m = static_cast<int>(cdiv(O, 128)); h.tiles_n = static_cast<int>(cdiv(Ip, 128)); h.chunks = 1;
+        h.symmetric = 0; h.c_tile_stride = 0;
+        const int64_t tiles = static_cast<int64_t>(h.tiles_m) * h.tiles_n;
+        int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, tiles)));
+        la.zchunk = static_cast<int>(cdiv(b, zsplit));
+        zsplit = cdiv(b, la.zchunk);
+        if (zsplit > 65535) return KF_ERR_INVALID_ARGUMENT;
+        la.batch = static_cast<int>(b); la.scale2 = scale * scale;
+        hipLaunchKernelGGL(lambda_bf16_kernel, dim3(static_cast<unsigned>(h.tiles_n), static_cast<unsigned>(h.tiles_m), static_cast<unsigned>(zsplit)),
+                           dim3(NTHREADS), HSMEM_BYTES, st, la);
+        return launch_status();
+    }
+    const float* Gt = reinterpret_cast<const float*>(Gtv);
+    const float* At = reinterpret_cast<const float*>(Atv);
     if (R == 1) {
         // Lambda += scale^2 * (Gt o Gt)^T (At o At): one GEMM over the batch dimension
         kf_view A = make_view(Gt, KF_F32, 0, 1, O, O, b, 0, 0, 1);

@@ -100,6 +100,8 @@ class LambdaTracker(BaseTracker):
                 storage[name] = q.to(device=device, dtype=torch.float32).contiguous()  # once (factor.py:191-201)
         return storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
 
+    _bf16_eigenvectors = None  # (Q_A^T, Q_G^T) in bf16, for lambda_dtype == bf16
+
     def _update_from_factors(self, g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> None:
         module, storage = self.module, self.module.storage
         b, r, o = g.shape
@@ -109,6 +111,17 @@ class LambdaTracker(BaseTracker):
             storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=g.device)
             storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
         storage[NUM_LAMBDA_PROCESSED].add_(b)  # samples, not tokens (factor.py:203)
+        if (module.factor_args.lambda_dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and a.dtype == torch.bfloat16
+                and r > 1 and not append_ones and o % 8 == 0 and ip % 8 == 0):
+            # The reference's bf16 lambda_dtype casts eigenvectors and gradients to bf16 (factor.py:191-201);
+            # here the rotations and the squared product run on the bf16 MFMA engine with fp32 accumulation.
+            if self._bf16_eigenvectors is None:
+                self._bf16_eigenvectors = (q_a.t().contiguous().to(torch.bfloat16), q_g.t().contiguous().to(torch.bfloat16))
+            qa_t, qg_t = self._bf16_eigenvectors
+            gt = ops.rotate_bf16(g.reshape(b * r, o), qg_t)
+            at = ops.rotate_bf16(a.reshape(b * r, ip), qa_t)
+            ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
+            return
         gt = ops.matmul_nn(g.reshape(b * r, o), q_g)
         at = ops.matmul_nn(a.reshape(b * r, a.shape[-1]), q_a, append_ones=append_ones)
         ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
@@ -181,5 +194,6 @@ class LambdaTracker(BaseTracker):
 
     def release_memory(self) -> None:
         self.clear_all_cache()
+        self._bf16_eigenvectors = None
         for name in LAMBDA_FACTOR_NAMES:
             self.module.storage[name] = None

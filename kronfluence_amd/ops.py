@@ -180,6 +180,22 @@ def matmul_nn(x: torch.Tensor, w: torch.Tensor, append_ones: bool = False) -> to
     return out
 
 
+def rotate_bf16(x: torch.Tensor, q_t: torch.Tensor) -> torch.Tensor:
+    """``x @ q`` on the bf16 MFMA engine: ``x: [n, d]`` bf16, ``q_t = q^T`` contiguous bf16 ``[m, d]`` -> bf16 ``[n, m]``
+    (the eigenbasis rotation of tracker/factor.py:218-226 in the reference's bf16 lambda_dtype)."""
+    x, q_t = _contig(x), _contig(q_t)
+    n, d = x.shape
+    m = q_t.shape[0]
+    out = torch.empty((n, m), dtype=torch.bfloat16, device=x.device)
+    nat.require_device(x, "x")
+    nat.check(
+        nat.lib().kf_gemm_out(out.data_ptr(), nat.dtype_code(out.dtype), m, 0, ctypes.byref(view(x, 0, d, 1, n, d)),
+                              ctypes.byref(view(q_t, 0, d, 1, m, d)), 1, 1.0, nat.stream_ptr(x.device)),
+        "kf_gemm_out",
+    )
+    return out
+
+
 def per_sample_gradient(g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> torch.Tensor:
     """``einsum("b...i,b...o->bio", g, [a,1])`` of module/linear.py:72 / conv2d.py:176: ``g: [b,R,O]``, ``a: [b,R,I]``."""
     g, a = _contig(g), _contig(a)
@@ -216,11 +232,12 @@ def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0) -> Tuple[torch.Te
 def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, r: int, scale: float = 1.0) -> None:
     """``lam += sum_b (Gt_b^T At_b)^2`` with rotated factors (kf_lambda_accum; tracker/factor.py:218-226)."""
     nat.require_device(lam, "lam")
-    assert lam.dtype == gt.dtype == at.dtype == torch.float32 and gt.is_contiguous() and at.is_contiguous()
+    assert lam.dtype == torch.float32 and gt.dtype == at.dtype and gt.dtype in (torch.float32, torch.bfloat16)
+    assert gt.is_contiguous() and at.is_contiguous()
     o, ip = lam.shape
     assert gt.numel() == b * r * o and at.numel() == b * r * ip
     nat.check(
-        nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), b, r, o, ip, scale,
+        nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), nat.dtype_code(gt.dtype), b, r, o, ip, scale,
                                   nat.stream_ptr(lam.device)),
         "kf_lambda_accum",
     )

@@ -321,3 +321,21 @@ def test_im2col_vectorised_path(ops, c, dtype):
     got = ops.im2col(x.to(DEV), conv, False, torch.bfloat16)
     assert got.shape == want.shape
     assert torch.equal(got.cpu().float(), want.to(torch.bfloat16).float())
+
+
+@pytest.mark.parametrize("b,r,o,i", [(5, 7, 64, 128), (3, 40, 128, 72), (6, 256, 64, 1152)])
+def test_lambda_accum_bf16_engine(ops, b, r, o, i):
+    """bf16 rotations (Q^T in bf16) + squared TN product on the bf16 engine vs the fp64 oracle fed the
+    same bf16-rounded eigenvectors and inputs.  The rotated factors are rounded to bf16 once (2^-9)."""
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].to(torch.bfloat16)
+    q_a = torch.linalg.qr(_rand(i, i, seed=3).double())[0].to(torch.bfloat16)
+    psg = ref.linear_per_sample_gradient(a.double(), g.double(), False) * 0.5
+    want = torch.zeros(o, i, dtype=torch.float64)
+    ref.lambda_update(want, psg, q_a.double(), q_g.double())
+    gt = ops.rotate_bf16(g.reshape(b * r, o).to(DEV), q_g.t().contiguous().to(DEV))
+    at = ops.rotate_bf16(a.reshape(b * r, i).to(DEV), q_a.t().contiguous().to(DEV))
+    assert gt.dtype == torch.bfloat16 and rel(gt, g.reshape(b * r, o).double() @ q_g.double()) <= 4e-3
+    lam = torch.zeros(o, i, device=DEV)
+    ops.lambda_accum(lam, gt, at, b, r, scale=0.5)
+    assert rel(lam, want) <= 1e-2
