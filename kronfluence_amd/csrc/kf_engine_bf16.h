@@ -190,10 +190,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
     // the 8 m-tiles x 8 n-tiles that re-read the same A / B k-range hit in that XCD's 4 MB L2 instead
     // of each XCD pulling its own copy over the fabric.
     const int tiles = a.symmetric ? a.tiles_m * (a.tiles_m + 1) / 2 : a.tiles_m * a.tiles_n;
+    // work items (chunk-major, tile-minor) are cut into 8 contiguous ranges, one per XCD: whole k-chunks
+    // when there are many, runs of neighbouring tiles (same A rows) when there are few.
+    const int64_t items = static_cast<int64_t>(a.chunks) * tiles, per_xcd = (items + 7) / 8;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int chunk = (j / tiles) * 8 + xcd;
-    if (chunk >= a.chunks) return;
-    const int tile = j % tiles;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int chunk = static_cast<int>(item / tiles);
+    const int tile = static_cast<int>(item % tiles);
     int tile_i = tile / a.tiles_n, tile_j = tile % a.tiles_n;
     if (a.symmetric) {  // tile -> (tile_i <= tile_j) of the upper triangle
         int t = tile;

@@ -183,7 +183,7 @@ int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batc
     h.ksplit = static_cast<int>(ksplit); h.kchunk = static_cast<int>(kchunk); h.alpha = alpha; h.beta = beta; h.atomic = atomic ? 1 : 0;
     h.tiles_m = static_cast<int>(tm); h.tiles_n = static_cast<int>(tn); h.chunks = static_cast<int>(batch * ksplit);
     h.symmetric = symmetric ? 1 : 0;
-    const int64_t nblocks = 8 * cdiv(batch * ksplit, 8) * (symmetric ? tm * (tm + 1) / 2 : tm * tn);
+    const int64_t nblocks = 8 * cdiv(batch * ksplit * (symmetric ? tm * (tm + 1) / 2 : tm * tn), 8);
     if (nblocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
     const dim3 grid(static_cast<unsigned>(nblocks));
     if (mode == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
