@@ -47,6 +47,14 @@ def make_model(kind: str, seed: int = 0) -> nn.Module:
             nn.Conv2d(8, 6, 3, padding=1, groups=2, bias=True), nn.ReLU(),
             nn.Flatten(), nn.Linear(6 * 4 * 4, 3),
         )
+    if kind == "conv8":
+        # channel counts / patch sizes that are multiples of 8: eligible for the bf16 MFMA engines
+        return nn.Sequential(
+            nn.Conv2d(8, 16, 3, padding=1, bias=False), nn.ReLU(),
+            nn.Conv2d(16, 16, 3, stride=2, padding=1, bias=False), nn.ReLU(),
+            nn.Conv2d(16, 8, 3, padding=1, bias=False), nn.ReLU(),
+            nn.Flatten(), nn.Linear(8 * 4 * 4, 8, bias=False),
+        )
     if kind == "seq":
         return _SeqModel()
     raise KeyError(kind)
@@ -58,6 +66,8 @@ def make_data(kind: str, n: int, seed: int) -> Batch:
         return (torch.randn(n, 12, generator=gen), torch.randint(0, 3, (n,), generator=gen))
     if kind == "conv":
         return (torch.randn(n, 3, 8, 8, generator=gen), torch.randint(0, 3, (n,), generator=gen))
+    if kind == "conv8":
+        return (torch.randn(n, 8, 8, 8, generator=gen), torch.randint(0, 8, (n,), generator=gen))
     if kind == "seq":
         t = 6
         ids = torch.randint(0, 20, (n, t), generator=gen)
@@ -135,3 +145,5 @@ FIXTURES: Dict[str, Fixture] = {
     "conv": Fixture("conv", 40, 6, 8, 10, 3),
     "seq": Fixture("seq", 48, 6, 16, 12, 3),
 }
+# bf16-engine fixture: not part of FIXTURES (the generic parametrised tests run fp32); see test_pipeline_gpu.py
+BF16_FIXTURE = Fixture("conv8", 256, 8, 64, 64, 4)

@@ -59,7 +59,7 @@ def make_task(kind: str) -> Task:
 
 
 def run(kind: str, dtype: torch.dtype, out_path: str) -> None:
-    spec = fx.FIXTURES[kind]
+    spec = fx.FIXTURES[kind] if kind in fx.FIXTURES else fx.BF16_FIXTURE
     model = fx.make_model(kind).to(dtype=dtype)
     train = data.TensorDataset(*fx.make_data(kind, spec.n_train, seed=1))
     query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
@@ -103,3 +103,4 @@ if __name__ == "__main__":
     for kind in fx.FIXTURES:
         for tag, dtype in (("fp64", torch.float64), ("fp32", torch.float32)):
             run(kind, dtype, os.path.join(HERE, f"{kind}_{tag}.safetensors"))
+    run("conv8", torch.float32, os.path.join(HERE, "conv8_fp32.safetensors"))

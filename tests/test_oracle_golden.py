@@ -107,3 +107,20 @@ def test_eigh_invariants():
     evals, evecs = ref.eigendecompose(cov, count)
     inv = ref.eigh_invariants(cov, count, evals, evecs)
     assert inv["orthogonality"] < 1e-13 and inv["reconstruction"] < 1e-13 and inv["ascending"] == 0.0
+
+
+def test_oracle_matches_conv8_golden():
+    """The bf16-engine fixture (channels multiples of 8): oracle vs the reference's fp32 run."""
+    gold = load_file(os.path.join(GOLDEN, "conv8_fp32.safetensors"))
+    spec = fx.BF16_FIXTURE
+    engine = ref.OracleEngine(fx.make_model("conv8"))
+    train = fx.make_data("conv8", spec.n_train, seed=1)
+    query = fx.make_data("conv8", spec.n_query, seed=2)
+    cov = engine.fit_covariance(fx.batches(train, spec.factor_batch), fx.train_loss("conv8"))
+    for factor in ("activation_covariance", "gradient_covariance"):
+        for module, want in _nested(gold, "cov")[factor].items():
+            assert _relerr(cov[factor][module], want) <= 2e-5, (factor, module)
+    got = engine.pairwise_scores(fx.batches(query, spec.query_batch), fx.batches(train, spec.train_batch),
+                                 fx.measurement("conv8"), fx.train_loss("conv8"),
+                                 _nested(gold, "eig"), _nested(gold, "lam"), None)
+    assert _relerr(got, gold["scores/dampNone"]) <= 5e-5
