@@ -179,7 +179,8 @@ def main() -> None:
     # hold every preconditioned query gradient resident in HBM (P: n_query x D) -> ONE train pass per step
     accumulate = -(-n_query // (per_dev_q * world))
     sargs = ScoreArguments(amp_dtype=amp, query_gradient_accumulation_steps=accumulate,
-                           score_dtype=torch.bfloat16 if amp == torch.bfloat16 else torch.float32)
+                           score_dtype=torch.bfloat16 if amp == torch.bfloat16 else torch.float32,
+                           precondition_dtype=torch.bfloat16 if amp == torch.bfloat16 else torch.float32)
     layers = tracked_shapes(model)
     D = sum(o * ip for o, ip in layers)
 

@@ -626,7 +626,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 4; }
+int kf_abi_version(void) { return 5; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -820,7 +820,7 @@ int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t
 
 int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O,
                     int64_t I, int append_ones, const float* Qg, const float* Qa, const float* inv_lambda, float scale,
-                    void* workspace, int64_t workspace_bytes, void* stream) {
+                    const void* Qa_bf16, const void* QgT_bf16, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!Pout || !G || !A || !Qg || !Qa || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
     if (!float_dtype(in_dtype) || (out_dtype != KF_F32 && out_dtype != KF_BF16)) return KF_ERR_UNSUPPORTED_DTYPE;
     const int64_t Ip = I + (append_ones ? 1 : 0);
@@ -832,6 +832,10 @@ int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int
     float* T = At + q * R * Ip;
     // fp32 staging of the rotated gradient: the caller's buffer when it is fp32, else workspace
     float* P = out_dtype == KF_F32 ? reinterpret_cast<float*>(Pout) : T + q * O * Ip;
+    // precondition_dtype = bf16 (reference low-precision preset): the two O(q O I' (O + I')) back-rotations run on
+    // the bf16 MFMA engine from bf16 copies of the eigenvectors; the cheap forward rotation stays fp32.
+    const bool low = Qa_bf16 && QgT_bf16 && out_dtype == KF_BF16 && O % 8 == 0 && Ip % 8 == 0 && Ip >= HBK && O >= 8 &&
+                     ((reinterpret_cast<uintptr_t>(Qa_bf16) | reinterpret_cast<uintptr_t>(QgT_bf16)) & 15) == 0;
     int rc;
     // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']
     rc = launch_gemm(Gt, O, 0, make_view(G, in_dtype, 0, O, 1, q * R, O), make_view(Qg, KF_F32, 0, 1, O, O, O), 1, 1.0f, 0.0f, nullptr, 0, st);
@@ -839,6 +843,20 @@ int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int
     // At[(q r), i'] = sum_i [A,1][(q r), i] Qa[i, i']
     rc = launch_gemm(At, Ip, 0, make_view(A, in_dtype, 0, I, 1, q * R, I, 0, append_ones ? 1 : 0), make_view(Qa, KF_F32, 0, 1, Ip, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
     if (rc != KF_OK) return rc;
+    if (low) {
+        uint16_t* rot16 = reinterpret_cast<uint16_t*>(T);            // [q, O, I'] bf16
+        uint16_t* T16 = rot16 + q * O * Ip;                          // [q, O, I'] bf16
+        rc = launch_gemm(rot16, Ip, O * Ip, make_view(Gt, KF_F32, R * O, 1, O, O, R), make_view(At, KF_F32, R * Ip, 1, Ip, Ip, R), q, 1.0f,
+                         0.0f, inv_lambda, Ip, st, KF_BF16);
+        if (rc != KF_OK) return rc;
+        // T16[(q o), j] = sum_i rot16[(q o), i] Qa[j, i]            (NT, both K-contiguous)
+        rc = launch_gemm(T16, Ip, 0, make_view(rot16, KF_BF16, 0, Ip, 1, q * O, Ip), make_view(Qa_bf16, KF_BF16, 0, Ip, 1, Ip, Ip), 1, 1.0f,
+                         0.0f, nullptr, 0, st, KF_BF16);
+        if (rc != KF_OK) return rc;
+        // P[q][m, n] = scale * sum_o QgT[o, m] T16[q][o, n]         (TN, both K-strided, batched over q)
+        return launch_gemm(Pout, Ip, O * Ip, make_view(QgT_bf16, KF_BF16, 0, 1, O, O, O), make_view(T16, KF_BF16, O * Ip, 1, Ip, Ip, O), q,
+                           scale, 0.0f, nullptr, 0, st, KF_BF16);
+    }
     // rot[q][o,i] = (sum_r Gt[q,r,o] At[q,r,i]) * inv_lambda[o,i]   (stored in the caller's P buffer)
     rc = launch_gemm(P, Ip, O * Ip, make_view(Gt, KF_F32, R * O, 1, O, O, R), make_view(At, KF_F32, R * Ip, 1, Ip, Ip, R), q, 1.0f, 0.0f, inv_lambda, Ip, st);
     if (rc != KF_OK) return rc;

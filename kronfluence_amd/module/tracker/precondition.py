@@ -32,6 +32,21 @@ class PreconditionTracker(BaseTracker):
         score contraction; everything else is held in fp32."""
         return torch.bfloat16 if self.module.score_args.score_dtype == torch.bfloat16 else torch.float32
 
+    _bf16_q = None
+
+    def _bf16_eigenvectors(self):
+        """bf16 copies ``(Q_A, Q_G^T)`` for ``precondition_dtype == bf16`` (the reference casts the eigenvectors to
+        that dtype in ``Ekfac.prepare``, factor/config.py:323-328); ``(None, None)`` otherwise."""
+        args = self.module.score_args
+        if args.precondition_dtype != torch.bfloat16 or args.score_dtype != torch.bfloat16:
+            return None, None
+        storage = self.module.storage
+        source = storage[ACTIVATION_EIGENVECTORS_NAME]
+        if self._bf16_q is None or self._bf16_q[0] is not source:
+            self._bf16_q = (source, source.to(torch.bfloat16).contiguous(),
+                            storage[GRADIENT_EIGENVECTORS_NAME].t().contiguous().to(torch.bfloat16))
+        return self._bf16_q[1], self._bf16_q[2]
+
     def _store(self, preconditioned: torch.Tensor) -> None:
         if preconditioned.dtype != self._out_dtype():
             preconditioned = preconditioned.to(self._out_dtype())
@@ -54,9 +69,11 @@ class PreconditionTracker(BaseTracker):
             self.cached_hooks.pop().remove()
             if module.per_sample_gradient_process_fnc is None and module.factor_args.strategy == "ekfac":
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
+                qa16, qgt16 = self._bf16_eigenvectors()
                 self._store(ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
                                              storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
-                                             scale=module.gradient_scale, out_dtype=self._out_dtype()))
+                                             scale=module.gradient_scale, out_dtype=self._out_dtype(),
+                                             q_a_bf16=qa16, q_g_t_bf16=qgt16))
             else:
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
                 out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(psg, storage)
@@ -121,6 +138,7 @@ class PreconditionTracker(BaseTracker):
         storage[PRECONDITIONED_GRADIENT_NAME] = None
 
     def release_memory(self) -> None:
+        self._bf16_q = None
         self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.clear_all_cache()

@@ -339,3 +339,17 @@ def test_lambda_accum_bf16_engine(ops, b, r, o, i):
     lam = torch.zeros(o, i, device=DEV)
     ops.lambda_accum(lam, gt, at, b, r, scale=0.5)
     assert rel(lam, want) <= 1e-2
+
+
+@pytest.mark.parametrize("q,r,o,i", [(4, 6, 64, 128), (3, 50, 128, 72), (5, 1, 16, 64)])
+def test_precondition_bf16_back_rotation(ops, q, r, o, i):
+    """precondition_dtype = bf16: back-rotations on the bf16 engine with bf16 eigenvector copies."""
+    g, a = _rand(q, r, o), _rand(q, r, i, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].contiguous()
+    q_a = torch.linalg.qr(_rand(i, i, seed=3).double())[0].contiguous()
+    lam_inv = _rand(o, i, seed=4).abs().double() + 0.1
+    want = ref.ekfac_precondition(ref.linear_per_sample_gradient(a.double(), g.double(), False), q_a, q_g, lam_inv)
+    qa_d, qg_d = q_a.float().to(DEV), q_g.float().to(DEV)
+    got = ops.precondition(g.to(DEV), a.to(DEV), False, qg_d, qa_d, lam_inv.float().to(DEV), out_dtype=torch.bfloat16,
+                           q_a_bf16=qa_d.to(torch.bfloat16).contiguous(), q_g_t_bf16=qg_d.t().contiguous().to(torch.bfloat16))
+    assert got.dtype == torch.bfloat16 and rel(got, want) <= 1.5e-2
