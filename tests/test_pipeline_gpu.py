@@ -196,6 +196,32 @@ def test_conv8_bf16_engines_stage_isolated_and_end_to_end(tmp_path):
         assert rel(lam["lambda_matrix"][module], want) <= 5e-2, (module, rel(lam["lambda_matrix"][module], want))
     s2 = analyzer.compute_pairwise_scores("s2", "low", query, train, **kw,
                                           score_args=ScoreArguments(damping_factor=None, amp_dtype=torch.bfloat16,
-                                                                    score_dtype=torch.bfloat16))["all_modules"]
+                                                                    score_dtype=torch.bfloat16,
+                                                                    precondition_dtype=torch.bfloat16))["all_modules"]
     corr = _pearson(s2, gold["scores/dampNone"])
     assert corr >= 0.99, (corr, rel(s2, gold["scores/dampNone"]))
+
+
+def test_fp16_amp_gradient_scale_plumbing(tmp_path):
+    """fp16 autocast with a fixed loss scale (FactorArguments.amp_scale): the hooks must un-scale exactly
+    (alpha = scale^2 in the gradient covariance, x scale in Lambda / preconditioning / scores; reference
+    factor.py:90-92, :269-270, precondition.py:117-118, pairwise_score.py:91-92).  fp16 rounding of the model's
+    forward/backward bounds the agreement with the fp32 reference run."""
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    gold = load_file(os.path.join(GOLDEN, "mlp_fp32.safetensors"))
+    spec, analyzer, train, query = build("mlp", tmp_path)
+    # (summed losses scaled by the default 2^16 overflow fp16 in any implementation: |dL/dlogit| reaches 1)
+    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.float16, amp_scale=2.0**10)
+    analyzer.fit_all_factors("f16", train, per_device_batch_size=spec.factor_batch, factor_args=fargs)
+    cov = analyzer.load_covariance_matrices("f16")
+    for module, want in nested(gold, "cov")["gradient_covariance"].items():
+        assert rel(cov["gradient_covariance"][module], want) <= 1e-2, (module, rel(cov["gradient_covariance"][module], want))
+    lam = analyzer.load_lambda_matrices("f16")
+    for module, want in nested(gold, "lam")["lambda_matrix"].items():
+        assert rel(lam["lambda_matrix"][module], want) <= 3e-2, (module, rel(lam["lambda_matrix"][module], want))
+    scores = analyzer.compute_pairwise_scores("s16", "f16", query, train, per_device_query_batch_size=spec.query_batch,
+                                              per_device_train_batch_size=spec.train_batch,
+                                              score_args=ScoreArguments(damping_factor=None, amp_dtype=torch.float16))["all_modules"]
+    assert _pearson(scores, gold["scores/dampNone"]) >= 0.995
+    assert rel(scores, gold["scores/dampNone"]) <= 0.1
