@@ -34,8 +34,28 @@ class _SeqModel(nn.Module):
         return self.head(h)
 
 
+class _SharedMLP(nn.Module):
+    """One Linear applied three times per forward: exercises ``has_shared_parameters`` (per-sample gradients of
+    the three uses are summed before Lambda / preconditioning / scoring)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.first = nn.Linear(12, 16)
+        self.shared = nn.Linear(16, 16)
+        self.last = nn.Linear(16, 3, bias=False)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        h = torch.relu(self.first(x))
+        h = torch.relu(self.shared(h))
+        h = torch.tanh(self.shared(h))
+        h = torch.relu(self.shared(h))
+        return self.last(h)
+
+
 def make_model(kind: str, seed: int = 0) -> nn.Module:
     torch.manual_seed(seed)
+    if kind == "shared":
+        return _SharedMLP()
     if kind == "mlp":
         return nn.Sequential(
             nn.Linear(12, 16), nn.ReLU(), nn.Linear(16, 16, bias=False), nn.ReLU(), nn.Linear(16, 3)
@@ -62,7 +82,7 @@ def make_model(kind: str, seed: int = 0) -> nn.Module:
 
 def make_data(kind: str, n: int, seed: int) -> Batch:
     gen = torch.Generator().manual_seed(seed)
-    if kind == "mlp":
+    if kind in ("mlp", "shared"):
         return (torch.randn(n, 12, generator=gen), torch.randint(0, 3, (n,), generator=gen))
     if kind == "conv":
         return (torch.randn(n, 3, 8, 8, generator=gen), torch.randint(0, 3, (n,), generator=gen))
@@ -147,3 +167,5 @@ FIXTURES: Dict[str, Fixture] = {
 }
 # bf16-engine fixture: not part of FIXTURES (the generic parametrised tests run fp32); see test_pipeline_gpu.py
 BF16_FIXTURE = Fixture("conv8", 256, 8, 64, 64, 4)
+# shared-parameter fixture (FactorArguments.has_shared_parameters=True)
+SHARED_FIXTURE = Fixture("shared", 48, 6, 16, 12, 3)

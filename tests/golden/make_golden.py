@@ -59,7 +59,7 @@ def make_task(kind: str) -> Task:
 
 
 def run(kind: str, dtype: torch.dtype, out_path: str) -> None:
-    spec = fx.FIXTURES[kind] if kind in fx.FIXTURES else fx.BF16_FIXTURE
+    spec = fx.FIXTURES.get(kind) or {"conv8": fx.BF16_FIXTURE, "shared": fx.SHARED_FIXTURE}[kind]
     model = fx.make_model(kind).to(dtype=dtype)
     train = data.TensorDataset(*fx.make_data(kind, spec.n_train, seed=1))
     query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
@@ -68,7 +68,7 @@ def run(kind: str, dtype: torch.dtype, out_path: str) -> None:
     with tempfile.TemporaryDirectory() as tmp:
         analyzer = Analyzer("golden", model, task, cpu=True, disable_tqdm=True, output_dir=tmp)
         fargs = FactorArguments(
-            use_empirical_fisher=True,
+            use_empirical_fisher=True, has_shared_parameters=(kind == "shared"),
             activation_covariance_dtype=dtype, gradient_covariance_dtype=dtype,
             per_sample_gradient_dtype=dtype, lambda_dtype=dtype,
         )
@@ -104,3 +104,4 @@ if __name__ == "__main__":
         for tag, dtype in (("fp64", torch.float64), ("fp32", torch.float32)):
             run(kind, dtype, os.path.join(HERE, f"{kind}_{tag}.safetensors"))
     run("conv8", torch.float32, os.path.join(HERE, "conv8_fp32.safetensors"))
+    run("shared", torch.float64, os.path.join(HERE, "shared_fp64.safetensors"))
