@@ -96,6 +96,8 @@ class TrackedModule(nn.Module):
         self.einsum_path: Optional[List[int]] = None  # kept for attribute compatibility; unused
         # (scores buffer [Q, N], column offset) shared by all layers during the train pass
         self.score_sink: Optional[Tuple[torch.Tensor, int]] = None
+        # True while storage["preconditioned_gradient"] holds eigenbasis-resident queries (PreconditionTracker)
+        self.queries_in_eigenbasis: bool = False
         self.storage: Dict[str, Any] = {}
         for key in (COVARIANCE_FACTOR_NAMES + EIGENDECOMPOSITION_FACTOR_NAMES + LAMBDA_FACTOR_NAMES
                     + [AGGREGATED_GRADIENT_NAME, PRECONDITIONED_GRADIENT_NAME,

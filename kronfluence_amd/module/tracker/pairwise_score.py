@@ -19,6 +19,8 @@ from kronfluence_amd import ops
 from kronfluence_amd.module.tracker.base import BaseTracker
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
+    ACTIVATION_EIGENVECTORS_NAME,
+    GRADIENT_EIGENVECTORS_NAME,
     PAIRWISE_SCORE_MATRIX_NAME,
     PRECONDITIONED_GRADIENT_NAME,
 )
@@ -68,6 +70,11 @@ class PairwiseScoreTracker(BaseTracker):
                 storage[PAIRWISE_SCORE_MATRIX_NAME] = scores
             if module.per_sample_gradient_process_fnc is None:
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
+                if module.queries_in_eigenbasis:  # see PreconditionTracker.EIGENBASIS_QUERIES
+                    n = g.shape[0]
+                    g = ops.matmul_nn(g.reshape(n, -1), storage[GRADIENT_EIGENVECTORS_NAME]).unsqueeze(1)
+                    a = ops.matmul_nn(a.reshape(n, -1), storage[ACTIVATION_EIGENVECTORS_NAME], append_ones=ones).unsqueeze(1)
+                    ones = False
                 ops.pairwise_score(scores, offset, preconditioned, g, a, ones, scale=module.gradient_scale,
                                    p_tiled=self._tiled_queries(preconditioned, g, a, ones))
             else:
