@@ -249,6 +249,10 @@ def main() -> None:
 
     for _ in range(args.warmup):
         step()
+    import gc
+
+    gc.collect()
+    gc.disable()  # no cyclic-GC pause between steps either (the stage loops already pause it inside a stage)
     ops.SCORE_EVENT_LOG = []
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)
     barrier()
@@ -262,6 +266,7 @@ def main() -> None:
     barrier()
     elapsed = time.perf_counter() - t0
     new_segments = torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0
+    gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
