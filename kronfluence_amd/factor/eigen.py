@@ -3,6 +3,8 @@
 
 from __future__ import annotations
 
+import threading
+from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
 
@@ -29,6 +31,9 @@ from kronfluence_amd.utils.constants import (
 )
 from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
 from kronfluence_amd.utils.state import State, no_sync, paused_gc
+
+
+EIGH_STREAMS = 4  # concurrent eigenproblems (HIP streams / host threads) per rank
 
 
 def eigendecomposition_save_path(output_dir: Path, factor_name: str) -> Path:
@@ -95,16 +100,52 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
         ):
             jobs.append((module_name, cov_name, count_name, vec_name, val_name))
     world = state.num_processes if (state.use_distributed and dist.is_initialized()) else 1
+    mine = [job for index, job in enumerate(jobs) if world == 1 or index % world == state.process_index]
+
+    def solve(job, stream):
+        module_name, cov_name, count_name, _vec, _val = job
+        with torch.cuda.stream(stream):
+            work = covariance_factors[cov_name][module_name].to(device=state.device)
+            if work.dtype not in (torch.float32, torch.float64):
+                work = work.to(torch.float32)
+            evals, evecs, _ = ops.eigh(work, float(covariance_factors[count_name][module_name].item()))
+        return evals, evecs
+
+    # The eigenproblems are independent and one Jacobi round kernel is latency / L2 bound far below the chip's
+    # capacity, so several are kept in flight on separate HIP streams, each driven by its own host thread (the C
+    # call releases the GIL and synchronises only its own stream, once per sweep).  Largest first.
+    results = {}
+    order = sorted(mine, key=lambda job: -covariance_factors[job[1]][job[0]].shape[0])
+    lanes = max(1, min(EIGH_STREAMS, len(order)))
+    if lanes == 1:
+        for job in order:
+            results[job[:2]] = solve(job, torch.cuda.current_stream(state.device))
+    else:
+        torch.cuda.synchronize(state.device)
+        streams = [torch.cuda.Stream(device=state.device) for _ in range(lanes)]
+        queue, lock = list(order), threading.Lock()
+
+        def worker(stream):
+            torch.cuda.set_device(state.device)
+            while True:
+                with lock:
+                    if not queue:
+                        return
+                    job = queue.pop(0)
+                results[job[:2]] = solve(job, stream)
+
+        with ThreadPoolExecutor(max_workers=lanes) as pool:
+            for future in [pool.submit(worker, stream) for stream in streams]:
+                future.result()
+        torch.cuda.synchronize(state.device)
+
     for index, (module_name, cov_name, count_name, vec_name, val_name) in enumerate(jobs):
         cov = covariance_factors[cov_name][module_name]
         original_dtype = cov.dtype
         owner = index % world
         d = cov.shape[0]
-        if owner == state.process_index or world == 1:
-            work = cov.to(device=state.device)
-            if work.dtype not in (torch.float32, torch.float64):
-                work = work.to(torch.float32)
-            evals, evecs, _ = ops.eigh(work, float(covariance_factors[count_name][module_name].item()))
+        if (module_name, cov_name) in results:
+            evals, evecs = results[(module_name, cov_name)]
         else:
             evals = torch.empty(d, dtype=torch.float64, device=state.device)
             evecs = torch.empty((d, d), dtype=torch.float64, device=state.device)
