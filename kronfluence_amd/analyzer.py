@@ -56,10 +56,7 @@ class Analyzer:
                  disable_tqdm: bool = False, output_dir: str = "./influence_results",
                  disable_model_save: bool = True) -> None:
         del log_main_process_only, disable_model_save
-        if cpu:
-            raise RuntimeError("`cpu=True` is not available: the MI355X-native engine has no CPU path.")
-        if not torch.cuda.is_available():
-            raise RuntimeError("No MI355X visible (torch.cuda.is_available() is False); there is no CPU fallback.")
+        self._require_gpu(cpu)
         self.name, self.task, self.disable_tqdm, self.profile = analysis_name, task, disable_tqdm, profile
         self.state = State(cpu=False)
         self.logger = logging.getLogger(f"kronfluence_amd.{analysis_name}")
@@ -78,6 +75,13 @@ class Analyzer:
         self.state.wait_for_everyone()
 
     # -- helpers -----------------------------------------------------------------------------------
+    @staticmethod
+    def _require_gpu(cpu: bool) -> None:
+        if cpu:
+            raise RuntimeError("`cpu=True` is not available: the MI355X-native engine has no CPU path.")
+        if not torch.cuda.is_available():
+            raise RuntimeError("No MI355X visible (torch.cuda.is_available() is False); there is no CPU fallback.")
+
     def set_dataloader_kwargs(self, dataloader_kwargs: DataLoaderKwargs) -> None:
         self._dataloader_params = dataloader_kwargs
 
@@ -87,16 +91,20 @@ class Analyzer:
     def scores_output_dir(self, scores_name: str) -> Path:
         return (self.output_dir / (SCORE_SAVE_PREFIX + scores_name)).resolve()
 
+    def _device_sync(self) -> None:
+        if self.state.device.type == "cuda":
+            torch.cuda.synchronize(self.state.device)
+
     def _timed(self, label: str):
         analyzer = self
 
         class _Timer:
             def __enter__(self):
-                torch.cuda.synchronize()
+                analyzer._device_sync()
                 self.t0 = time.perf_counter()
 
             def __exit__(self, *exc):
-                torch.cuda.synchronize()
+                analyzer._device_sync()
                 analyzer.timings[label] = analyzer.timings.get(label, 0.0) + time.perf_counter() - self.t0
 
         return _Timer()

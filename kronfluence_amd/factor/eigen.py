@@ -3,6 +3,7 @@
 
 from __future__ import annotations
 
+import contextlib
 import threading
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -104,7 +105,7 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
 
     def solve(job, stream):
         module_name, cov_name, count_name, _vec, _val = job
-        with torch.cuda.stream(stream):
+        with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             work = covariance_factors[cov_name][module_name].to(device=state.device)
             if work.dtype not in (torch.float32, torch.float64):
                 work = work.to(torch.float32)
@@ -116,10 +117,10 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
     # call releases the GIL and synchronises only its own stream, once per sweep).  Largest first.
     results = {}
     order = sorted(mine, key=lambda job: -covariance_factors[job[1]][job[0]].shape[0])
-    lanes = max(1, min(EIGH_STREAMS, len(order)))
+    lanes = max(1, min(EIGH_STREAMS, len(order))) if state.device.type == "cuda" else 1
     if lanes == 1:
         for job in order:
-            results[job[:2]] = solve(job, torch.cuda.current_stream(state.device))
+            results[job[:2]] = solve(job, None)
     else:
         torch.cuda.synchronize(state.device)
         streams = [torch.cuda.Stream(device=state.device) for _ in range(lanes)]

@@ -26,3 +26,15 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture
+def cpu_engine(monkeypatch):
+    """Host-logic tests: swap the HIP leaf operators for the torch-CPU stand-ins of tests/cpu_engine.py."""
+    import cpu_engine as engine
+    from kronfluence_amd.utils.state import State
+
+    State._reset_state()
+    engine.install(monkeypatch)
+    yield engine
+    State._reset_state()
