@@ -12,7 +12,8 @@ import logging
 import os
 import time
 from pathlib import Path
-from typing import Dict, List, Optional, Sequence
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple, Union
 
 import torch
 from torch import nn
@@ -29,13 +30,15 @@ from kronfluence_amd.factor.eigen import (
     load_lambda_matrices, perform_eigendecomposition, save_eigendecomposition, save_lambda_matrices,
 )
 from kronfluence_amd.module.tracked_module import TrackedModule
-from kronfluence_amd.module.utils import get_tracked_module_names, wrap_tracked_modules
+from kronfluence_amd.module.utils import get_tracked_module_names, make_modules_partition, wrap_tracked_modules
 from kronfluence_amd.score.pairwise import (
     compute_pairwise_scores_with_loaders, load_pairwise_scores, pairwise_scores_exist, save_pairwise_scores,
 )
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import FACTOR_SAVE_PREFIX, FACTOR_TYPE, SCORE_SAVE_PREFIX, SCORE_TYPE
-from kronfluence_amd.utils.dataset import DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack
+from kronfluence_amd.utils.dataset import (
+    DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack, make_indices_partition,
+)
 from kronfluence_amd.utils.exceptions import FactorsNotFoundError, TrackedModuleNotFoundError
 from kronfluence_amd.utils.save import load_json, save_json
 from kronfluence_amd.utils.state import State
@@ -48,6 +51,20 @@ def prepare_model(model: nn.Module, task: Task) -> nn.Module:
     for tensor in list(model.parameters()) + list(model.buffers()):
         tensor.requires_grad = False
     return wrap_tracked_modules(model=model, task=task)
+
+
+@dataclass
+class _PartitionPlan:
+    partitioned: bool
+    ranges: List[Tuple[int, int]]
+    modules: List[List[str]]
+    data_targets: List[int]
+    module_targets: List[int]
+
+    def cells(self):
+        for d in self.data_targets:
+            for m in self.module_targets:
+                yield (d, m) if self.partitioned else None, self.ranges[d], self.modules[m]
 
 
 class Analyzer:
@@ -133,11 +150,108 @@ class Analyzer:
             raise ValueError(f"`{what}` must be given explicitly (automatic batch-size search is not part of this build).")
         return value
 
-    @staticmethod
-    def _single_partition(*partitions: int) -> None:
-        if any(p != 1 for p in partitions):
-            raise NotImplementedError("Data/module partitioning is a memory work-around for 80 GB GPUs and is not "
-                                      "part of the MI355X hot path (SURVEY.md section 2.1 row 2).")
+    def _partition_plan(self, total_examples: int, data_partitions: int, module_partitions: int,
+                        target_data_partitions, target_module_partitions) -> "_PartitionPlan":
+        """Index ranges / module-name lists of every partition and the ones this call computes
+        (reference ``computer/computer.py:249-316``; same error rules)."""
+        partitioned = not (data_partitions == 1 and module_partitions == 1)
+        if not partitioned and (target_data_partitions is not None or target_module_partitions is not None):
+            raise ValueError("`target_data_partitions` or `target_module_partitions` were specified, while the "
+                             "arguments did not expect any data and module partition.")
+        if total_examples < data_partitions:
+            raise ValueError(f"Data partition size ({data_partitions}) exceeds total data points ({total_examples}). "
+                             "Please reduce the data partition size.")
+        names = get_tracked_module_names(self.model)
+        if len(names) < module_partitions:
+            raise ValueError(f"Module partition size ({module_partitions}) exceeds total tracked modules "
+                             f"({len(names)}). Please reduce the module partition size.")
+        if total_examples // data_partitions < self.state.num_processes:
+            raise ValueError("The number of processes are larger than the data points per partition. "
+                             "Try reducing the number of processes or the data partitions.")
+
+        def targets(wanted, count: int, what: str) -> List[int]:
+            if wanted is None:
+                return list(range(count))
+            wanted = [wanted] if isinstance(wanted, int) else list(wanted)
+            for index in wanted:
+                if index < 0 or index >= count:
+                    raise ValueError(f"Invalid {what} partition {index}. Must be in range [0, {count}).")
+            return wanted
+
+        return _PartitionPlan(
+            partitioned=partitioned,
+            ranges=make_indices_partition(total_data_examples=total_examples, partition_size=data_partitions),
+            modules=make_modules_partition(total_module_names=names, partition_size=module_partitions),
+            data_targets=targets(target_data_partitions, data_partitions, "data"),
+            module_targets=targets(target_module_partitions, module_partitions, "module"),
+        )
+
+    def _stored_factor_args(self, factors_name: str) -> FactorArguments:
+        stored = self.load_factor_args(factors_name)
+        if stored is None:
+            raise FactorsNotFoundError(f"Factors with name `{factors_name}` not found at `{self.factors_output_dir(factors_name)}`.")
+        return FactorArguments(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
+                                  for k, v in stored.items()})
+
+    def _stored_score_args(self, scores_name: str) -> ScoreArguments:
+        path = self.scores_output_dir(scores_name) / "score_arguments.json"
+        if not path.exists():
+            raise ValueError(f"Arguments for scores with name `{scores_name}` were not found.")
+        return ScoreArguments(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
+                                 for k, v in load_json(path).items()})
+
+    @torch.no_grad()
+    def _aggregate_factors(self, factors_name: str, data_partitions: int, module_partitions: int, exist_fnc, load_fnc,
+                           save_fnc) -> Optional[FACTOR_TYPE]:
+        """Sum over data partitions, union over module partitions (reference ``factor_computer.py:57-108``);
+        nothing happens until every partition file exists."""
+        out = self.factors_output_dir(factors_name)
+        if not out.exists():
+            raise FileNotFoundError(f"Factors directory `{out}` not found when trying to aggregate factors.")
+        grid = [(i, j) for i in range(data_partitions) for j in range(module_partitions)]
+        if not all(exist_fnc(out, partition=cell) for cell in grid):
+            return None
+        total: FACTOR_TYPE = {}
+        for cell in grid:
+            for factor_name, per_module in load_fnc(out, partition=cell).items():
+                held = total.setdefault(factor_name, {})
+                for module_name, tensor in per_module.items():
+                    if module_name in held:
+                        held[module_name].add_(tensor)
+                    else:
+                        held[module_name] = tensor.clone()
+        save_fnc(out, total)
+        return total
+
+    @torch.no_grad()
+    def _aggregate_scores(self, scores_name: str, exist_fnc, load_fnc, save_fnc, dim: int) -> Optional[SCORE_TYPE]:
+        """Module partitions add, data partitions concatenate along the train axis -- or add, when the train
+        gradients were aggregated (reference ``score_computer.py:77-139``)."""
+        out = self.scores_output_dir(scores_name)
+        if not out.exists():
+            raise FileNotFoundError(f"Scores directory `{out}` not found when trying to aggregate scores.")
+        score_args = self._stored_score_args(scores_name)
+        grid = [(i, j) for i in range(score_args.data_partitions) for j in range(score_args.module_partitions)]
+        if not all(exist_fnc(out, partition=cell) for cell in grid):
+            return None
+        total: SCORE_TYPE = {}
+        for i in range(score_args.data_partitions):
+            block: SCORE_TYPE = {}
+            for j in range(score_args.module_partitions):
+                for key, tensor in load_fnc(out, partition=(i, j)).items():
+                    if key in block:
+                        block[key].add_(tensor)
+                    else:
+                        block[key] = tensor.clone()
+            for key, tensor in block.items():
+                if key not in total:
+                    total[key] = tensor
+                elif score_args.aggregate_train_gradients:
+                    total[key].add_(tensor)
+                else:
+                    total[key] = torch.cat((total[key], tensor), dim=dim)
+        save_fnc(out, total, metadata=score_args.to_str_dict())
+        return total
 
     def _save_arguments(self, path: Path, arguments, overwrite: bool) -> None:
         if self.state.is_main_process:
@@ -158,9 +272,8 @@ class Analyzer:
                                 target_data_partitions: Optional[Sequence[int]] = None,
                                 target_module_partitions: Optional[Sequence[int]] = None,
                                 overwrite_output_dir: bool = False) -> None:
-        del initial_per_device_batch_size_attempt, target_data_partitions, target_module_partitions
+        del initial_per_device_batch_size_attempt
         factor_args = factor_args or FactorArguments()
-        self._single_partition(factor_args.covariance_data_partitions, factor_args.covariance_module_partitions)
         out = self.factors_output_dir(factors_name)
         if self.state.is_main_process:
             os.makedirs(out, exist_ok=True)
@@ -172,13 +285,29 @@ class Analyzer:
             return
         batch_size = self._require_batch_size(per_device_batch_size, "per_device_batch_size")
         total = len(dataset) if factor_args.covariance_max_examples is None else min(factor_args.covariance_max_examples, len(dataset))
-        loader = self._get_dataloader(dataset, batch_size, (dataloader_kwargs or self._dataloader_params).to_dict(),
-                                      indices=list(range(total)), allow_duplicates=False)
-        with self._timed("fit_covariance"):
-            _, factors = fit_covariance_matrices_with_loader(self.model, self.state, self.task, loader, factor_args)
-        if self.state.is_main_process:
-            save_covariance_matrices(out, factors, metadata=factor_args.to_str_dict())
-        self.state.wait_for_everyone()
+        plan = self._partition_plan(total, factor_args.covariance_data_partitions, factor_args.covariance_module_partitions,
+                                    target_data_partitions, target_module_partitions)
+        params = (dataloader_kwargs or self._dataloader_params).to_dict()
+        for partition, (start, end), module_names in plan.cells():
+            if covariance_matrices_exist(out, partition) and not overwrite_output_dir:
+                continue
+            loader = self._get_dataloader(dataset, batch_size, params, indices=list(range(start, end)), allow_duplicates=False)
+            with self._timed("fit_covariance"):
+                _, factors = fit_covariance_matrices_with_loader(self.model, self.state, self.task, loader, factor_args,
+                                                                 tracked_module_names=module_names)
+            if self.state.is_main_process:
+                save_covariance_matrices(out, factors, partition=partition, metadata=factor_args.to_str_dict())
+            self.state.wait_for_everyone()
+        if plan.partitioned:
+            if self.state.is_main_process:
+                self.aggregate_covariance_matrices(factors_name)
+            self.state.wait_for_everyone()
+
+    def aggregate_covariance_matrices(self, factors_name: str) -> None:
+        """Aggregates the partitioned covariance files once all of them exist (reference ``factor_computer.py:350-378``)."""
+        factor_args = self._stored_factor_args(factors_name)
+        self._aggregate_factors(factors_name, factor_args.covariance_data_partitions, factor_args.covariance_module_partitions,
+                                covariance_matrices_exist, load_covariance_matrices, save_covariance_matrices)
 
     def perform_eigendecomposition(self, factors_name: str, factor_args: Optional[FactorArguments] = None,
                                    overwrite_output_dir: bool = False,
@@ -190,6 +319,7 @@ class Analyzer:
         self.state.wait_for_everyone()
         if eigendecomposition_exist(out) and not overwrite_output_dir:
             return
+        self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)
         if not FactorConfig.CONFIGS[factor_args.strategy].requires_eigendecomposition:
             return
         source = self.factors_output_dir(load_from_factors_name) if load_from_factors_name else out
@@ -211,15 +341,15 @@ class Analyzer:
                             target_module_partitions: Optional[Sequence[int]] = None,
                             overwrite_output_dir: bool = False,
                             load_from_factors_name: Optional[str] = None) -> None:
-        del initial_per_device_batch_size_attempt, target_data_partitions, target_module_partitions
+        del initial_per_device_batch_size_attempt
         factor_args = factor_args or FactorArguments()
-        self._single_partition(factor_args.lambda_data_partitions, factor_args.lambda_module_partitions)
         out = self.factors_output_dir(factors_name)
         if self.state.is_main_process:
             os.makedirs(out, exist_ok=True)
         self.state.wait_for_everyone()
         if lambda_matrices_exist(out) and not overwrite_output_dir:
             return
+        self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)
         config = FactorConfig.CONFIGS[factor_args.strategy]
         if not config.requires_lambda_matrices:
             return
@@ -232,13 +362,29 @@ class Analyzer:
             eigen = load_eigendecomposition(source)
         batch_size = self._require_batch_size(per_device_batch_size, "per_device_batch_size")
         total = len(dataset) if factor_args.lambda_max_examples is None else min(factor_args.lambda_max_examples, len(dataset))
-        loader = self._get_dataloader(dataset, batch_size, (dataloader_kwargs or self._dataloader_params).to_dict(),
-                                      indices=list(range(total)), allow_duplicates=False)
-        with self._timed("fit_lambda"):
-            _, factors = fit_lambda_matrices_with_loader(self.model, self.state, self.task, loader, factor_args, eigen)
-        if self.state.is_main_process:
-            save_lambda_matrices(out, factors, metadata=factor_args.to_str_dict())
-        self.state.wait_for_everyone()
+        plan = self._partition_plan(total, factor_args.lambda_data_partitions, factor_args.lambda_module_partitions,
+                                    target_data_partitions, target_module_partitions)
+        params = (dataloader_kwargs or self._dataloader_params).to_dict()
+        for partition, (start, end), module_names in plan.cells():
+            if lambda_matrices_exist(out, partition) and not overwrite_output_dir:
+                continue
+            loader = self._get_dataloader(dataset, batch_size, params, indices=list(range(start, end)), allow_duplicates=False)
+            with self._timed("fit_lambda"):
+                _, factors = fit_lambda_matrices_with_loader(self.model, self.state, self.task, loader, factor_args, eigen,
+                                                             tracked_module_names=module_names)
+            if self.state.is_main_process:
+                save_lambda_matrices(out, factors, partition=partition, metadata=factor_args.to_str_dict())
+            self.state.wait_for_everyone()
+        if plan.partitioned:
+            if self.state.is_main_process:
+                self.aggregate_lambda_matrices(factors_name)
+            self.state.wait_for_everyone()
+
+    def aggregate_lambda_matrices(self, factors_name: str) -> None:
+        """Aggregates the partitioned Lambda files once all of them exist (reference ``factor_computer.py:704-732``)."""
+        factor_args = self._stored_factor_args(factors_name)
+        self._aggregate_factors(factors_name, factor_args.lambda_data_partitions, factor_args.lambda_module_partitions,
+                                lambda_matrices_exist, load_lambda_matrices, save_lambda_matrices)
 
     def fit_all_factors(self, factors_name: str, dataset: data.Dataset, per_device_batch_size: Optional[int] = None,
                         initial_per_device_batch_size_attempt: int = 4096,
@@ -296,39 +442,54 @@ class Analyzer:
                                 target_data_partitions: Optional[Sequence[int]] = None,
                                 target_module_partitions: Optional[Sequence[int]] = None,
                                 overwrite_output_dir: bool = False) -> Optional[SCORE_TYPE]:
-        del initial_per_device_train_batch_size_attempt, target_data_partitions, target_module_partitions
+        del initial_per_device_train_batch_size_attempt
         score_args = score_args or ScoreArguments()
-        self._single_partition(score_args.data_partitions, score_args.module_partitions)
         out = self.scores_output_dir(scores_name)
         if self.state.is_main_process:
             os.makedirs(out, exist_ok=True)
         self.state.wait_for_everyone()
         if pairwise_scores_exist(out) and not overwrite_output_dir:
             return self.load_pairwise_scores(scores_name)
-        stored = self.load_factor_args(factors_name)
-        if stored is None:
-            raise FactorsNotFoundError(f"Factors with name `{factors_name}` not found at `{self.factors_output_dir(factors_name)}`.")
-        factor_args = FactorArguments(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
-                                         for k, v in stored.items()})
+        factor_args = self._stored_factor_args(factors_name)
         self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
         loaded = self.load_all_factors(factors_name)
-        if not loaded:
+        if not loaded and FactorConfig.CONFIGS[factor_args.strategy].requires_lambda_matrices_for_precondition:
             raise FactorsNotFoundError(f"Factors with name `{factors_name}` are incomplete.")
         params = (dataloader_kwargs or self._dataloader_params).to_dict()
         train_batch = self._require_batch_size(per_device_train_batch_size, "per_device_train_batch_size")
-        query_loader = self._get_dataloader(query_dataset, per_device_query_batch_size, params, indices=query_indices,
-                                            allow_duplicates=True)
-        train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=train_indices,
-                                            allow_duplicates=True, stack=True)
-        with self._timed("compute_pairwise_scores"):
-            scores = compute_pairwise_scores_with_loaders(
-                loaded_factors=loaded, model=self.model, state=self.state, task=self.task, query_loader=query_loader,
-                per_device_query_batch_size=per_device_query_batch_size, train_loader=train_loader,
-                score_args=score_args, factor_args=factor_args, tracked_module_names=get_tracked_module_names(self.model))
-        if self.state.is_main_process:
-            save_pairwise_scores(out, scores, metadata=score_args.to_str_dict())
-        self.state.wait_for_everyone()
+        if query_indices is not None:
+            query_dataset = data.Subset(dataset=query_dataset, indices=query_indices)
+        if train_indices is not None:
+            train_dataset = data.Subset(dataset=train_dataset, indices=train_indices)
+        plan = self._partition_plan(len(train_dataset), score_args.data_partitions, score_args.module_partitions,
+                                    target_data_partitions, target_module_partitions)
+        scores = None
+        for partition, (start, end), module_names in plan.cells():
+            if pairwise_scores_exist(out, partition) and not overwrite_output_dir:
+                continue
+            query_loader = self._get_dataloader(query_dataset, per_device_query_batch_size, params,
+                                                allow_duplicates=not score_args.aggregate_query_gradients)
+            train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=list(range(start, end)),
+                                                allow_duplicates=not score_args.aggregate_train_gradients,
+                                                stack=not score_args.aggregate_train_gradients)
+            with self._timed("compute_pairwise_scores"):
+                scores = compute_pairwise_scores_with_loaders(
+                    loaded_factors=loaded, model=self.model, state=self.state, task=self.task, query_loader=query_loader,
+                    per_device_query_batch_size=per_device_query_batch_size, train_loader=train_loader,
+                    score_args=score_args, factor_args=factor_args, tracked_module_names=module_names)
+            if self.state.is_main_process:
+                save_pairwise_scores(out, scores, partition=partition, metadata=score_args.to_str_dict())
+            self.state.wait_for_everyone()
+        if plan.partitioned:
+            scores = None
+            if self.state.is_main_process:
+                scores = self.aggregate_pairwise_scores(scores_name)
+            self.state.wait_for_everyone()
         return scores if self.state.is_main_process else None
+
+    def aggregate_pairwise_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
+        """Aggregates the partitioned score files once all of them exist (reference ``score_computer.py:466-482``)."""
+        return self._aggregate_scores(scores_name, pairwise_scores_exist, load_pairwise_scores, save_pairwise_scores, dim=1)
 
     def load_pairwise_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
         out = self.scores_output_dir(scores_name)

@@ -1,0 +1,106 @@
+"""Rows of SURVEY.md section 8(f) ("next"): data/module partitions + aggregation + resume, the other factor
+strategies, self-influence, gradient aggregation, per-module / per-token scores.
+
+Every scenario runs twice: ``[gpu]`` through libkronfluence_hip.so on an MI355X (``-m gpu``), and ``[cpu-hostlogic]``
+with the HIP leaf operators replaced by the torch stand-ins of tests/cpu_engine.py (host logic only; see there).
+Expected values are the reference's golden tensors (tests/golden/make_golden.py) or invariances the reference's own
+tests assert (partitioned == un-partitioned, batch-size independence)."""
+
+import os
+
+import pytest
+import torch
+from safetensors.torch import load_file
+
+import fixtures as fx
+from test_pipeline_gpu import GOLDEN, build, nested, rel
+
+ENGINES = [pytest.param("cpu", id="cpu-hostlogic"), pytest.param("gpu", marks=pytest.mark.gpu, id="gpu")]
+
+
+@pytest.fixture(params=ENGINES)
+def engine(request):
+    if request.param == "cpu":
+        request.getfixturevalue("cpu_engine")
+    return request.param
+
+
+def _tol(engine, cpu, gpu):
+    return cpu if engine == "cpu" else gpu
+
+
+# ---- 8(f)-2: partitions, aggregation, skip-if-exists -------------------------------------------------------------
+@pytest.mark.parametrize("kind", ["mlp", "conv"])
+def test_partitioned_factors_and_scores_equal_unpartitioned(kind, tmp_path, engine):
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    spec, analyzer, train, query = build(kind, tmp_path)
+    analyzer.fit_all_factors("whole", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(use_empirical_fisher=True))
+    split = FactorArguments(use_empirical_fisher=True, covariance_data_partitions=2, covariance_module_partitions=2,
+                            lambda_data_partitions=3, lambda_module_partitions=2)
+    analyzer.fit_all_factors("split", train, per_device_batch_size=spec.factor_batch, factor_args=split)
+    out = analyzer.factors_output_dir("split")
+    for i in range(2):
+        for j in range(2):
+            assert (out / f"activation_covariance_data_partition{i}_module_partition{j}.safetensors").exists()
+    assert (out / "lambda_matrix_data_partition2_module_partition1.safetensors").exists()
+    tol = _tol(engine, 1e-6, 2e-6)
+    whole, parts = analyzer.load_covariance_matrices("whole"), analyzer.load_covariance_matrices("split")
+    for factor in whole:
+        assert set(whole[factor]) == set(parts[factor])
+        for module, want in whole[factor].items():
+            if want.dtype == torch.int64:
+                assert torch.equal(parts[factor][module], want)
+            else:
+                assert rel(parts[factor][module], want) <= tol, (factor, module)
+    # Lambda of the split run on ITS eigenbasis; compare on a common basis by re-fitting with the whole run's eigenvectors
+    analyzer.fit_lambda_matrices("split2", train, per_device_batch_size=spec.factor_batch, factor_args=split,
+                                 load_from_factors_name="whole")
+    whole_l, parts_l = analyzer.load_lambda_matrices("whole"), analyzer.load_lambda_matrices("split2")
+    for module, want in whole_l["lambda_matrix"].items():
+        assert rel(parts_l["lambda_matrix"][module], want) <= _tol(engine, 1e-6, 2e-5), module
+        assert torch.equal(parts_l["num_lambda_processed"][module], whole_l["num_lambda_processed"][module])
+
+    common = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
+    want = analyzer.compute_pairwise_scores("s_whole", "whole", query, train,
+                                            score_args=ScoreArguments(damping_factor=None), **common)["all_modules"]
+    got = analyzer.compute_pairwise_scores("s_split", "whole", query, train,
+                                           score_args=ScoreArguments(damping_factor=None, data_partitions=3, module_partitions=2),
+                                           **common)["all_modules"]
+    assert got.shape == want.shape and rel(got, want) <= _tol(engine, 1e-6, 2e-5), rel(got, want)
+    assert (analyzer.scores_output_dir("s_split") / "pairwise_scores_data_partition2_module_partition1.safetensors").exists()
+    assert rel(analyzer.load_pairwise_scores("s_split")["all_modules"], want) <= _tol(engine, 1e-6, 2e-5)
+
+
+def test_target_partitions_resume_and_late_aggregation(tmp_path, engine):
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    spec, analyzer, train, query = build("mlp", tmp_path)
+    args = FactorArguments(use_empirical_fisher=True, covariance_data_partitions=2, covariance_module_partitions=1)
+    with pytest.raises(ValueError):
+        analyzer.fit_covariance_matrices("bad", train, per_device_batch_size=8,
+                                         factor_args=FactorArguments(), target_data_partitions=[0])
+    with pytest.raises(ValueError):
+        analyzer.fit_covariance_matrices("f", train, per_device_batch_size=8, factor_args=args, target_data_partitions=[2])
+    analyzer.fit_covariance_matrices("f", train, per_device_batch_size=8, factor_args=args, target_data_partitions=[0])
+    assert analyzer.load_covariance_matrices("f") is None  # one partition missing: nothing aggregated yet
+    analyzer.fit_covariance_matrices("f", train, per_device_batch_size=8, factor_args=args, target_data_partitions=1)
+    cov = analyzer.load_covariance_matrices("f")
+    assert cov is not None and int(cov["num_activation_covariance_processed"]["0"].item()) == spec.n_train
+    # skip-if-exists: a second call leaves the files untouched
+    stamp = (analyzer.factors_output_dir("f") / "activation_covariance.safetensors").stat().st_mtime_ns
+    analyzer.fit_covariance_matrices("f", train, per_device_batch_size=8, factor_args=args)
+    assert (analyzer.factors_output_dir("f") / "activation_covariance.safetensors").stat().st_mtime_ns == stamp
+    # explicit aggregation entry points exist and are idempotent
+    analyzer.aggregate_covariance_matrices("f")
+    analyzer.perform_eigendecomposition("f", factor_args=args)
+    analyzer.fit_lambda_matrices("f", train, per_device_batch_size=8, factor_args=args)
+    score_args = ScoreArguments(damping_factor=None, data_partitions=2)
+    first = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=3,
+                                             per_device_train_batch_size=12, score_args=score_args, target_data_partitions=[1])
+    assert first is None and analyzer.load_pairwise_scores("s") is None
+    full = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=3,
+                                            per_device_train_batch_size=12, score_args=score_args)
+    assert full["all_modules"].shape == (spec.n_query, spec.n_train)
+    assert torch.equal(analyzer.aggregate_pairwise_scores("s")["all_modules"], full["all_modules"])
