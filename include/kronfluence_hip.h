@@ -212,6 +212,22 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dty
                       int64_t b, int64_t R, int64_t O, int64_t I, int append_ones, float scale,
                       void* workspace, int64_t workspace_bytes, void* stream);
 
+/*
+ * out[r] (+)= scale * sum_i X[r,i] * Y[r,i] * (W ? W[i] : 1)      r < rows, i < D
+ * The reduction of self-influence scores: module/tracker/self_score.py:61-62
+ * (`preconditioned.mul_(gradient).sum(dim=(1,2))`) with X = Y = the rotated per-sample gradient and
+ * W = Lambda^-1 for EK-FAC / K-FAC, X = Y = g for the identity strategy, W = Lambda^-1 for the diagonal
+ * one; and self_score.py:164 / linear.py:141-146 (self-measurement scores) with X = the preconditioned
+ * measurement gradient, Y = the loss gradient.  X, Y: [rows, D] contiguous, KF_F32 or KF_BF16
+ * independently; W: fp32 [D] or NULL; accumulate == 0 overwrites out.  fp32 accumulation.
+ */
+int kf_rowwise_dot(float* out, const void* X, int x_dtype, const void* Y, int y_dtype, const float* W,
+                   int64_t rows, int64_t D, float scale, int accumulate, void* stream);
+
+/* out[r,i] = scale * X[r,i] * M[i]: the diagonal strategy's preconditioner (factor/config.py:215-222). */
+int kf_mul_bcast(float* out, const void* X, int x_dtype, const float* M, int64_t rows, int64_t D,
+                 float scale, void* stream);
+
 /* Elementwise helper: dst[i] = (out_dtype) src[i] -- export of fp32 accumulators in the factor dtype. */
 int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream);
 

@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libkronfluence_hip.so"
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 KF_F32, KF_BF16, KF_F16, KF_F64, KF_I64, KF_I32, KF_U8 = range(7)
 
@@ -58,6 +58,8 @@ SIGNATURES = {
     "kf_precondition": (_i, [_p, _i, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _f, _p, _p, _p, _i64, _p]),
     "kf_pairwise_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "kf_pairwise_score": (_i, [_p, _i64, _p, _i, _i64, _i64, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
+    "kf_rowwise_dot": (_i, [_p, _p, _i, _p, _i, _p, _i64, _i64, _f, _i, _p]),
+    "kf_mul_bcast": (_i, [_p, _p, _i, _p, _i64, _i64, _f, _p]),
     "kf_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
 }
 

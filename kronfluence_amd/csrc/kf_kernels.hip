@@ -596,6 +596,68 @@ void launch_score_r1(const ScoreArgs& a, dim3 grid, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Row-wise weighted dot products (self-influence) and the broadcast product of the
+// diagonal strategy.  Both are pure HBM streams: one read of each operand, 16-byte loads when the
+// row length allows, fp32 accumulation, one atomicAdd per (row, split).
+// ------------------------------------------------------------------------------------------------
+template <int DT> struct Vec4;
+template <> struct Vec4<F32> {
+    static __device__ __forceinline__ void load(const void* p, int64_t idx, float (&v)[4]) {
+        const float4 r = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p) + idx);
+        v[0] = r.x; v[1] = r.y; v[2] = r.z; v[3] = r.w;
+    }
+};
+template <> struct Vec4<BF16> {
+    static __device__ __forceinline__ void load(const void* p, int64_t idx, float (&v)[4]) {
+        const uint2 r = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(p) + idx);
+        v[0] = __uint_as_float(r.x << 16); v[1] = __uint_as_float(r.x & 0xffff0000u);
+        v[2] = __uint_as_float(r.y << 16); v[3] = __uint_as_float(r.y & 0xffff0000u);
+    }
+};
+
+template <int DTX, int DTY>
+__global__ __launch_bounds__(256) void rowwise_dot_kernel(float* out, const void* X, const void* Y, const float* W,
+                                                          int64_t D, float scale, int vec) {
+    __shared__ float part[4];
+    const int64_t row = blockIdx.x;
+    const int64_t base = row * D;
+    const int64_t splits = gridDim.y, split = blockIdx.y;
+    float s = 0.f;
+    if (vec) {  // D % 4 == 0 and 16-byte aligned bases: groups of four elements
+        const int64_t groups = D >> 2;
+        for (int64_t j = split * 256 + threadIdx.x; j < groups; j += splits * 256) {
+            float x[4], y[4];
+            Vec4<DTX>::load(X, base + 4 * j, x);
+            Vec4<DTY>::load(Y, base + 4 * j, y);
+            if (W) {
+                const float4 w = *reinterpret_cast<const float4*>(W + 4 * j);
+                s += x[0] * y[0] * w.x + x[1] * y[1] * w.y + x[2] * y[2] * w.z + x[3] * y[3] * w.w;
+            } else {
+                s += x[0] * y[0] + x[1] * y[1] + x[2] * y[2] + x[3] * y[3];
+            }
+        }
+    } else {
+        for (int64_t i = split * 256 + threadIdx.x; i < D; i += splits * 256) {
+            const float t = load_t<DTX>(X, base + i) * load_t<DTY>(Y, base + i);
+            s += W ? t * W[i] : t;
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out + row, scale * (part[0] + part[1] + part[2] + part[3]));
+}
+
+template <int DTX>
+__global__ __launch_bounds__(256) void mul_bcast_kernel(float* out, const void* X, const float* M, int64_t rows, int64_t D,
+                                                        float scale) {
+    const int64_t total = rows * D;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x)
+        out[e] = scale * load_t<DTX>(X, e) * M[e % D];
+}
+
+// ------------------------------------------------------------------------------------------------
 // cast
 // ------------------------------------------------------------------------------------------------
 __global__ void cast_kernel(void* dst, int dd, const void* src, int sd, int64_t n) {
@@ -626,7 +688,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 5; }
+int kf_abi_version(void) { return 6; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -921,6 +983,42 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dty
     kf_view vg = make_view(psg, p_dtype, 0, tiled ? 64 : D, 1, b, D);
     if (tiled) { vp.k_tile_stride = Q * 64; vg.k_tile_stride = b * 64; }
     return launch_gemm(scores, ld_scores, 0, vp, vg, 1, scale, 1.0f, nullptr, 0, st);
+}
+
+int kf_rowwise_dot(float* out, const void* X, int x_dtype, const void* Y, int y_dtype, const float* W, int64_t rows,
+                   int64_t D, float scale, int accumulate, void* stream) {
+    if (!out || !X || !Y || rows < 0 || D < 0) return KF_ERR_INVALID_ARGUMENT;
+    if ((x_dtype != KF_F32 && x_dtype != KF_BF16) || (y_dtype != KF_F32 && y_dtype != KF_BF16)) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (rows == 0) return KF_OK;
+    hipStream_t st = as_stream(stream);
+    if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * rows, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    if (D == 0) return KF_OK;
+    const auto aligned = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; };
+    const int vec = (D % 8 == 0) && aligned(X) && aligned(Y) && (!W || aligned(W));
+    // enough blocks to fill 256 CUs even for a handful of rows, without splitting short rows
+    int64_t splits = std::max<int64_t>(1, std::min<int64_t>(cdiv(2048, rows), cdiv(D, 256 * 16)));
+    const dim3 grid(static_cast<unsigned>(rows), static_cast<unsigned>(splits));
+    if (x_dtype == KF_F32 && y_dtype == KF_F32)
+        hipLaunchKernelGGL((rowwise_dot_kernel<F32, F32>), grid, dim3(256), 0, st, out, X, Y, W, D, scale, vec);
+    else if (x_dtype == KF_BF16 && y_dtype == KF_F32)
+        hipLaunchKernelGGL((rowwise_dot_kernel<BF16, F32>), grid, dim3(256), 0, st, out, X, Y, W, D, scale, vec);
+    else if (x_dtype == KF_F32 && y_dtype == KF_BF16)
+        hipLaunchKernelGGL((rowwise_dot_kernel<F32, BF16>), grid, dim3(256), 0, st, out, X, Y, W, D, scale, vec);
+    else
+        hipLaunchKernelGGL((rowwise_dot_kernel<BF16, BF16>), grid, dim3(256), 0, st, out, X, Y, W, D, scale, vec);
+    return launch_status();
+}
+
+int kf_mul_bcast(float* out, const void* X, int x_dtype, const float* M, int64_t rows, int64_t D, float scale, void* stream) {
+    if (!out || !X || !M || rows < 0 || D <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (x_dtype != KF_F32 && x_dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (rows == 0) return KF_OK;
+    hipStream_t st = as_stream(stream);
+    if (x_dtype == KF_F32)
+        hipLaunchKernelGGL((mul_bcast_kernel<F32>), dim3(stream_grid(rows * D)), dim3(256), 0, st, out, X, M, rows, D, scale);
+    else
+        hipLaunchKernelGGL((mul_bcast_kernel<BF16>), dim3(stream_grid(rows * D)), dim3(256), 0, st, out, X, M, rows, D, scale);
+    return launch_status();
 }
 
 int kf_cast(void* dst, int dst_dtype, const void* src, int src_dtype, int64_t numel, void* stream) {

@@ -102,9 +102,25 @@ class LambdaTracker(BaseTracker):
 
     _bf16_eigenvectors = None  # (Q_A^T, Q_G^T) in bf16, for lambda_dtype == bf16
 
+    def _rotates(self) -> bool:
+        """EK-FAC fits Lambda in the Kronecker eigenbasis; the diagonal strategy in parameter space
+        (``requires_eigendecomposition_for_lambda``, reference factor.py:184-201)."""
+        return FactorConfig.CONFIGS[self.module.factor_args.strategy].requires_eigendecomposition_for_lambda
+
     def _update_from_factors(self, g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> None:
         module, storage = self.module, self.module.storage
         b, r, o = g.shape
+        if not self._rotates():
+            ip = a.shape[-1] + int(append_ones)
+            if storage[LAMBDA_MATRIX_NAME] is None:
+                storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=g.device)
+                storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
+            storage[NUM_LAMBDA_PROCESSED].add_(b)
+            gt, at = ops.cast(g, torch.float32), ops.cast(a, torch.float32)
+            if append_ones:
+                at = torch.cat([at, at.new_ones(at.shape[:-1] + (1,))], dim=-1).contiguous()
+            ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
+            return
         q_a, q_g = self._eigenvectors(g.device)
         ip = q_a.shape[0]
         if storage[LAMBDA_MATRIX_NAME] is None:
@@ -132,17 +148,23 @@ class LambdaTracker(BaseTracker):
         storage = self.module.storage
         g = per_sample_gradient.to(torch.float32).contiguous()
         b, o, ip = g.shape
-        q_a, q_g = self._eigenvectors(g.device)
         if storage[LAMBDA_MATRIX_NAME] is None:
             storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=g.device)
             storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
         storage[NUM_LAMBDA_PROCESSED].add_(b)
-        t1 = torch.empty((b * o, ip), dtype=torch.float32, device=g.device)
-        ops.gemm(t1, ip, 0, ops.view(g, 0, ip, 1, b * o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
-        t2 = torch.empty((b, o, ip), dtype=torch.float32, device=g.device)
-        ops.gemm(t2, ip, o * ip, ops.view(q_g, 0, 1, o, o, o), ops.view(t1, o * ip, 1, ip, ip, o), batch=b)
+        if self._rotates():
+            q_a, q_g = self._eigenvectors(g.device)
+            t1 = torch.empty((b * o, ip), dtype=torch.float32, device=g.device)
+            ops.gemm(t1, ip, 0, ops.view(g, 0, ip, 1, b * o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
+            rotated = torch.empty((b, o, ip), dtype=torch.float32, device=g.device)
+            ops.gemm(rotated, ip, o * ip, ops.view(q_g, 0, 1, o, o, o), ops.view(t1, o * ip, 1, ip, ip, o), batch=b)
+        else:
+            rotated = g
+        # Lambda[n] += scale^2 * sum_b rotated[b, n]^2: a 1 x (O I') GEMM over the batch axis, squares fused in the loader
         scale = self.module.gradient_scale
-        storage[LAMBDA_MATRIX_NAME].add_(t2.square_().sum(dim=0), alpha=scale * scale)
+        ones = torch.ones(b, dtype=torch.float32, device=g.device)
+        ops.gemm(storage[LAMBDA_MATRIX_NAME], o * ip, 0, ops.view(ones, 0, 0, 1, 1, b),
+                 ops.view(rotated, 0, 1, o * ip, o * ip, b, square=True), alpha=scale * scale, beta=1.0)
 
     def register_hooks(self) -> None:
         module = self.module

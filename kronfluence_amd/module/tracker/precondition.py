@@ -75,7 +75,7 @@ class PreconditionTracker(BaseTracker):
         def backward_hook(output_gradient: torch.Tensor) -> None:
             activation = self._take_activation()
             self.cached_hooks.pop().remove()
-            if module.per_sample_gradient_process_fnc is None and module.factor_args.strategy == "ekfac":
+            if module.per_sample_gradient_process_fnc is None and module.factor_args.strategy in ("ekfac", "kfac"):
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 if self.EIGENBASIS_QUERIES and g.shape[1] == 1 and not module.factor_args.has_shared_parameters:
                     q = g.shape[0]
@@ -95,6 +95,7 @@ class PreconditionTracker(BaseTracker):
                                              scale=module.gradient_scale, out_dtype=self._out_dtype(),
                                              q_a_bf16=qa16, q_g_t_bf16=qgt16))
             else:
+                module.queries_in_eigenbasis = False
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
                 out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(psg, storage)
                 if module.gradient_scale != 1.0:
@@ -116,6 +117,7 @@ class PreconditionTracker(BaseTracker):
     def finalize_iteration(self) -> None:
         module = self.module
         if module.factor_args.has_shared_parameters and self.cached_per_sample_gradient is not None:
+            module.queries_in_eigenbasis = False
             out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(
                 self.cached_per_sample_gradient, module.storage)
             if module.gradient_scale != 1.0:

@@ -328,6 +328,47 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: to
         SCORE_EVENT_LOG.append((start, end, flops))
 
 
+def rowwise_dot(out: torch.Tensor, x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor] = None,
+                scale: float = 1.0, accumulate: bool = True) -> None:
+    """``out[r] (+)= scale * sum_i x[r,i] y[r,i] (weight[i])`` (kf_rowwise_dot): the reduction of self-influence
+    scores (module/tracker/self_score.py:61-62, 164).  ``x``, ``y``: ``[rows, ...]`` fp32 / bf16; ``out``: fp32 ``[rows]``."""
+    nat.require_device(out, "out")
+    nat.require_device(x, "x")
+    nat.require_device(y, "y")
+    x, y = _contig(x), _contig(y)
+    rows = x.shape[0]
+    d = x.numel() // max(rows, 1)
+    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == rows and y.numel() == x.numel()
+    assert x.dtype in (torch.float32, torch.bfloat16) and y.dtype in (torch.float32, torch.bfloat16)
+    if weight is not None:
+        nat.require_device(weight, "weight")
+        weight = _contig(weight)
+        assert weight.dtype == torch.float32 and weight.numel() == d
+    nat.check(
+        nat.lib().kf_rowwise_dot(out.data_ptr(), x.data_ptr(), nat.dtype_code(x.dtype), y.data_ptr(), nat.dtype_code(y.dtype),
+                                 _ptr(weight), rows, d, scale, int(accumulate), nat.stream_ptr(x.device)),
+        "kf_rowwise_dot",
+    )
+
+
+def mul_bcast(x: torch.Tensor, m: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """``scale * x[r] o m`` for ``x: [rows, ...]`` (fp32 / bf16) and ``m`` fp32 of one row's shape -> fp32 (kf_mul_bcast;
+    the diagonal strategy's ``gradient * lambda_matrix``, factor/config.py:215-222)."""
+    nat.require_device(x, "x")
+    nat.require_device(m, "m")
+    x, m = _contig(x), _contig(m)
+    rows = x.shape[0]
+    d = m.numel()
+    assert m.dtype == torch.float32 and x.numel() == rows * d and x.dtype in (torch.float32, torch.bfloat16)
+    out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    nat.check(
+        nat.lib().kf_mul_bcast(out.data_ptr(), x.data_ptr(), nat.dtype_code(x.dtype), m.data_ptr(), rows, d, scale,
+                               nat.stream_ptr(x.device)),
+        "kf_mul_bcast",
+    )
+    return out
+
+
 def cast(src: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
     """Device-side dtype conversion used when exporting fp32/fp64 accumulators in the factor dtype."""
     nat.require_device(src, "src")

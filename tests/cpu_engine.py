@@ -132,13 +132,20 @@ def pairwise_score(scores, col_offset, p, g, a, append_ones, scale=1.0, p_tiled=
     scores[:, col_offset:col_offset + psg.shape[0]] += block.to(scores.dtype)
 
 
-def rowwise_dot(out, x, y, scale=1.0, accumulate=True) -> None:
+def rowwise_dot(out, x, y, weight=None, scale=1.0, accumulate=True) -> None:
     b = x.shape[0]
-    value = (x.reshape(b, -1).double() * y.reshape(b, -1).double()).sum(1) * scale
+    prod = x.reshape(b, -1).double() * y.reshape(b, -1).double()
+    if weight is not None:
+        prod = prod * weight.reshape(1, -1).double()
+    value = prod.sum(1) * scale
     if accumulate:
         out.add_(value.to(out.dtype))
     else:
         out.copy_(value.to(out.dtype))
+
+
+def mul_bcast(x, m, scale=1.0):
+    return (x.double() * m.double().reshape((1,) + tuple(x.shape[1:])) * scale).to(torch.float32)
 
 
 def cast(src, dtype):
@@ -146,7 +153,7 @@ def cast(src, dtype):
 
 
 LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "lambda_accum", "inv_lambda", "precondition",
-          "pairwise_score", "rowwise_dot", "cast")
+          "pairwise_score", "rowwise_dot", "mul_bcast", "cast")
 
 
 def install(monkeypatch) -> None:

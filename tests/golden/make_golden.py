@@ -98,7 +98,69 @@ def run(kind: str, dtype: torch.dtype, out_path: str) -> None:
     print(f"{out_path}: {len(out)} tensors, scores {tuple(out['scores/damp1e-8'].shape)}")
 
 
+def run_widen(kind: str, out_path: str) -> None:
+    """Goldens for the SURVEY.md 8(f) rows, fp64: self-influence (both variants), the identity / diagonal / kfac
+    strategies, per-module scores, query / train gradient aggregation and (sequence fixture) per-token scores."""
+    dtype = torch.float64
+    spec = fx.FIXTURES[kind]
+    train = data.TensorDataset(*fx.make_data(kind, spec.n_train, seed=1))
+    query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
+    task = make_task(kind)
+    out = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        for strategy in ("ekfac", "kfac", "diagonal", "identity"):
+            model = prepare_model(fx.make_model(kind).to(dtype=dtype), task)
+            analyzer = Analyzer(f"widen_{strategy}", model, task, cpu=True, disable_tqdm=True, output_dir=tmp)
+            fargs = FactorArguments(strategy=strategy, use_empirical_fisher=True, activation_covariance_dtype=dtype,
+                                    gradient_covariance_dtype=dtype, per_sample_gradient_dtype=dtype, lambda_dtype=dtype)
+            analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch, factor_args=fargs,
+                                     overwrite_output_dir=True)
+            if strategy == "diagonal":
+                for name, per_module in analyzer.load_lambda_matrices("f").items():
+                    for module, tensor in per_module.items():
+                        out[f"strategy/diagonal/lam/{name}/{module}"] = tensor.contiguous()
+
+            def sargs(**kw):
+                return ScoreArguments(damping_factor=None, per_sample_gradient_dtype=dtype, precondition_dtype=dtype,
+                                      score_dtype=dtype, **kw)
+
+            batch = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
+            analyzer.compute_pairwise_scores("s", "f", query, train, score_args=sargs(), overwrite_output_dir=True, **batch)
+            out[f"strategy/{strategy}/scores"] = analyzer.load_pairwise_scores("s")["all_modules"].contiguous()
+            analyzer.compute_self_scores("self", "f", train, per_device_train_batch_size=spec.train_batch,
+                                         score_args=sargs(), overwrite_output_dir=True)
+            out[f"strategy/{strategy}/self"] = analyzer.load_self_scores("self")["all_modules"].contiguous()
+            if strategy != "ekfac":
+                continue
+            analyzer.compute_self_scores("selfm", "f", train, per_device_train_batch_size=spec.train_batch,
+                                         score_args=sargs(use_measurement_for_self_influence=True), overwrite_output_dir=True)
+            out["self_measurement"] = analyzer.load_self_scores("selfm")["all_modules"].contiguous()
+            analyzer.compute_pairwise_scores("pm", "f", query, train, score_args=sargs(compute_per_module_scores=True),
+                                             overwrite_output_dir=True, **batch)
+            for module, tensor in analyzer.load_pairwise_scores("pm").items():
+                out[f"permodule/{module}"] = tensor.contiguous()
+            analyzer.compute_self_scores("selfpm", "f", train, per_device_train_batch_size=spec.train_batch,
+                                         score_args=sargs(compute_per_module_scores=True), overwrite_output_dir=True)
+            for module, tensor in analyzer.load_self_scores("selfpm").items():
+                out[f"self_permodule/{module}"] = tensor.contiguous()
+            for tag, kw in (("aggq", dict(aggregate_query_gradients=True)), ("aggt", dict(aggregate_train_gradients=True)),
+                            ("aggqt", dict(aggregate_query_gradients=True, aggregate_train_gradients=True))):
+                analyzer.compute_pairwise_scores(tag, "f", query, train, score_args=sargs(**kw), overwrite_output_dir=True, **batch)
+                out[tag] = analyzer.load_pairwise_scores(tag)["all_modules"].contiguous()
+            if kind == "seq":
+                analyzer.compute_pairwise_scores("tok", "f", query, train, score_args=sargs(compute_per_token_scores=True),
+                                                 overwrite_output_dir=True, **batch)
+                out["pertoken"] = analyzer.load_pairwise_scores("tok")["all_modules"].contiguous()
+    save_file(out, out_path)
+    print(f"{out_path}: {len(out)} tensors: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in out.items() if "/" not in k or k.endswith(("scores", "self"))))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "widen":
+        torch.manual_seed(0)
+        for kind in fx.FIXTURES:
+            run_widen(kind, os.path.join(HERE, f"widen_{kind}_fp64.safetensors"))
+        sys.exit(0)
     torch.manual_seed(0)
     for kind in fx.FIXTURES:
         for tag, dtype in (("fp64", torch.float64), ("fp32", torch.float32)):

@@ -104,3 +104,34 @@ def test_target_partitions_resume_and_late_aggregation(tmp_path, engine):
                                             per_device_train_batch_size=12, score_args=score_args)
     assert full["all_modules"].shape == (spec.n_query, spec.n_train)
     assert torch.equal(analyzer.aggregate_pairwise_scores("s")["all_modules"], full["all_modules"])
+
+
+# ---- 8(f)-4: identity / diagonal / kfac strategies ---------------------------------------------------------------
+def _widen(kind):
+    return load_file(os.path.join(GOLDEN, f"widen_{kind}_fp64.safetensors"))
+
+
+@pytest.mark.parametrize("strategy", ["kfac", "diagonal", "identity"])
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_other_strategies_match_reference(kind, strategy, tmp_path, engine):
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    gold = _widen(kind)
+    spec, analyzer, train, query = build(kind, tmp_path)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(strategy=strategy, use_empirical_fisher=True))
+    out = analyzer.factors_output_dir("f")
+    assert (out / "activation_covariance.safetensors").exists() == (strategy == "kfac")
+    assert (out / "lambda_matrix.safetensors").exists() == (strategy == "diagonal")
+    if strategy == "diagonal":
+        lam = analyzer.load_lambda_matrices("f")
+        for key, want in gold.items():
+            if key.startswith("strategy/diagonal/lam/lambda_matrix/"):
+                module = key.rsplit("/", 1)[1]
+                assert rel(lam["lambda_matrix"][module], want) <= _tol(engine, 1e-6, 2e-5), module
+    scores = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=spec.query_batch,
+                                              per_device_train_batch_size=spec.train_batch,
+                                              score_args=ScoreArguments(damping_factor=None))["all_modules"]
+    want = gold[f"strategy/{strategy}/scores"]
+    assert scores.shape == want.shape
+    assert rel(scores, want) <= _tol(engine, 1e-5, 5e-4 if strategy == "kfac" else 1e-4), rel(scores, want)
