@@ -34,6 +34,10 @@ from kronfluence_amd.module.utils import get_tracked_module_names, make_modules_
 from kronfluence_amd.score.pairwise import (
     compute_pairwise_scores_with_loaders, load_pairwise_scores, pairwise_scores_exist, save_pairwise_scores,
 )
+from kronfluence_amd.score.self import (
+    compute_self_measurement_scores_with_loaders, compute_self_scores_with_loaders, load_self_scores, save_self_scores,
+    self_scores_exist,
+)
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import FACTOR_SAVE_PREFIX, FACTOR_TYPE, SCORE_SAVE_PREFIX, SCORE_TYPE
 from kronfluence_amd.utils.dataset import (
@@ -494,3 +498,60 @@ class Analyzer:
     def load_pairwise_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
         out = self.scores_output_dir(scores_name)
         return load_pairwise_scores(out) if pairwise_scores_exist(out) else None
+
+    def compute_self_scores(self, scores_name: str, factors_name: str, train_dataset: data.Dataset,
+                            per_device_train_batch_size: Optional[int] = None,
+                            initial_per_device_train_batch_size_attempt: int = 4096,
+                            train_indices: Optional[Sequence[int]] = None,
+                            dataloader_kwargs: Optional[DataLoaderKwargs] = None,
+                            score_args: Optional[ScoreArguments] = None,
+                            target_data_partitions: Optional[Sequence[int]] = None,
+                            target_module_partitions: Optional[Sequence[int]] = None,
+                            overwrite_output_dir: bool = False) -> Optional[SCORE_TYPE]:
+        """Self-influence scores ``[N]`` (reference ``computer/score_computer.py:558-773``)."""
+        del initial_per_device_train_batch_size_attempt
+        score_args = score_args or ScoreArguments()
+        out = self.scores_output_dir(scores_name)
+        if self.state.is_main_process:
+            os.makedirs(out, exist_ok=True)
+        self.state.wait_for_everyone()
+        if self_scores_exist(out) and not overwrite_output_dir:
+            return self.load_self_scores(scores_name)
+        factor_args = self._stored_factor_args(factors_name)
+        self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
+        loaded = self.load_all_factors(factors_name)
+        params = (dataloader_kwargs or self._dataloader_params).to_dict()
+        train_batch = self._require_batch_size(per_device_train_batch_size, "per_device_train_batch_size")
+        if train_indices is not None:
+            train_dataset = data.Subset(dataset=train_dataset, indices=train_indices)
+        plan = self._partition_plan(len(train_dataset), score_args.data_partitions, score_args.module_partitions,
+                                    target_data_partitions, target_module_partitions)
+        stage = (compute_self_measurement_scores_with_loaders if score_args.use_measurement_for_self_influence
+                 else compute_self_scores_with_loaders)
+        scores = None
+        for partition, (start, end), module_names in plan.cells():
+            if self_scores_exist(out, partition) and not overwrite_output_dir:
+                continue
+            train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=list(range(start, end)),
+                                                allow_duplicates=True, stack=True)
+            with self._timed("compute_self_scores"):
+                scores = stage(loaded_factors=loaded, model=self.model, state=self.state, task=self.task,
+                               train_loader=train_loader, score_args=score_args, factor_args=factor_args,
+                               tracked_module_names=module_names)
+            if self.state.is_main_process:
+                save_self_scores(out, scores, partition=partition, metadata=score_args.to_str_dict())
+            self.state.wait_for_everyone()
+        if plan.partitioned:
+            scores = None
+            if self.state.is_main_process:
+                scores = self.aggregate_self_scores(scores_name)
+            self.state.wait_for_everyone()
+        return scores if self.state.is_main_process else None
+
+    def aggregate_self_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
+        """Aggregates the partitioned self-score files once all of them exist (reference ``score_computer.py:775-790``)."""
+        return self._aggregate_scores(scores_name, self_scores_exist, load_self_scores, save_self_scores, dim=0)
+
+    def load_self_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
+        out = self.scores_output_dir(scores_name)
+        return load_self_scores(out) if self_scores_exist(out) else None

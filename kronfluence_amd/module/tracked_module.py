@@ -21,12 +21,14 @@ from typing import Any, Callable, Dict, List, Optional, Tuple, Type, Union
 import torch
 from torch import nn
 
+from kronfluence_amd import ops
 from kronfluence_amd.arguments import FactorArguments, ScoreArguments
 from kronfluence_amd.factor.config import FactorConfig
 from kronfluence_amd.module.tracker.base import BaseTracker
 from kronfluence_amd.module.tracker.factor import CovarianceTracker, LambdaTracker
 from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
 from kronfluence_amd.module.tracker.precondition import PreconditionTracker
+from kronfluence_amd.module.tracker.self_score import SelfScoreTracker, SelfScoreWithMeasurementTracker
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
     AGGREGATED_GRADIENT_NAME,
@@ -88,8 +90,8 @@ class TrackedModule(nn.Module):
             ModuleMode.PRECONDITION_GRADIENT: PreconditionTracker(self),
             ModuleMode.PAIRWISE_SCORE: PairwiseScoreTracker(self),
             ModuleMode.GRADIENT_AGGREGATION: _OutOfScopeTracker(self),
-            ModuleMode.SELF_SCORE: _OutOfScopeTracker(self),
-            ModuleMode.SELF_MEASUREMENT_SCORE: _OutOfScopeTracker(self),
+            ModuleMode.SELF_SCORE: SelfScoreTracker(self),
+            ModuleMode.SELF_MEASUREMENT_SCORE: SelfScoreWithMeasurementTracker(self),
         }
         self.attention_mask: Optional[torch.Tensor] = None
         self.gradient_scale: float = 1.0
@@ -183,7 +185,16 @@ class TrackedModule(nn.Module):
 
     def compute_self_measurement_score(self, preconditioned_gradient: torch.Tensor, input_activation: torch.Tensor,
                                        output_gradient: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("Self-influence is outside the accelerated hot path (SURVEY.md 8f).")
+        """``einsum("bio,b...i,b...o->b")`` of reference ``linear.py:124-138`` / ``conv2d.py:211-227``: the per-sample
+        gradient on the MFMA engine, then one ``kf_rowwise_dot``."""
+        g, a, ones = self.gradient_factors(input_activation, output_gradient)
+        psg = ops.per_sample_gradient(g, a, ones)
+        p = preconditioned_gradient.contiguous()
+        if p.dtype not in (torch.float32, torch.bfloat16):
+            p = p.to(torch.float32)
+        scores = torch.zeros(psg.shape[0], dtype=torch.float32, device=psg.device)
+        ops.rowwise_dot(scores, p, psg, None, accumulate=False)
+        return scores
 
     # -- fused hot-path operators ------------------------------------------------------------------
     @property

@@ -135,3 +135,37 @@ def test_other_strategies_match_reference(kind, strategy, tmp_path, engine):
     want = gold[f"strategy/{strategy}/scores"]
     assert scores.shape == want.shape
     assert rel(scores, want) <= _tol(engine, 1e-5, 5e-4 if strategy == "kfac" else 1e-4), rel(scores, want)
+
+
+# ---- 8(f)-3: self-influence -------------------------------------------------------------------------------------
+@pytest.mark.parametrize("strategy", ["ekfac", "kfac", "diagonal", "identity"])
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_self_scores_match_reference(kind, strategy, tmp_path, engine):
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    gold = _widen(kind)
+    spec, analyzer, train, _query = build(kind, tmp_path)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(strategy=strategy, use_empirical_fisher=True))
+    scores = analyzer.compute_self_scores("self", "f", train, per_device_train_batch_size=spec.train_batch,
+                                          score_args=ScoreArguments(damping_factor=None))["all_modules"]
+    want = gold[f"strategy/{strategy}/self"]
+    assert scores.shape == want.shape == (spec.n_train,)
+    tol = _tol(engine, 1e-5, 5e-4 if strategy in ("ekfac", "kfac") else 1e-4)
+    assert rel(scores, want) <= tol, rel(scores, want)
+    assert (analyzer.scores_output_dir("self") / "self_scores.safetensors").exists()
+    if strategy != "ekfac":
+        return
+    # batch-size independence, per-module split, data/module partitions (reference tests/scores/test_self_scores.py)
+    other = analyzer.compute_self_scores("self_b", "f", train, per_device_train_batch_size=7,
+                                         score_args=ScoreArguments(damping_factor=None, data_partitions=2, module_partitions=2))
+    assert rel(other["all_modules"], scores) <= _tol(engine, 1e-6, 2e-5)
+    per_module = analyzer.compute_self_scores("self_pm", "f", train, per_device_train_batch_size=spec.train_batch,
+                                              score_args=ScoreArguments(damping_factor=None, compute_per_module_scores=True))
+    for key, value in gold.items():
+        if key.startswith("self_permodule/"):
+            assert rel(per_module[key.split("/", 1)[1]], value) <= tol, key
+    assert rel(sum(per_module.values()), scores) <= _tol(engine, 1e-6, 2e-5)
+    measured = analyzer.compute_self_scores("self_m", "f", train, per_device_train_batch_size=spec.train_batch,
+                                            score_args=ScoreArguments(damping_factor=None, use_measurement_for_self_influence=True))
+    assert rel(measured["all_modules"], gold["self_measurement"]) <= tol, rel(measured["all_modules"], gold["self_measurement"])
