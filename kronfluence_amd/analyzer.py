@@ -12,6 +12,7 @@ import logging
 import os
 import time
 from pathlib import Path
+import dataclasses
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence, Tuple, Union
 
@@ -32,7 +33,7 @@ from kronfluence_amd.factor.eigen import (
 from kronfluence_amd.module.tracked_module import TrackedModule
 from kronfluence_amd.module.utils import get_tracked_module_names, make_modules_partition, wrap_tracked_modules
 from kronfluence_amd.score.pairwise import (
-    compute_pairwise_scores_with_loaders, load_pairwise_scores, pairwise_scores_exist, save_pairwise_scores,
+    compute_pairwise_query_aggregated_scores_with_loaders, compute_pairwise_scores_with_loaders, load_pairwise_scores, pairwise_scores_exist, save_pairwise_scores,
 )
 from kronfluence_amd.score.self import (
     compute_self_measurement_scores_with_loaders, compute_self_scores_with_loaders, load_self_scores, save_self_scores,
@@ -455,6 +456,12 @@ class Analyzer:
         if pairwise_scores_exist(out) and not overwrite_output_dir:
             return self.load_pairwise_scores(scores_name)
         factor_args = self._stored_factor_args(factors_name)
+        if score_args.compute_per_token_scores and (score_args.aggregate_train_gradients or factor_args.has_shared_parameters
+                                                    or self.task.enable_post_process_per_sample_gradient):
+            # reference score_computer.py:287-308: token-wise scores are silently disabled in these configurations
+            self.logger.warning("Token-wise influence computation is not compatible with this configuration; "
+                                "disabling `compute_per_token_scores`.")
+            score_args = dataclasses.replace(score_args, compute_per_token_scores=False)
         self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
         loaded = self.load_all_factors(factors_name)
         if not loaded and FactorConfig.CONFIGS[factor_args.strategy].requires_lambda_matrices_for_precondition:
@@ -476,8 +483,10 @@ class Analyzer:
             train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=list(range(start, end)),
                                                 allow_duplicates=not score_args.aggregate_train_gradients,
                                                 stack=not score_args.aggregate_train_gradients)
+            stage = (compute_pairwise_query_aggregated_scores_with_loaders if score_args.aggregate_query_gradients
+                     else compute_pairwise_scores_with_loaders)
             with self._timed("compute_pairwise_scores"):
-                scores = compute_pairwise_scores_with_loaders(
+                scores = stage(
                     loaded_factors=loaded, model=self.model, state=self.state, task=self.task, query_loader=query_loader,
                     per_device_query_batch_size=per_device_query_batch_size, train_loader=train_loader,
                     score_args=score_args, factor_args=factor_args, tracked_module_names=module_names)

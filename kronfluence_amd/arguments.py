@@ -101,9 +101,6 @@ def unsupported_score_options(score_args: ScoreArguments) -> Dict[str, Any]:
     """Options outside the accelerated hot path ("next" rows); the score stage
     rejects them explicitly instead of silently computing something else."""
     flagged = {}
-    for name in ("compute_per_token_scores", "aggregate_query_gradients", "aggregate_train_gradients"):
-        if getattr(score_args, name):
-            flagged[name] = True
     if score_args.query_gradient_low_rank is not None:
         flagged["query_gradient_low_rank"] = score_args.query_gradient_low_rank
     return flagged

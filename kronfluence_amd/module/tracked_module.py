@@ -26,6 +26,7 @@ from kronfluence_amd.arguments import FactorArguments, ScoreArguments
 from kronfluence_amd.factor.config import FactorConfig
 from kronfluence_amd.module.tracker.base import BaseTracker
 from kronfluence_amd.module.tracker.factor import CovarianceTracker, LambdaTracker
+from kronfluence_amd.module.tracker.gradient import GradientTracker
 from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
 from kronfluence_amd.module.tracker.precondition import PreconditionTracker
 from kronfluence_amd.module.tracker.self_score import SelfScoreTracker, SelfScoreWithMeasurementTracker
@@ -54,15 +55,6 @@ class ModuleMode(str):
     GRADIENT_AGGREGATION = "gradient_aggregation"
 
 
-class _OutOfScopeTracker(BaseTracker):
-    """Modes outside the accelerated path (self-influence, gradient aggregation)."""
-
-    def register_hooks(self) -> None:
-        raise NotImplementedError(
-            f"Mode `{self.module.current_mode}` is not part of the MI355X hot path (pairwise EK-FAC scoring)."
-        )
-
-
 class TrackedModule(nn.Module):
     SUPPORTED_MODULES: Dict[Type[nn.Module], Any] = {}
 
@@ -89,7 +81,7 @@ class TrackedModule(nn.Module):
             ModuleMode.LAMBDA: LambdaTracker(self),
             ModuleMode.PRECONDITION_GRADIENT: PreconditionTracker(self),
             ModuleMode.PAIRWISE_SCORE: PairwiseScoreTracker(self),
-            ModuleMode.GRADIENT_AGGREGATION: _OutOfScopeTracker(self),
+            ModuleMode.GRADIENT_AGGREGATION: GradientTracker(self),
             ModuleMode.SELF_SCORE: SelfScoreTracker(self),
             ModuleMode.SELF_MEASUREMENT_SCORE: SelfScoreWithMeasurementTracker(self),
         }
@@ -181,7 +173,21 @@ class TrackedModule(nn.Module):
         raise NotImplementedError
 
     def compute_summed_gradient(self, input_activation: torch.Tensor, output_gradient: torch.Tensor) -> torch.Tensor:
-        raise NotImplementedError("Gradient aggregation is outside the accelerated hot path (SURVEY.md 8f).")
+        """``einsum("b...i,b...o->io")[None]`` of reference ``linear.py:56-66`` / ``conv2d.py:134-162`` -> ``[1, O, I']``."""
+        g, a, ones = self.gradient_factors(input_activation, output_gradient)
+        out = torch.zeros((1, g.shape[-1], a.shape[-1] + int(ones)), dtype=torch.float32, device=g.device)
+        self.accumulate_summed_gradient(out, g, a, ones, 1.0)
+        return out
+
+    @staticmethod
+    def accumulate_summed_gradient(total: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool, scale: float) -> None:
+        """``total[0] += scale * G^T [A, 1]`` over all ``b * R`` rows: one GEMM, depth ``b R``."""
+        g, a = g.contiguous(), a.contiguous()
+        rows = g.shape[0] * g.shape[1]
+        o, i = g.shape[-1], a.shape[-1]
+        ip = i + int(ones)
+        ops.gemm(total, ip, 0, ops.view(g, 0, 1, o, o, rows), ops.view(a, 0, 1, i, i, rows, ones_row=ones),
+                 alpha=scale, beta=1.0)
 
     def compute_self_measurement_score(self, preconditioned_gradient: torch.Tensor, input_activation: torch.Tensor,
                                        output_gradient: torch.Tensor) -> torch.Tensor:

@@ -19,11 +19,44 @@ from kronfluence_amd import ops
 from kronfluence_amd.module.tracker.base import BaseTracker
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
+    AGGREGATED_GRADIENT_NAME,
     ACTIVATION_EIGENVECTORS_NAME,
     GRADIENT_EIGENVECTORS_NAME,
     PAIRWISE_SCORE_MATRIX_NAME,
     PRECONDITIONED_GRADIENT_NAME,
 )
+
+
+DIMENSION_NOT_MATCH_ERROR_MSG = (
+    "The model does not support token-wise score computation. Set `compute_per_module_scores=True` or "
+    "`compute_per_token_scores=False` to avoid this error."
+)
+
+
+class ScoreSink:
+    """The fp32 score block of one train shard, resident in HBM and shared by the tracked layers that add into it:
+    ``[Q, N_shard]``, or ``[Q, N_shard, T]`` for per-token scores (``T`` is learnt from the first sequence layer)."""
+
+    def __init__(self, num_queries: int, shard_size: int, device: torch.device, per_token: bool = False) -> None:
+        self.num_queries, self.shard_size, self.device, self.per_token = num_queries, shard_size, device, per_token
+        self.tokens = None if per_token else 1
+        self._flat = None if per_token else torch.zeros((num_queries, shard_size), dtype=torch.float32, device=device)
+
+    def matrix(self, tokens: int = 1) -> torch.Tensor:
+        """2-D view ``[Q, N_shard * T]`` the kernels accumulate into (sample ``n``, token ``t`` -> column ``n T + t``)."""
+        if self.tokens is None:
+            self.tokens = tokens
+            self._flat = torch.zeros((self.num_queries, self.shard_size * tokens), dtype=torch.float32, device=self.device)
+        if tokens != self.tokens:
+            raise RuntimeError(DIMENSION_NOT_MATCH_ERROR_MSG)
+        return self._flat
+
+    def result(self) -> torch.Tensor:
+        if self._flat is None:
+            raise RuntimeError("No tracked layer contributed to the scores.")
+        if self.per_token and self.tokens != 1:
+            return self._flat.view(self.num_queries, self.shard_size, self.tokens)
+        return self._flat
 
 
 class PairwiseScoreTracker(BaseTracker):
@@ -59,8 +92,11 @@ class PairwiseScoreTracker(BaseTracker):
             if preconditioned.dtype not in (torch.float32, torch.bfloat16):
                 preconditioned = preconditioned.to(torch.float32)
             batch = output_gradient.shape[0]
+            per_token = module.score_args.compute_per_token_scores and activation.dim() == 3 and module.score_sink is not None
             if module.score_sink is not None:
-                scores, offset = module.score_sink
+                sink, offset = module.score_sink
+                tokens = activation.shape[1] if per_token else 1
+                scores, offset = sink.matrix(tokens), offset * tokens
             else:
                 scores = torch.zeros((preconditioned.shape[0], batch), dtype=torch.float32, device=output_gradient.device)
                 offset = 0
@@ -70,6 +106,8 @@ class PairwiseScoreTracker(BaseTracker):
                 storage[PAIRWISE_SCORE_MATRIX_NAME] = scores
             if module.per_sample_gradient_process_fnc is None:
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
+                if per_token:  # "qio,bti,bto->qbt" (linear.py:100-111): every token is a rank-one "sample"
+                    g, a = g.reshape(-1, 1, g.shape[-1]), a.reshape(-1, 1, a.shape[-1])
                 if module.queries_in_eigenbasis:  # see PreconditionTracker.EIGENBASIS_QUERIES
                     n = g.shape[0]
                     g = ops.matmul_nn(g.reshape(n, -1), storage[GRADIENT_EIGENVECTORS_NAME]).unsqueeze(1)
@@ -100,6 +138,32 @@ class PairwiseScoreTracker(BaseTracker):
 
     @torch.no_grad()
     def finalize_all_iterations(self) -> None:
+        """With ``aggregate_train_gradients`` the ``GradientTracker`` left the summed train gradient in storage:
+        its dot product with every held query gradient is column 0 of the sink (reference ``pairwise_score.py:119-133``)."""
+        module, storage = self.module, self.module.storage
+        summed = storage[AGGREGATED_GRADIENT_NAME]
+        if summed is not None and module.score_sink is not None:
+            preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
+            if preconditioned is None:
+                raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
+            preconditioned = preconditioned.contiguous()
+            if preconditioned.dtype != torch.float32:
+                preconditioned = ops.cast(preconditioned, torch.float32)
+            summed = summed.to(torch.float32).contiguous()
+            _, o, ip = summed.shape
+            if module.queries_in_eigenbasis:  # queries are held as M_q: rotate the summed gradient instead
+                q_a, q_g = storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
+                t1 = torch.empty((o, ip), dtype=torch.float32, device=summed.device)
+                ops.gemm(t1, ip, 0, ops.view(summed, 0, ip, 1, o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
+                rotated = torch.empty((1, o, ip), dtype=torch.float32, device=summed.device)
+                ops.gemm(rotated, ip, 0, ops.view(q_g, 0, 1, o, o, o), ops.view(t1, 0, 1, ip, ip, o))
+                summed = rotated
+            sink, offset = module.score_sink
+            scores = sink.matrix(1)
+            q = preconditioned.shape[0]
+            ops.gemm(scores[:, offset:offset + 1], scores.shape[1], 0, ops.view(preconditioned, 0, o * ip, 1, q, o * ip),
+                     ops.view(summed, 0, o * ip, 1, 1, o * ip), beta=1.0)
+            storage[AGGREGATED_GRADIENT_NAME] = None
         self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.module.score_sink = None

@@ -19,6 +19,7 @@ from kronfluence_amd.factor.config import FactorConfig
 from kronfluence_amd.module.tracker.base import BaseTracker
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
+    AGGREGATED_GRADIENT_NAME,
     ACTIVATION_EIGENVECTORS_NAME,
     GRADIENT_EIGENVECTORS_NAME,
     LAMBDA_MATRIX_NAME,
@@ -158,6 +159,21 @@ class PreconditionTracker(BaseTracker):
         storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
             new.contiguous() if held is None else torch.cat((held, new), dim=0).contiguous())
         storage[PRECONDITIONED_GRADIENT_NAME] = None
+
+    @torch.no_grad()
+    def finalize_all_iterations(self) -> None:
+        """``aggregate_query_gradients``: preconditions the summed query gradient held by the ``GradientTracker``
+        and makes it the (single-row) accumulated query gradient (reference ``precondition.py:242-255``)."""
+        storage = self.module.storage
+        summed = storage[AGGREGATED_GRADIENT_NAME]
+        if summed is None:
+            return
+        self.module.queries_in_eigenbasis = False
+        out = FactorConfig.CONFIGS[self.module.factor_args.strategy].precondition_gradient(
+            summed.to(torch.float32).contiguous(), storage)
+        storage[AGGREGATED_GRADIENT_NAME] = None
+        self._store(out if out is not summed else out.clone())
+        self.accumulate_iterations()
 
     def release_memory(self) -> None:
         self._bf16_q = None

@@ -16,10 +16,13 @@ from torch.utils import data
 
 from kronfluence_amd.arguments import FactorArguments, ScoreArguments
 from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
-from kronfluence_amd.module.utils import finalize_all_iterations, finalize_iteration, set_mode, set_score_sink
+from kronfluence_amd.module.tracker.pairwise_score import ScoreSink
+from kronfluence_amd.module.utils import (
+    finalize_all_iterations, finalize_iteration, set_mode, set_score_sink, synchronize_modules,
+)
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import (
-    ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, ALL_MODULE_NAME, SCORE_TYPE,
+    ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, AGGREGATED_GRADIENT_NAME, ALL_MODULE_NAME, SCORE_TYPE,
 )
 from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
 from kronfluence_amd.utils.state import State, no_sync
@@ -50,15 +53,15 @@ def compute_dot_products_with_loader(model: nn.Module, task: Task, state: State,
     dataset_size = len(train_loader.dataset)
 
     keys = [m.name for m in modules] if score_args.compute_per_module_scores else [ALL_MODULE_NAME]
-    buffers: Dict[str, torch.Tensor] = {
-        key: torch.zeros((num_queries, shard_size), dtype=torch.float32, device=state.device) for key in keys
+    sinks: Dict[str, ScoreSink] = {
+        key: ScoreSink(num_queries, shard_size, state.device, per_token=score_args.compute_per_token_scores) for key in keys
     }
     enable_amp = score_args.amp_dtype is not None
     offset = 0
     for batch in train_loader:
         batch = send_to_device(batch, state.device)
         for m in modules:
-            m.score_sink = (buffers[m.name if score_args.compute_per_module_scores else ALL_MODULE_NAME], offset)
+            m.score_sink = (sinks[m.name if score_args.compute_per_module_scores else ALL_MODULE_NAME], offset)
         with no_sync(model, state):
             model.zero_grad(set_to_none=True)
             with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
@@ -74,7 +77,50 @@ def compute_dot_products_with_loader(model: nn.Module, task: Task, state: State,
     set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=False)
 
     total_scores: SCORE_TYPE = {}
-    for key, block in buffers.items():
-        total_scores[key] = gather_score_blocks(block.to(score_args.score_dtype), state, dataset_size)
+    for key, sink in sinks.items():
+        total_scores[key] = gather_score_blocks(sink.result().to(score_args.score_dtype), state, dataset_size)
+    state.wait_for_everyone()
+    return total_scores
+
+
+def compute_aggregated_dot_products_with_loader(model: nn.Module, task: Task, state: State, train_loader: data.DataLoader,
+                                                factor_args: FactorArguments, score_args: ScoreArguments,
+                                                tracked_module_names: List[str], loss_scale: float = 1.0,
+                                                disable_tqdm: bool = False) -> SCORE_TYPE:
+    """``aggregate_train_gradients`` (reference ``score/dot_product.py:156-290``): the train pass only SUMS the
+    gradients (one GEMM per layer and batch, ``GradientTracker``), the ranks all-reduce the sums, and the scores are
+    one ``[Q, O I'] x [O I']`` product per layer -> ``[Q, 1]``."""
+    del disable_tqdm
+    model.zero_grad(set_to_none=True)
+    set_mode(model, ModuleMode.GRADIENT_AGGREGATION, tracked_module_names, release_memory=False)
+    modules = [m for m in model.modules() if isinstance(m, TrackedModule) and m.name in tracked_module_names]
+    num_queries = modules[0].storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME].shape[0]
+    enable_amp = score_args.amp_dtype is not None
+    if not all(m.exist() for m in modules):  # the summed train gradient is reused across query chunks
+        for batch in train_loader:
+            batch = send_to_device(batch, state.device)
+            with no_sync(model, state):
+                model.zero_grad(set_to_none=True)
+                with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                    loss = task.compute_train_loss(batch=batch, model=model, sample=False)
+                (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+            if factor_args.has_shared_parameters:
+                finalize_iteration(model, tracked_module_names)
+            del loss
+        if state.use_distributed:
+            synchronize_modules(model, tracked_module_names, num_processes=state.num_processes)
+    set_mode(model, ModuleMode.PAIRWISE_SCORE, tracked_module_names, release_memory=False)
+    keys = [m.name for m in modules] if score_args.compute_per_module_scores else [ALL_MODULE_NAME]
+    sinks = {key: ScoreSink(num_queries, 1, state.device) for key in keys}
+    for m in modules:
+        m.score_sink = (sinks[m.name if score_args.compute_per_module_scores else ALL_MODULE_NAME], 0)
+    held = {m.name: m.storage[AGGREGATED_GRADIENT_NAME] for m in modules}
+    finalize_all_iterations(model, tracked_module_names)  # scores from the summed gradient (PairwiseScoreTracker)
+    for m in modules:
+        m.storage[AGGREGATED_GRADIENT_NAME] = held[m.name]  # kept for the next query chunk
+    model.zero_grad(set_to_none=True)
+    set_score_sink(model, None, tracked_module_names)
+    set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=False)
+    total_scores: SCORE_TYPE = {key: sink.result().to(score_args.score_dtype).cpu() for key, sink in sinks.items()}
     state.wait_for_everyone()
     return total_scores

@@ -18,7 +18,9 @@ from kronfluence_amd.module.utils import (
     accumulate_iterations, finalize_all_iterations, finalize_iteration, get_tracked_module_names, prepare_modules,
     set_factors, set_gradient_scale, set_mode, synchronize_modules, truncate, update_factor_args, update_score_args,
 )
-from kronfluence_amd.score.dot_product import compute_dot_products_with_loader
+from kronfluence_amd.score.dot_product import (
+    compute_aggregated_dot_products_with_loader, compute_dot_products_with_loader,
+)
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import FACTOR_TYPE, SCORE_TYPE
 from kronfluence_amd.utils.dataset import send_to_device
@@ -91,9 +93,10 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
         held += 1
         if held < score_args.query_gradient_accumulation_steps and query_index != num_batches - 1:
             continue
-        scores = compute_dot_products_with_loader(model=model, state=state, task=task, train_loader=train_loader,
-                                                  factor_args=factor_args, score_args=score_args,
-                                                  tracked_module_names=tracked_module_names, loss_scale=scale)
+        dot_products = (compute_aggregated_dot_products_with_loader if score_args.aggregate_train_gradients
+                        else compute_dot_products_with_loader)
+        scores = dot_products(model=model, state=state, task=task, train_loader=train_loader, factor_args=factor_args,
+                              score_args=score_args, tracked_module_names=tracked_module_names, loss_scale=scale)
         if state.is_main_process:
             for key, value in scores.items():
                 chunks.setdefault(key, []).append(value)
@@ -110,6 +113,62 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
     set_mode(model, ModuleMode.DEFAULT, release_memory=True)
     state.wait_for_everyone()
     return total
+
+
+def _compute_pairwise_query_aggregated_scores_impl(loaded_factors: FACTOR_TYPE, model: nn.Module, state: State, task: Task,
+                                                   query_loader: data.DataLoader, per_device_query_batch_size: int,
+                                                   train_loader: data.DataLoader, score_args: ScoreArguments,
+                                                   factor_args: FactorArguments, tracked_module_names: Optional[List[str]],
+                                                   disable_tqdm: bool = False) -> SCORE_TYPE:
+    """``aggregate_query_gradients`` (reference ``score/pairwise.py:296-393``): the query pass sums the raw query
+    gradients (``GradientTracker``), the sum is preconditioned once, and a single train pass scores against it."""
+    del per_device_query_batch_size, disable_tqdm
+    flagged = unsupported_score_options(score_args)
+    if flagged:
+        raise NotImplementedError(
+            f"ScoreArguments options {flagged} are outside the MI355X pairwise hot path (SURVEY.md section 8f)."
+        )
+    update_factor_args(model, factor_args)
+    update_score_args(model, score_args)
+    if tracked_module_names is None:
+        tracked_module_names = get_tracked_module_names(model)
+    set_mode(model, ModuleMode.GRADIENT_AGGREGATION, tracked_module_names, release_memory=True)
+    for name in loaded_factors:
+        set_factors(model, name, loaded_factors[name], clone=True)
+    prepare_modules(model, tracked_module_names, state.device)
+    enable_amp = score_args.amp_dtype is not None
+    scale = _loss_scale(factor_args) if (enable_amp and factor_args.amp_dtype == torch.float16) else 1.0
+    if scale != 1.0:
+        set_gradient_scale(model, 1.0 / scale)
+    for query_batch in query_loader:
+        query_batch = send_to_device(query_batch, state.device)
+        with no_sync(model, state):
+            model.zero_grad(set_to_none=True)
+            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                measurement = task.compute_measurement(batch=query_batch, model=model)
+            (measurement * scale if scale != 1.0 else measurement).backward()
+        if factor_args.has_shared_parameters:
+            finalize_iteration(model, tracked_module_names)
+        del query_batch, measurement
+    if state.use_distributed:
+        synchronize_modules(model, tracked_module_names, num_processes=state.num_processes)
+    set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=False)
+    finalize_all_iterations(model, tracked_module_names)  # precondition the summed gradient -> one held query row
+    dot_products = (compute_aggregated_dot_products_with_loader if score_args.aggregate_train_gradients
+                    else compute_dot_products_with_loader)
+    scores = dot_products(model=model, state=state, task=task, train_loader=train_loader, factor_args=factor_args,
+                          score_args=score_args, tracked_module_names=tracked_module_names, loss_scale=scale)
+    model.zero_grad(set_to_none=True)
+    set_gradient_scale(model, 1.0)
+    set_mode(model, ModuleMode.DEFAULT, release_memory=True)
+    state.wait_for_everyone()
+    return scores if state.is_main_process else {}
+
+
+def compute_pairwise_query_aggregated_scores_with_loaders(*args, **kwargs) -> SCORE_TYPE:
+    """Stage entry point of the query-aggregated variant, cyclic GC paused."""
+    with paused_gc():
+        return _compute_pairwise_query_aggregated_scores_impl(*args, **kwargs)
 
 
 def compute_pairwise_scores_with_loaders(*args, **kwargs) -> SCORE_TYPE:

@@ -125,8 +125,11 @@ def test_mode_switch_registers_and_releases_hooks():
     assert all(len(m._forward_hooks) == 1 and m.current_mode == "lambda" for m in mods)
     set_mode(model, ModuleMode.DEFAULT)
     assert all(len(m._forward_hooks) == 0 for m in mods)
-    with pytest.raises(NotImplementedError):
-        set_mode(model, ModuleMode.SELF_SCORE)
+    for mode in (ModuleMode.SELF_SCORE, ModuleMode.SELF_MEASUREMENT_SCORE, ModuleMode.GRADIENT_AGGREGATION,
+                 ModuleMode.PRECONDITION_GRADIENT, ModuleMode.PAIRWISE_SCORE):
+        set_mode(model, mode)
+        assert all(len(m._forward_hooks) == 1 and m.current_mode == mode for m in mods)
+    set_mode(model, ModuleMode.DEFAULT)
     for m in mods:  # storage holds exactly the reference's keys
         assert set(m.storage) >= set(C.COVARIANCE_FACTOR_NAMES + C.EIGENDECOMPOSITION_FACTOR_NAMES + C.LAMBDA_FACTOR_NAMES)
 

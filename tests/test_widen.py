@@ -169,3 +169,59 @@ def test_self_scores_match_reference(kind, strategy, tmp_path, engine):
     measured = analyzer.compute_self_scores("self_m", "f", train, per_device_train_batch_size=spec.train_batch,
                                             score_args=ScoreArguments(damping_factor=None, use_measurement_for_self_influence=True))
     assert rel(measured["all_modules"], gold["self_measurement"]) <= tol, rel(measured["all_modules"], gold["self_measurement"])
+
+
+# ---- 8(f)-4: per-module / per-token scores, query / train gradient aggregation ------------------------------------
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_score_reductions_match_reference(kind, tmp_path, engine):
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    gold = _widen(kind)
+    spec, analyzer, train, query = build(kind, tmp_path)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(use_empirical_fisher=True))
+    common = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
+    tol = _tol(engine, 1e-5, 5e-4)
+
+    def run(name, **kw):
+        return analyzer.compute_pairwise_scores(name, "f", query, train, score_args=ScoreArguments(damping_factor=None, **kw),
+                                                **common)
+
+    def agg_err(got, tag):
+        """Aggregated scores are sums with cancellation: error relative to the norm of what was summed."""
+        pairwise = gold["strategy/ekfac/scores"].double()
+        dims = {"aggq": (0,), "aggt": (1,), "aggqt": (0, 1)}[tag]
+        scale = pairwise.abs().sum(dim=dims, keepdim=True)
+        return float(((got.double() - gold[tag].double()).abs() / scale).max())
+
+    per_module = run("pm", compute_per_module_scores=True)
+    wanted = {k.split("/", 1)[1]: v for k, v in gold.items() if k.startswith("permodule/")}
+    assert set(per_module) == set(wanted)
+    for module, want in wanted.items():
+        assert rel(per_module[module], want) <= tol, (module, rel(per_module[module], want))
+    for tag, kw in (("aggq", dict(aggregate_query_gradients=True)), ("aggt", dict(aggregate_train_gradients=True)),
+                    ("aggqt", dict(aggregate_query_gradients=True, aggregate_train_gradients=True))):
+        got = run(tag, **kw)["all_modules"]
+        assert got.shape == gold[tag].shape, (tag, got.shape)
+        assert agg_err(got, tag) <= tol, (tag, agg_err(got, tag))
+    # train aggregation adds over data partitions (score_computer.py:122-124)
+    got = run("aggt_parts", aggregate_train_gradients=True, data_partitions=2)["all_modules"]
+    assert agg_err(got, "aggt") <= tol
+    if kind == "seq":
+        got = run("tok", compute_per_token_scores=True)["all_modules"]
+        assert got.shape == gold["pertoken"].shape
+        assert rel(got, gold["pertoken"]) <= tol, rel(got, gold["pertoken"])
+        assert rel(got.sum(-1), gold["strategy/ekfac/scores"]) <= tol
+
+
+def test_score_sink_refuses_mixed_token_axes():
+    """A block that first receives a token-less layer and then a sequence layer must refuse, as the reference's
+    ``add_`` does (score/dot_product.py:33-36, 114-116)."""
+    from kronfluence_amd.module.tracker.pairwise_score import ScoreSink
+
+    sink = ScoreSink(2, 4, torch.device("cpu"), per_token=True)
+    assert sink.matrix(1).shape == (2, 4)
+    with pytest.raises(RuntimeError, match="token-wise"):
+        sink.matrix(6)
+    sink = ScoreSink(2, 4, torch.device("cpu"), per_token=True)
+    assert sink.matrix(6).shape == (2, 24) and sink.result().shape == (2, 4, 6)
