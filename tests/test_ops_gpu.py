@@ -353,3 +353,63 @@ def test_precondition_bf16_back_rotation(ops, q, r, o, i):
     got = ops.precondition(g.to(DEV), a.to(DEV), False, qg_d, qa_d, lam_inv.float().to(DEV), out_dtype=torch.bfloat16,
                            q_a_bf16=qa_d.to(torch.bfloat16).contiguous(), q_g_t_bf16=qg_d.t().contiguous().to(torch.bfloat16))
     assert got.dtype == torch.bfloat16 and rel(got, want) <= 1.5e-2
+
+
+# ---- SURVEY.md 8(f) kernels: row-wise weighted dots, broadcast product, squared-operand GEMM ---------------------
+@pytest.mark.parametrize("rows,d", [(1, 1), (5, 37), (48, 16 * 17), (3, 1 << 20), (1000, 1024 * 8), (7, 4096 + 8)])
+@pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
+                                     (torch.float32, torch.bfloat16), (torch.bfloat16, torch.bfloat16)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_rowwise_dot(ops, rows, d, xdt, ydt, weighted):
+    x, y = _rand(rows, d, dtype=xdt, seed=1), _rand(rows, d, dtype=ydt, seed=2)
+    w = _rand(d, seed=3).abs() if weighted else None
+    prod = x.double() * y.double() * (w.double() if weighted else 1.0)
+    want = 0.5 * prod.sum(1)
+    bound = 0.5 * prod.abs().sum(1)  # fp32 accumulation: error relative to the sum of magnitudes
+    out = torch.full((rows,), 3.0, device=DEV)
+    ops.rowwise_dot(out, x.to(DEV), y.to(DEV), None if w is None else w.to(DEV), scale=0.5, accumulate=True)
+    assert float(((out.double().cpu() - 3.0 - want).abs() / bound.clamp(min=1e-30)).max()) <= 2e-6
+    ops.rowwise_dot(out, x.to(DEV), y.to(DEV), None if w is None else w.to(DEV), scale=0.5, accumulate=False)
+    assert float(((out.double().cpu() - want).abs() / bound.clamp(min=1e-30)).max()) <= 2e-6
+
+
+def test_rowwise_dot_unaligned_views(ops):
+    """Row slices that start off a 16-byte boundary take the scalar path."""
+    base_x, base_y = _rand(4 * 64 + 1, seed=4).to(DEV), _rand(4 * 64 + 1, seed=5).to(DEV)
+    x, y = base_x[1:].view(4, 64), base_y[1:].view(4, 64)
+    out = torch.zeros(4, device=DEV)
+    ops.rowwise_dot(out, x, y, None, accumulate=False)
+    assert rel(out, (x.double() * y.double()).sum(1)) <= 1e-6
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_mul_bcast(ops, dtype):
+    x, m = _rand(9, 6, 11, dtype=dtype, seed=1), _rand(6, 11, seed=2)
+    got = ops.mul_bcast(x.to(DEV), m.to(DEV), scale=0.25)
+    assert got.dtype == torch.float32 and rel(got, 0.25 * x.double() * m.double()) <= 1e-6
+
+
+@pytest.mark.parametrize("b,n", [(1, 5), (13, 16 * 17), (300, 1025 * 3)])
+def test_gemm_squared_operand_batch_reduction(ops, b, n):
+    """``C[0, n] = beta C + alpha sum_b x[b, n]^2``: the Lambda update on a materialised gradient."""
+    x = _rand(b, n, seed=7)
+    c0 = _rand(1, n, seed=8)
+    c = c0.clone().to(DEV)
+    ones = torch.ones(b, device=DEV)
+    xd = x.to(DEV)
+    ops.gemm(c, n, 0, ops.view(ones, 0, 0, 1, 1, b), ops.view(xd, 0, 1, n, n, b, square=True), alpha=0.5, beta=1.0)
+    assert rel(c, c0.double() + 0.5 * (x.double() ** 2).sum(0, keepdim=True)) <= TOL
+
+
+def test_summed_gradient_gemm(ops):
+    """``total += scale * G^T [A, 1]`` over all b*R rows (GradientTracker)."""
+    from kronfluence_amd.module.tracked_module import TrackedModule
+
+    b, r, o, i = 5, 7, 12, 9
+    g, a = _rand(b, r, o, seed=1), _rand(b, r, i, seed=2)
+    total = torch.zeros(1, o, i + 1, device=DEV)
+    for _ in range(2):
+        TrackedModule.accumulate_summed_gradient(total, g.to(DEV), a.to(DEV), True, 0.5)
+    a1 = torch.cat([a, torch.ones(b, r, 1)], dim=-1).double()
+    want = torch.einsum("bro,bri->oi", g.double(), a1)
+    assert rel(total[0], want) <= TOL
