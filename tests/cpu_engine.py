@@ -156,6 +156,19 @@ LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "lambda
           "pairwise_score", "rowwise_dot", "mul_bcast", "cast")
 
 
+class _Setter:
+    """Minimal stand-in for pytest's monkeypatch in spawned worker processes (they exit afterwards)."""
+
+    @staticmethod
+    def setattr(obj, name, value, raising=True):
+        del raising
+        setattr(obj, name, value)
+
+
+def install_in_worker() -> None:
+    install(_Setter())
+
+
 def install(monkeypatch) -> None:
     """Patch the leaf operators and the GPU guards (call from a fixture)."""
     from kronfluence_amd import analyzer, ops

@@ -144,3 +144,79 @@ def test_score_block_gather_concatenates_in_dataset_order(tmp_path):
     got = torch.load(os.path.join(tmp_path, "rank0.pt"))
     want = torch.tensor([[100.0 * qi + t for t in range(7)] for qi in range(3)])
     assert torch.equal(got, want)
+
+
+# ---- whole stages on 2 ranks (host logic; HIP leaf operators replaced by tests/cpu_engine.py) -------------------
+def _pipeline_two_ranks(rank, world, out_dir):
+    import cpu_engine
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments
+    from test_pipeline_gpu import make_task
+    from kronfluence_amd import prepare_model
+
+    cpu_engine.install_in_worker()
+    kind = "seq"
+    spec = fx.FIXTURES[kind]
+    task = make_task(kind)
+    model = prepare_model(fx.make_model(kind), task)
+    analyzer = Analyzer("t", model, task, output_dir=out_dir, disable_tqdm=True)
+    assert analyzer.state.num_processes == world and analyzer.state.process_index == rank
+    train = data.TensorDataset(*fx.make_data(kind, spec.n_train - 1, seed=1))  # odd size: uneven shards, padding
+    query = data.TensorDataset(*fx.make_data(kind, spec.n_query - 1, seed=2))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=7, factor_args=FactorArguments(use_empirical_fisher=True))
+    common = dict(per_device_query_batch_size=2, per_device_train_batch_size=5)
+    results = {}
+    for name, kw in (("plain", {}), ("aggq", dict(aggregate_query_gradients=True)),
+                     ("aggt", dict(aggregate_train_gradients=True)), ("tok", dict(compute_per_token_scores=True)),
+                     ("parts", dict(data_partitions=2, module_partitions=2))):
+        out = analyzer.compute_pairwise_scores(name, "f", query, train, score_args=ScoreArguments(damping_factor=None, **kw),
+                                               **common)
+        if rank == 0:
+            results[name] = out["all_modules"]
+        else:
+            assert out is None
+    for name, kw in (("self", {}), ("selfm", dict(use_measurement_for_self_influence=True))):
+        out = analyzer.compute_self_scores(name, "f", train, per_device_train_batch_size=5,
+                                           score_args=ScoreArguments(damping_factor=None, **kw))
+        if rank == 0:
+            results[name] = out["all_modules"]
+    if rank == 0:
+        torch.save(results, os.path.join(out_dir, "two_ranks.pt"))
+
+
+def test_whole_stages_on_two_ranks_match_single_process(tmp_path, cpu_engine):
+    """Sharded factor fit + all-reduce, query all-gather / interleave / truncate, score-block gather, summed-gradient
+    all-reduce and self-score gather reproduce the single-process results (uneven shard sizes)."""
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from test_pipeline_gpu import make_task
+
+    _run("_pipeline_two_ranks", tmp_path / "two")
+    got = torch.load(tmp_path / "two" / "two_ranks.pt")
+    kind = "seq"
+    spec = fx.FIXTURES[kind]
+    task = make_task(kind)
+    analyzer = Analyzer("t", prepare_model(fx.make_model(kind), task), task, output_dir=str(tmp_path / "one"), disable_tqdm=True)
+    train = data.TensorDataset(*fx.make_data(kind, spec.n_train - 1, seed=1))
+    query = data.TensorDataset(*fx.make_data(kind, spec.n_query - 1, seed=2))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=7, factor_args=FactorArguments(use_empirical_fisher=True))
+    common = dict(per_device_query_batch_size=2, per_device_train_batch_size=5)
+
+    def close(a, b, tol=2e-5):
+        a, b = a.double(), b.double()
+        return a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) <= tol
+
+    plain = analyzer.compute_pairwise_scores("plain", "f", query, train, score_args=ScoreArguments(damping_factor=None), **common)["all_modules"]
+    assert close(got["plain"], plain) and close(got["parts"], plain)
+    assert plain.shape == (spec.n_query - 1, spec.n_train - 1)
+    for name, kw in (("aggq", dict(aggregate_query_gradients=True)), ("aggt", dict(aggregate_train_gradients=True)),
+                     ("tok", dict(compute_per_token_scores=True))):
+        want = analyzer.compute_pairwise_scores(name, "f", query, train, score_args=ScoreArguments(damping_factor=None, **kw),
+                                                **common)["all_modules"]
+        assert close(got[name], want, 1e-4), name
+    for name, kw in (("self", {}), ("selfm", dict(use_measurement_for_self_influence=True))):
+        want = analyzer.compute_self_scores(name, "f", train, per_device_train_batch_size=5,
+                                            score_args=ScoreArguments(damping_factor=None, **kw))["all_modules"]
+        assert close(got[name], want), name
