@@ -150,6 +150,17 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
                 void* stream);
 
 /*
+ * Batched eigendecomposition of small symmetric matrices (l <= 96), one workgroup per matrix, all in LDS:
+ * G[batch,l,l] fp32 -> evals[batch,l] DESCENDING, evecs[batch,l,l] row-major with eigenvectors in columns in
+ * the same order.  inv_sqrt != 0 scales column j by 1/sqrt(max(lambda_j, floor_rel * lambda_max)): with G = Y^T Y
+ * that makes Y * evecs an orthonormal basis of range(Y) (symmetric orthogonalisation).  Building block of the
+ * low-rank query factorisation (module/tracker/precondition.py:19-75: torch.linalg.svd / torch.svd_lowrank).
+ * max_sweeps <= 0 selects the default (60).  Does not synchronise.
+ */
+int kf_eigh_small_batched(const float* G, int64_t batch, int l, float* evals, float* evecs, int inv_sqrt,
+                          float floor_rel, int max_sweeps, void* stream);
+
+/*
  * Lambda[O,I'] += sum_b ( sum_r Gt[b,r,o] * At[b,r,i] )^2
  * where Gt = G Qg and At = [A,1] Qa are the factors of the per-sample gradient already rotated
  * into the eigenbasis (two kf_gemm calls).  Identical mathematics to

@@ -58,6 +58,7 @@ SIGNATURES = {
     "kf_precondition": (_i, [_p, _i, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _f, _p, _p, _p, _i64, _p]),
     "kf_pairwise_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "kf_pairwise_score": (_i, [_p, _i64, _p, _i, _i64, _i64, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
+    "kf_eigh_small_batched": (_i, [_p, _i64, _i, _p, _p, _i, _f, _i, _p]),
     "kf_rowwise_dot": (_i, [_p, _p, _i, _p, _i, _p, _i64, _i64, _f, _i, _p]),
     "kf_mul_bcast": (_i, [_p, _p, _i, _p, _i64, _i64, _f, _p]),
     "kf_cast": (_i, [_p, _i, _p, _i, _i64, _p]),

@@ -527,6 +527,13 @@ class Analyzer:
         if self_scores_exist(out) and not overwrite_output_dir:
             return self.load_self_scores(scores_name)
         factor_args = self._stored_factor_args(factors_name)
+        if (score_args.query_gradient_low_rank is not None or score_args.aggregate_query_gradients
+                or score_args.aggregate_train_gradients or score_args.compute_per_token_scores):
+            # reference score_computer.py:620-640: these options do not apply to self-influence and are switched off
+            self.logger.warning("Low-rank queries, gradient aggregation and token-wise scores do not apply to "
+                                "self-influence; disabling them.")
+            score_args = dataclasses.replace(score_args, query_gradient_low_rank=None, aggregate_query_gradients=False,
+                                             aggregate_train_gradients=False, compute_per_token_scores=False)
         self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
         loaded = self.load_all_factors(factors_name)
         params = (dataloader_kwargs or self._dataloader_params).to_dict()

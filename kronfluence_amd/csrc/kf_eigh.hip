@@ -137,6 +137,103 @@ __global__ void scatter_vectors_kernel(double* evecs, const double* Vt, const in
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Batched small symmetric eigensolver, one workgroup per matrix, everything in LDS (l <= 96).
+// Used by the low-rank query factorisation (module/tracker/precondition.py:19-75 of the reference,
+// torch.linalg.svd / svd_lowrank there): the l x l Gram matrices of the randomised range finder.
+// Same one-sided Jacobi as above -- W = G V kept in fp64, tournament rounds, 8 lanes per column
+// pair -- but a round is a __syncthreads() instead of a kernel launch.
+// ------------------------------------------------------------------------------------------------
+constexpr int SMALL_MAX = 96;
+
+__global__ __launch_bounds__(256) void eigh_small_kernel(const float* G, int l, float* evals, float* evecs, int inv_sqrt,
+                                                         float floor_rel, int max_sweeps) {
+    extern __shared__ double lds[];
+    const int ld = l | 1;
+    double* W = lds;
+    double* V = W + l * ld;
+    double* lam = V + l * ld;
+    int* rank = reinterpret_cast<int*>(lam + l);
+    __shared__ double red[4];
+    __shared__ double lam_max;
+    const int tid = threadIdx.x, grp = tid >> 3, sub = tid & 7;
+    const float* g = G + static_cast<int64_t>(blockIdx.x) * l * l;
+    double f2 = 0.0;
+    for (int e = tid; e < l * l; e += 256) {
+        const int j = e / l, i = e % l;
+        const double x = 0.5 * (static_cast<double>(g[j * l + i]) + static_cast<double>(g[i * l + j]));
+        W[j * ld + i] = x;
+        V[j * ld + i] = (i == j) ? 1.0 : 0.0;
+        f2 += x * x;
+    }
+    f2 = block_sum(f2, red);
+    const double eps = 2.220446049250313e-16;
+    const double null2 = f2 * eps * eps * l, tol = 4.0 * eps * sqrt(static_cast<double>(l));
+    const int npl = l + (l & 1), pairs = npl / 2, m = npl - 1;
+    __syncthreads();
+    for (int sweep = 0; sweep < max_sweeps && l > 1; ++sweep) {
+        int rotated = 0;
+        for (int round = 0; round < m; ++round) {
+            for (int k = grp; k < pairs; k += 32) {
+                int p, q;
+                if (k == 0) { p = round % m; q = m; }
+                else { p = (round + k) % m; q = (round - k + m) % m; }
+                const bool live = p < l && q < l;  // the bye of an odd l
+                double a = 0.0, b = 0.0, c = 0.0;
+                if (live)
+                    for (int i = sub; i < l; i += 8) {
+                        const double x = W[p * ld + i], y = W[q * ld + i];
+                        a += x * x; b += y * y; c += x * y;
+                    }
+                for (int off = 1; off < 8; off <<= 1) {
+                    a += __shfl_xor(a, off); b += __shfl_xor(b, off); c += __shfl_xor(c, off);
+                }
+                if (live && fabs(c) > tol * sqrt(a) * sqrt(b) && a > null2 && b > null2) {
+                    const double zeta = (b - a) / (2.0 * c);
+                    const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                    const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                    for (int i = sub; i < l; i += 8) {
+                        const double x = W[p * ld + i], y = W[q * ld + i];
+                        W[p * ld + i] = cs * x - sn * y; W[q * ld + i] = sn * x + cs * y;
+                        const double u = V[p * ld + i], v = V[q * ld + i];
+                        V[p * ld + i] = cs * u - sn * v; V[q * ld + i] = sn * u + cs * v;
+                    }
+                    rotated = 1;
+                }
+            }
+            __syncthreads();
+        }
+        if (!__syncthreads_or(rotated)) break;
+    }
+    for (int j = grp; j < l; j += 32) {  // Rayleigh quotients
+        double r = 0.0;
+        for (int i = sub; i < l; i += 8) r += V[j * ld + i] * W[j * ld + i];
+        for (int off = 1; off < 8; off <<= 1) r += __shfl_xor(r, off);
+        if (sub == 0) lam[j] = r;
+    }
+    __syncthreads();
+    if (tid < l) {  // descending order
+        const double x = lam[tid];
+        int r = 0;
+        for (int k = 0; k < l; ++k) r += (lam[k] > x || (lam[k] == x && k < tid)) ? 1 : 0;
+        rank[tid] = r;
+        if (r == 0) lam_max = x;
+        evals[static_cast<int64_t>(blockIdx.x) * l + r] = static_cast<float>(x);
+    }
+    __syncthreads();
+    float* out = evecs + static_cast<int64_t>(blockIdx.x) * l * l;
+    const double floor_value = static_cast<double>(floor_rel) * fmax(lam_max, 0.0);
+    for (int e = tid; e < l * l; e += 256) {
+        const int j = e / l, i = e % l;
+        double scale = 1.0;
+        if (inv_sqrt) {
+            const double x = fmax(lam[j], floor_value);
+            scale = x > 0.0 ? 1.0 / sqrt(x) : 0.0;
+        }
+        out[i * l + rank[j]] = static_cast<float>(V[j * ld + i] * scale);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -194,6 +291,36 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
     hipLaunchKernelGGL(scatter_vectors_kernel, dim3(t, t), dim3(32, 8), 0, st, evecs, Vt, rank, d);
     if (hipGetLastError() != hipSuccess) return KF_ERR_LAUNCH_FAILED;
     return status;
+}
+
+int kf_eigh_small_batched(const float* G, int64_t batch, int l, float* evals, float* evecs, int inv_sqrt, float floor_rel,
+                          int max_sweeps, void* stream) {
+    if (!G || !evals || !evecs || batch < 0 || l <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (l > SMALL_MAX) return KF_ERR_INVALID_ARGUMENT;
+    if (batch == 0) return KF_OK;
+    if (max_sweeps <= 0) max_sweeps = 60;
+    const int ld = l | 1;
+    const size_t bytes = sizeof(double) * (2 * static_cast<size_t>(l) * ld + l) + sizeof(int) * l + 16;
+    static bool configured = false;
+    if (!configured) {
+        const int ld_max = SMALL_MAX | 1;
+        const size_t max_bytes = sizeof(double) * (2 * static_cast<size_t>(SMALL_MAX) * ld_max + SMALL_MAX) + sizeof(int) * SMALL_MAX + 16;
+        const hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_small_kernel),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(max_bytes));
+        if (err != hipSuccess) {
+            fprintf(stderr, "[kf_eigh_small] hipFuncSetAttribute(%zu): %s\n", max_bytes, hipGetErrorString(err));
+            return KF_ERR_LAUNCH_FAILED;
+        }
+        configured = true;
+    }
+    hipLaunchKernelGGL(eigh_small_kernel, dim3(static_cast<unsigned>(batch)), dim3(256), bytes,
+                       reinterpret_cast<hipStream_t>(stream), G, l, evals, evecs, inv_sqrt, floor_rel, max_sweeps);
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) {
+        fprintf(stderr, "[kf_eigh_small] launch (l=%d, lds=%zu): %s\n", l, bytes, hipGetErrorString(err));
+        return KF_ERR_LAUNCH_FAILED;
+    }
+    return KF_OK;
 }
 
 }  // extern "C"

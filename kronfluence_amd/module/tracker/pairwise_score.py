@@ -59,7 +59,42 @@ class ScoreSink:
         return self._flat
 
 
+# Low-rank query gradients are expanded to dense [q, O, I'] blocks just ahead of the score GEMM, this many bytes
+# (fp32) at a time; if ALL held queries of a layer fit, the expansion is done once per train pass and cached.
+LOW_RANK_EXPANSION_BYTES = 4 << 30
+
+
+def dense_queries(preconditioned, score_dtype: torch.dtype = torch.float32) -> torch.Tensor:
+    """The held query gradients as one dense ``[Q, O, I']`` tensor (expands low-rank factors)."""
+    if isinstance(preconditioned, list):
+        dense = ops.low_rank_product(preconditioned[0], preconditioned[1])
+        return ops.cast(dense, torch.bfloat16) if score_dtype == torch.bfloat16 else dense
+    if preconditioned.dtype not in (torch.float32, torch.bfloat16):
+        return preconditioned.to(torch.float32)
+    return preconditioned
+
+
 class PairwiseScoreTracker(BaseTracker):
+    _expanded = None  # (left factor, dense tensor): per-pass cache of expanded low-rank queries
+
+    def _query_blocks(self, preconditioned):
+        """Yields ``(first_row, dense [q_c, O, I'])`` covering the held queries."""
+        if not isinstance(preconditioned, list):
+            yield 0, dense_queries(preconditioned)
+            return
+        left, right = preconditioned
+        score_dtype = left.dtype if left.dtype == torch.bfloat16 else torch.float32
+        q, o, ip = left.shape[0], left.shape[1], right.shape[2]
+        per_query = o * ip * 4
+        if q * per_query <= LOW_RANK_EXPANSION_BYTES:
+            if self._expanded is None or self._expanded[0] is not left:
+                self._expanded = (left, dense_queries(preconditioned, score_dtype))
+            yield 0, self._expanded[1]
+            return
+        step = max(1, LOW_RANK_EXPANSION_BYTES // per_query)
+        for start in range(0, q, step):
+            yield start, dense_queries([left[start:start + step], right[start:start + step]], score_dtype)
+
     _tiled = None  # (source tensor, k-tile-major bf16 copy) of the held query gradients
 
     def _tiled_queries(self, preconditioned: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool):
@@ -89,8 +124,7 @@ class PairwiseScoreTracker(BaseTracker):
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
-            if preconditioned.dtype not in (torch.float32, torch.bfloat16):
-                preconditioned = preconditioned.to(torch.float32)
+            num_queries = preconditioned[0].shape[0] if isinstance(preconditioned, list) else preconditioned.shape[0]
             batch = output_gradient.shape[0]
             per_token = module.score_args.compute_per_token_scores and activation.dim() == 3 and module.score_sink is not None
             if module.score_sink is not None:
@@ -98,7 +132,7 @@ class PairwiseScoreTracker(BaseTracker):
                 tokens = activation.shape[1] if per_token else 1
                 scores, offset = sink.matrix(tokens), offset * tokens
             else:
-                scores = torch.zeros((preconditioned.shape[0], batch), dtype=torch.float32, device=output_gradient.device)
+                scores = torch.zeros((num_queries, batch), dtype=torch.float32, device=output_gradient.device)
                 offset = 0
                 accumulate_into = storage[PAIRWISE_SCORE_MATRIX_NAME] if module.factor_args.has_shared_parameters else None
                 if accumulate_into is not None and accumulate_into.shape == scores.shape:
@@ -113,17 +147,20 @@ class PairwiseScoreTracker(BaseTracker):
                     g = ops.matmul_nn(g.reshape(n, -1), storage[GRADIENT_EIGENVECTORS_NAME]).unsqueeze(1)
                     a = ops.matmul_nn(a.reshape(n, -1), storage[ACTIVATION_EIGENVECTORS_NAME], append_ones=ones).unsqueeze(1)
                     ones = False
-                ops.pairwise_score(scores, offset, preconditioned, g, a, ones, scale=module.gradient_scale,
-                                   p_tiled=self._tiled_queries(preconditioned, g, a, ones))
+                for first, block in self._query_blocks(preconditioned):
+                    rows = scores[first:first + block.shape[0]]
+                    ops.pairwise_score(rows, offset, block, g, a, ones, scale=module.gradient_scale,
+                                       p_tiled=self._tiled_queries(block, g, a, ones))
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()
-                preconditioned = preconditioned.to(torch.float32)
                 b, o, ip = psg.shape
-                q = preconditioned.shape[0]
-                ops.gemm(scores[:, offset:offset + b], scores.shape[1], 0,
-                         ops.view(preconditioned.contiguous(), 0, o * ip, 1, q, o * ip),
-                         ops.view(psg, 0, o * ip, 1, b, o * ip), alpha=module.gradient_scale, beta=1.0)
+                for first, block in self._query_blocks(preconditioned):
+                    block = block if block.dtype == torch.float32 else ops.cast(block, torch.float32)
+                    q = block.shape[0]
+                    ops.gemm(scores[first:first + q, offset:offset + b], scores.shape[1], 0,
+                             ops.view(block.contiguous(), 0, o * ip, 1, q, o * ip),
+                             ops.view(psg, 0, o * ip, 1, b, o * ip), alpha=module.gradient_scale, beta=1.0)
 
         self.registered_hooks.append(module.register_forward_hook(forward_hook))
 
@@ -146,7 +183,7 @@ class PairwiseScoreTracker(BaseTracker):
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
-            preconditioned = preconditioned.contiguous()
+            preconditioned = dense_queries(preconditioned).contiguous()
             if preconditioned.dtype != torch.float32:
                 preconditioned = ops.cast(preconditioned, torch.float32)
             summed = summed.to(torch.float32).contiguous()
@@ -168,6 +205,7 @@ class PairwiseScoreTracker(BaseTracker):
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.module.score_sink = None
         self._tiled = None
+        self._expanded = None
         self.clear_all_cache()
 
     def release_memory(self) -> None:

@@ -2,8 +2,7 @@
 
 The hook hands the query batch's activation / output-gradient factors to ``kf_precondition``
 (per-sample gradient + EK-FAC preconditioner + scale in one call chain on the MFMA engine); results
-stay resident in HBM in fp32.  Low-rank query batching (``query_gradient_low_rank``) is a
-"next" row and is rejected up front by the score stage.
+stay resident in HBM.  With ``query_gradient_low_rank`` only rank-k factors are kept.
 """
 
 from __future__ import annotations
@@ -57,6 +56,18 @@ class PreconditionTracker(BaseTracker):
         return self._bf16_q[1], self._bf16_q[2]
 
     def _store(self, preconditioned: torch.Tensor) -> None:
+        """Keeps the ``[q, O, I']`` block, or -- with ``query_gradient_low_rank = k < min(O, I')`` -- its rank-k factors
+        ``[left [q,O,k], right [q,k,I']]`` (reference ``precondition.py:19-75``; ``use_full_svd`` buys two more
+        subspace iterations instead of a dense SVD)."""
+        args = self.module.score_args
+        rank = args.query_gradient_low_rank
+        if rank is not None and min(preconditioned.shape[1:]) > rank:
+            dense = preconditioned if preconditioned.dtype == torch.float32 else ops.cast(preconditioned, torch.float32)
+            left, right = ops.low_rank_factors(dense, rank, power_iterations=4 if args.use_full_svd else 2)
+            if self._out_dtype() != torch.float32:
+                left, right = ops.cast(left, self._out_dtype()), ops.cast(right, self._out_dtype())
+            self.module.storage[PRECONDITIONED_GRADIENT_NAME] = [left, right]
+            return
         if preconditioned.dtype != self._out_dtype():
             preconditioned = preconditioned.to(self._out_dtype())
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = preconditioned
@@ -131,33 +142,48 @@ class PreconditionTracker(BaseTracker):
         return (storage[PRECONDITIONED_GRADIENT_NAME] is not None
                 or storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] is not None)
 
-    def synchronize(self, num_processes: int = 1) -> None:
-        """C4: all-gather the ``[q, O, I']`` block of every rank and interleave so that row
-        ``j * P + r`` is rank ``r``'s ``j``-th query -- the dataset order of a strided
-        ``DistributedSampler`` (reference ``precondition.py:181-201``)."""
-        storage = self.module.storage
-        local = storage[PRECONDITIONED_GRADIENT_NAME]
-        if not dist.is_initialized() or local is None:
-            return
+    @staticmethod
+    def _gather_interleaved(local: torch.Tensor, num_processes: int) -> torch.Tensor:
         local = local.contiguous()
         q = local.shape[0]
         gathered = torch.empty((num_processes * q,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         dist.all_gather_into_tensor(gathered, local)  # rank-major concatenation (layout both RCCL and gloo accept)
         stacked = gathered.reshape((num_processes, q) + tuple(local.shape[1:]))
-        storage[PRECONDITIONED_GRADIENT_NAME] = stacked.transpose(0, 1).reshape(
-            num_processes * q, local.shape[1], local.shape[2])
+        return stacked.transpose(0, 1).reshape((num_processes * q,) + tuple(local.shape[1:]))
+
+    def synchronize(self, num_processes: int = 1) -> None:
+        """C4: all-gather the ``[q, O, I']`` block (or both low-rank factors) of every rank and interleave so that
+        row ``j * P + r`` is rank ``r``'s ``j``-th query -- the dataset order of a strided ``DistributedSampler``
+        (reference ``precondition.py:181-201``)."""
+        storage = self.module.storage
+        local = storage[PRECONDITIONED_GRADIENT_NAME]
+        if not dist.is_initialized() or local is None:
+            return
+        if isinstance(local, list):
+            storage[PRECONDITIONED_GRADIENT_NAME] = [self._gather_interleaved(t, num_processes) for t in local]
+        else:
+            storage[PRECONDITIONED_GRADIENT_NAME] = self._gather_interleaved(local, num_processes)
 
     def truncate(self, keep_size: int) -> None:
         storage = self.module.storage
-        storage[PRECONDITIONED_GRADIENT_NAME] = storage[PRECONDITIONED_GRADIENT_NAME][:keep_size].clone()
+        held = storage[PRECONDITIONED_GRADIENT_NAME]
+        if isinstance(held, list):
+            storage[PRECONDITIONED_GRADIENT_NAME] = [t[:keep_size].clone() for t in held]
+        else:
+            storage[PRECONDITIONED_GRADIENT_NAME] = held[:keep_size].clone()
 
     def accumulate_iterations(self) -> None:
         storage = self.module.storage
         held, new = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME], storage[PRECONDITIONED_GRADIENT_NAME]
         if new is None:
             return
-        storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
-            new.contiguous() if held is None else torch.cat((held, new), dim=0).contiguous())
+        if isinstance(new, list):
+            storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
+                [t.contiguous() for t in new] if held is None
+                else [torch.cat((h, t), dim=0).contiguous() for h, t in zip(held, new)])
+        else:
+            storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
+                new.contiguous() if held is None else torch.cat((held, new), dim=0).contiguous())
         storage[PRECONDITIONED_GRADIENT_NAME] = None
 
     @torch.no_grad()

@@ -229,6 +229,87 @@ def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0) -> Tuple[torch.Te
     return evals, evecs, sweeps.value
 
 
+EIGH_SMALL_MAX = 96
+
+
+def eigh_small(g: torch.Tensor, inv_sqrt: bool = False, floor_rel: float = 1e-12) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Batched eigendecomposition of ``[batch, l, l]`` fp32 symmetric matrices, ``l <= 96`` (kf_eigh_small_batched):
+    eigenvalues DESCENDING, eigenvectors in columns; ``inv_sqrt`` scales column j by ``1/sqrt(lambda_j)``."""
+    nat.require_device(g, "g")
+    g = _contig(g)
+    batch, l, l2 = g.shape
+    assert g.dtype == torch.float32 and l == l2 and l <= EIGH_SMALL_MAX
+    evals = torch.empty((batch, l), dtype=torch.float32, device=g.device)
+    evecs = torch.empty((batch, l, l), dtype=torch.float32, device=g.device)
+    nat.check(
+        nat.lib().kf_eigh_small_batched(g.data_ptr(), batch, l, evals.data_ptr(), evecs.data_ptr(), int(inv_sqrt), floor_rel, 0,
+                                        nat.stream_ptr(g.device)),
+        "kf_eigh_small_batched",
+    )
+    return evals, evecs
+
+
+def _bmm(out_shape, a: kf_view, b: kf_view, batch: int, device, alpha: float = 1.0) -> torch.Tensor:
+    out = torch.empty(out_shape, dtype=torch.float32, device=device)
+    gemm(out, out_shape[2], out_shape[1] * out_shape[2], a, b, batch=batch, alpha=alpha)
+    return out
+
+
+def low_rank_factors(p: torch.Tensor, rank: int, power_iterations: int = 2, oversample: int = 8
+                     ) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Rank-``rank`` factors ``(left [q,O,k], right [q,k,I'])`` with ``left @ right ~= p`` for ``p: [q,O,I']`` fp32 --
+    the truncated SVD of the reference's low-rank query batching (module/tracker/precondition.py:19-75), computed as
+    a randomised range finder with subspace iteration (Halko et al. 2011, the algorithm behind ``torch.svd_lowrank``)
+    entirely out of batched MFMA GEMMs and the in-LDS small eigensolver:
+
+        Y = P Omega;  Q = orth(Y);  repeat: Q = orth(P orth(P^T Q));  B = Q^T P;  B B^T = W S^2 W^T;
+        left = Q W_k,  right = W_k^T B            (left @ right = Q W_k W_k^T Q^T P)
+
+    ``orth(Y) = Y V S^-1`` from the eigendecomposition of the ``l x l`` Gram matrix ``Y^T Y`` (``l = rank + oversample``,
+    capped by ``min(O, I')`` -- where the range finder, hence the truncated SVD, is exact)."""
+    p = _contig(p)
+    assert p.dtype == torch.float32 and p.dim() == 3
+    q, o, ip = p.shape
+    l = min(rank + oversample, o, ip, EIGH_SMALL_MAX)
+    k = min(rank, l)
+    dev = p.device
+    gen = torch.Generator(device=dev).manual_seed(0x5eed)
+    omega_t = torch.randn((l, ip), generator=gen, dtype=torch.float32, device=dev)  # Omega^T, shared by the batch
+
+    def orth(y: torch.Tensor, rows: int) -> torch.Tensor:  # y: [q, rows, l]
+        gram = _bmm((q, l, l), view(y, rows * l, 1, l, l, rows), view(y, rows * l, 1, l, l, rows), q, dev)
+        _, basis = eigh_small(gram, inv_sqrt=True, floor_rel=1e-10)
+        return _bmm((q, rows, l), view(y, rows * l, l, 1, rows, l), view(basis, l * l, 1, l, l, l), q, dev)
+
+    def p_times(z: torch.Tensor) -> torch.Tensor:  # [q,O,I'] x [q,I',l] -> [q,O,l]
+        return _bmm((q, o, l), view(p, o * ip, ip, 1, o, ip), view(z, ip * l, 1, l, l, ip), q, dev)
+
+    def pt_times(y: torch.Tensor) -> torch.Tensor:  # [q,O,I']^T x [q,O,l] -> [q,I',l]
+        return _bmm((q, ip, l), view(p, o * ip, 1, ip, ip, o), view(y, o * l, 1, l, l, o), q, dev)
+
+    basis = orth(_bmm((q, o, l), view(p, o * ip, ip, 1, o, ip), view(omega_t, 0, ip, 1, l, ip), q, dev), o)
+    for _ in range(power_iterations):
+        basis = orth(p_times(orth(pt_times(basis), ip)), o)
+    b = _bmm((q, l, ip), view(basis, o * l, 1, l, l, o), view(p, o * ip, 1, ip, ip, o), q, dev)  # Q^T P
+    small = _bmm((q, l, l), view(b, l * ip, ip, 1, l, ip), view(b, l * ip, ip, 1, l, ip), q, dev)  # B B^T
+    _, w = eigh_small(small)
+    left = _bmm((q, o, k), view(basis, o * l, l, 1, o, l), view(w, l * l, 1, l, k, l), q, dev)
+    right = _bmm((q, k, ip), view(w, l * l, 1, l, k, l), view(b, l * ip, 1, ip, ip, l), q, dev)
+    return left, right
+
+
+def low_rank_product(left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
+    """``left @ right`` -> fp32 ``[q, O, I']`` (reconstruction of low-rank query gradients ahead of the score GEMM)."""
+    left, right = _contig(left), _contig(right)
+    if left.dtype != torch.float32:
+        left = cast(left, torch.float32)
+    if right.dtype != torch.float32:
+        right = cast(right, torch.float32)
+    q, o, k = left.shape
+    ip = right.shape[2]
+    return _bmm((q, o, ip), view(left, o * k, k, 1, o, k), view(right, k * ip, 1, ip, ip, k), q, left.device)
+
+
 def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, r: int, scale: float = 1.0) -> None:
     """``lam += sum_b (Gt_b^T At_b)^2`` with rotated factors (kf_lambda_accum; tracker/factor.py:218-226)."""
     nat.require_device(lam, "lam")

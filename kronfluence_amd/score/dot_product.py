@@ -48,7 +48,8 @@ def compute_dot_products_with_loader(model: nn.Module, task: Task, state: State,
     model.zero_grad(set_to_none=True)
     set_mode(model, ModuleMode.PAIRWISE_SCORE, tracked_module_names, release_memory=False)
     modules = [m for m in model.modules() if isinstance(m, TrackedModule) and m.name in tracked_module_names]
-    num_queries = modules[0].storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME].shape[0]
+    held = modules[0].storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
+    num_queries = (held[0] if isinstance(held, list) else held).shape[0]
     shard_size = len(train_loader.sampler) if hasattr(train_loader, "sampler") else len(train_loader.dataset)
     dataset_size = len(train_loader.dataset)
 
@@ -94,7 +95,8 @@ def compute_aggregated_dot_products_with_loader(model: nn.Module, task: Task, st
     model.zero_grad(set_to_none=True)
     set_mode(model, ModuleMode.GRADIENT_AGGREGATION, tracked_module_names, release_memory=False)
     modules = [m for m in model.modules() if isinstance(m, TrackedModule) and m.name in tracked_module_names]
-    num_queries = modules[0].storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME].shape[0]
+    held = modules[0].storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
+    num_queries = (held[0] if isinstance(held, list) else held).shape[0]
     enable_amp = score_args.amp_dtype is not None
     if not all(m.exist() for m in modules):  # the summed train gradient is reused across query chunks
         for batch in train_loader:

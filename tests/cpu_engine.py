@@ -103,6 +103,18 @@ def eigh(cov, count, max_sweeps=0):
     return evals, evecs.contiguous(), 1
 
 
+def eigh_small(g, inv_sqrt=False, floor_rel=1e-12):
+    sym = 0.5 * (g.double() + g.double().transpose(1, 2))
+    evals, evecs = torch.linalg.eigh(sym)
+    evals, evecs = evals.flip(-1), evecs.flip(-1)
+    if inv_sqrt:
+        floor = floor_rel * evals[:, :1].clamp(min=0.0)
+        clipped = torch.maximum(evals, floor)
+        scale = torch.where(clipped > 0, clipped.rsqrt(), torch.zeros_like(clipped))
+        evecs = evecs * scale.unsqueeze(1)
+    return evals.float(), evecs.float().contiguous()
+
+
 def lambda_accum(lam, gt, at, b, r, scale=1.0) -> None:
     o, ip = lam.shape
     g = torch.einsum("bro,bri->boi", gt.reshape(b, r, o).double(), at.reshape(b, r, ip).double()) * scale
@@ -152,7 +164,7 @@ def cast(src, dtype):
     return src.to(dtype).clone()
 
 
-LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "lambda_accum", "inv_lambda", "precondition",
+LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "eigh_small", "lambda_accum", "inv_lambda", "precondition",
           "pairwise_score", "rowwise_dot", "mul_bcast", "cast")
 
 

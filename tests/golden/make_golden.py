@@ -147,6 +147,11 @@ def run_widen(kind: str, out_path: str) -> None:
                             ("aggqt", dict(aggregate_query_gradients=True, aggregate_train_gradients=True))):
                 analyzer.compute_pairwise_scores(tag, "f", query, train, score_args=sargs(**kw), overwrite_output_dir=True, **batch)
                 out[tag] = analyzer.load_pairwise_scores(tag)["all_modules"].contiguous()
+            rank = 4
+            analyzer.compute_pairwise_scores("lowrank", "f", query, train, overwrite_output_dir=True, **batch,
+                                             score_args=sargs(query_gradient_low_rank=rank, use_full_svd=True,
+                                                              query_gradient_svd_dtype=dtype))
+            out[f"lowrank{rank}"] = analyzer.load_pairwise_scores("lowrank")["all_modules"].contiguous()
             if kind == "seq":
                 analyzer.compute_pairwise_scores("tok", "f", query, train, score_args=sargs(compute_per_token_scores=True),
                                                  overwrite_output_dir=True, **batch)

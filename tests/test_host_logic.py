@@ -49,7 +49,8 @@ def test_argument_validation_matches_reference_rules():
     assert args.strategy == "ekfac" and args.eigendecomposition_dtype == torch.float64
     assert args.to_dict()["lambda_dtype"] == "torch.float32"
     assert ScoreArguments().damping_factor == 1e-8
-    assert unsupported_score_options(ScoreArguments(query_gradient_low_rank=8)) == {"query_gradient_low_rank": 8}
+    assert unsupported_score_options(ScoreArguments(query_gradient_low_rank=8)) == {}
+    assert unsupported_score_options(ScoreArguments(query_gradient_low_rank=128)) == {"query_gradient_low_rank": 128}
     assert unsupported_score_options(ScoreArguments()) == {}
 
 

@@ -413,3 +413,47 @@ def test_summed_gradient_gemm(ops):
     a1 = torch.cat([a, torch.ones(b, r, 1)], dim=-1).double()
     want = torch.einsum("bro,bri->oi", g.double(), a1)
     assert rel(total[0], want) <= TOL
+
+
+# ---- batched in-LDS eigensolver and the low-rank query factorisation --------------------------
+@pytest.mark.parametrize("l", [1, 2, 3, 12, 17, 40, 64, 72, 95, 96])
+def test_eigh_small_batched(ops, l):
+    batch = 37
+    y = _rand(batch, l + 5, l, seed=l)
+    if l > 4:
+        y[:, :, -2:] = y[:, :, :2] * 0.5  # rank deficient Gram matrices
+    g = (y.transpose(1, 2) @ y).contiguous()
+    evals, evecs = ops.eigh_small(g.to(DEV))
+    evals, evecs = evals.double().cpu(), evecs.double().cpu()
+    want = torch.linalg.eigvalsh(g.double()).flip(-1)
+    assert float((evals - want).abs().max() / want.abs().max()) <= 2e-6
+    assert bool((evals[:, :-1] >= evals[:, 1:] - 1e-6 * want.abs().max()).all())  # descending
+    eye = torch.eye(l, dtype=torch.float64)
+    assert float((evecs.transpose(1, 2) @ evecs - eye).abs().max()) <= 5e-6
+    recon = evecs @ torch.diag_embed(evals) @ evecs.transpose(1, 2)
+    assert rel(recon, g) <= 5e-6
+    # inv_sqrt: Y V S^-1 is orthonormal on the numerical range
+    _, basis = ops.eigh_small(g.to(DEV), inv_sqrt=True, floor_rel=1e-10)
+    qmat = y.double() @ basis.double().cpu()
+    gram = qmat.transpose(1, 2) @ qmat
+    keep = want > 1e-5 * want[:, :1]
+    diag = torch.diagonal(gram, dim1=1, dim2=2)
+    assert float((diag[keep] - 1.0).abs().max()) <= 1e-3
+    off = gram - torch.diag_embed(diag)
+    assert float(off.abs().max()) <= 1e-3
+
+
+@pytest.mark.parametrize("q,o,ip,k", [(3, 16, 13, 4), (2, 40, 120, 8), (5, 256, 300, 32), (2, 1024, 785, 64)])
+def test_low_rank_factors_are_near_optimal(ops, q, o, ip, k):
+    g = torch.Generator().manual_seed(q * 1000 + k)
+    r = min(o, ip)
+    u = torch.linalg.qr(torch.randn(q, o, r, generator=g))[0]
+    v = torch.linalg.qr(torch.randn(q, ip, r, generator=g))[0]
+    sv = torch.logspace(0, -3, r)
+    p = ((u * sv) @ v.transpose(1, 2)).float().contiguous()
+    left, right = ops.low_rank_factors(p.to(DEV), k)
+    assert left.shape == (q, o, k) and right.shape == (q, k, ip)
+    approx = ops.low_rank_product(left, right).double().cpu()
+    best_err = float(sv[k:].norm() / sv.norm())  # Eckart-Young: error of the exact truncated SVD
+    err = float((approx - p.double()).norm() / p.double().norm())
+    assert err <= best_err * 1.02 + 1e-5, (err, best_err)

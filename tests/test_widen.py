@@ -225,3 +225,40 @@ def test_score_sink_refuses_mixed_token_axes():
         sink.matrix(6)
     sink = ScoreSink(2, 4, torch.device("cpu"), per_token=True)
     assert sink.matrix(6).shape == (2, 24) and sink.result().shape == (2, 4, 6)
+
+
+# ---- 8(f)-1: low-rank query batching ------------------------------------------------------------------------------
+def _spearman(a, b):
+    ra, rb = a.flatten().argsort().argsort().double(), b.flatten().argsort().argsort().double()
+    ra, rb = ra - ra.mean(), rb - rb.mean()
+    return float((ra @ rb) / (ra.norm() * rb.norm()))
+
+
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_low_rank_query_gradients_match_reference(kind, tmp_path, engine):
+    """``query_gradient_low_rank=4``: on these small layers the range finder spans the whole row space, so the
+    factors are the exact truncated SVD and the scores equal the reference's ``use_full_svd=True`` run; the reference's
+    own bar for this option is rank correlation with the full-rank scores (tests/scores/test_pairwise_scores.py:977-978)."""
+    from kronfluence_amd import FactorArguments, ScoreArguments
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.utils.constants import ACCUMULATED_PRECONDITIONED_GRADIENT_NAME
+
+    gold = _widen(kind)
+    spec, analyzer, train, query = build(kind, tmp_path)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(use_empirical_fisher=True))
+    common = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
+    for name, full_svd in (("lr", False), ("lr_full", True)):
+        got = analyzer.compute_pairwise_scores(name, "f", query, train, **common,
+                                               score_args=ScoreArguments(damping_factor=None, query_gradient_low_rank=4,
+                                                                         use_full_svd=full_svd))["all_modules"]
+        assert got.shape == gold["lowrank4"].shape
+        assert rel(got, gold["lowrank4"]) <= _tol(engine, 1e-4, 2e-3), (name, rel(got, gold["lowrank4"]))
+        assert _spearman(got, gold["strategy/ekfac/scores"]) >= _spearman(gold["lowrank4"], gold["strategy/ekfac/scores"]) - 0.01
+    # same through query accumulation, module partitions and query aggregation on low-rank factors
+    again = analyzer.compute_pairwise_scores("lr_acc", "f", query, train, per_device_query_batch_size=2,
+                                             per_device_train_batch_size=7,
+                                             score_args=ScoreArguments(damping_factor=None, query_gradient_low_rank=4,
+                                                                       query_gradient_accumulation_steps=2,
+                                                                       module_partitions=2))["all_modules"]
+    assert rel(again, got) <= _tol(engine, 1e-5, 1e-3)
