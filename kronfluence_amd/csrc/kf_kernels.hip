@@ -410,6 +410,7 @@ __global__ void im2col_vec8_kernel(Im2colArgs a) {
     const int P = static_cast<int>(a.O1 * a.O2), Ip = static_cast<int>(a.Ip), octs = Ip >> 3;
     const int64_t total = a.b * P * octs;
     const int H = static_cast<int>(a.H), W = static_cast<int>(a.W);
+    const bool same_dtype = a.in_dtype == a.out_dtype;
     for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
          e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
         const int iv = static_cast<int>(e % octs);
@@ -421,26 +422,93 @@ __global__ void im2col_vec8_kernel(Im2colArgs a) {
         int i0 = iv * 8;
         int kx = i0 % a.k2, ky = (i0 / a.k2) % a.k1, c = i0 / (a.k1 * a.k2);
         const int64_t img = n * a.C * H * W;
-        uint32_t w[4];
+        // Addresses are clamped into the image and the loads issued unconditionally (zero selected afterwards):
+        // a branch around a load makes the compiler serialise the eight gathers behind one another.
+        uint32_t raw[8];
+        bool inside[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int iy = by + ky * a.d1, ix = bx + kx * a.d2;
-            uint32_t bits = 0;
-            if (iy >= 0 && iy < H && ix >= 0 && ix < W) {
-                const int64_t src = img + (static_cast<int64_t>(c) * H + iy) * W + ix;
-                if (a.in_dtype == a.out_dtype) {
-                    bits = reinterpret_cast<const uint16_t*>(a.x)[src];
-                } else {
-                    uint16_t tmp;
-                    store_as(&tmp, a.out_dtype, 0, load_f32(a.x, a.in_dtype, src));
-                    bits = tmp;
-                }
+            inside[j] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
+            const int64_t src = img + (static_cast<int64_t>(c) * H + cy) * W + cx;
+            if (same_dtype) {
+                raw[j] = reinterpret_cast<const uint16_t*>(a.x)[src];
+            } else {
+                uint16_t tmp;
+                store_as(&tmp, a.out_dtype, 0, load_f32(a.x, a.in_dtype, src));
+                raw[j] = tmp;
             }
-            if (j & 1) w[j >> 1] |= bits << 16; else w[j >> 1] = bits;
             if (++kx == a.k2) { kx = 0; if (++ky == a.k1) { ky = 0; ++c; } }
+        }
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t bits = inside[j] ? raw[j] : 0u;
+            if (j & 1) w[j >> 1] |= bits << 16; else w[j >> 1] = bits;
         }
         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
         reinterpret_cast<u32x4_t*>(a.out)[e] = u32x4_t{w[0], w[1], w[2], w[3]};
+    }
+}
+
+// LDS-staged variant for 2-byte dtypes (same in / out dtype, groups == 1, I' % 8 == 0, W % 8 == 0): one workgroup
+// owns one image and a band of RB output rows.  The input rows the band touches are copied ONCE into LDS with
+// coalesced 16-byte loads ([C][NR][W + 2 p2], zero-filled borders, so no bounds checks afterwards); every
+// 16-byte chunk of the patch matrix is then assembled from eight ds_read_u16.  The scattered 2-byte global
+// gathers of the kernel above kept it at 0.6 TB/s of writes (texture-address bound); this one streams.
+struct Im2colLdsArgs { Im2colArgs a; int RB, NR, Wp; };
+
+__global__ __launch_bounds__(256) void im2col_lds_kernel(Im2colLdsArgs p) {
+    extern __shared__ uint16_t tile[];
+    const Im2colArgs& a = p.a;
+    const int C = static_cast<int>(a.C), H = static_cast<int>(a.H), W = static_cast<int>(a.W);
+    const int O1 = static_cast<int>(a.O1), O2 = static_cast<int>(a.O2), Ip = static_cast<int>(a.Ip);
+    const int bands = (O1 + p.RB - 1) / p.RB;
+    const int64_t n = blockIdx.x / bands;
+    const int oy0 = static_cast<int>(blockIdx.x % bands) * p.RB;
+    const int rows_here = min(p.RB, O1 - oy0);
+    const int iy0 = oy0 * a.s1 - a.p1;
+    const uint16_t* x = reinterpret_cast<const uint16_t*>(a.x) + n * C * H * W;
+    // ---- stage: [C][NR][Wp]; 8 elements (16 B) per thread-iteration along W
+    const int w8 = W >> 3, chunks = C * p.NR * w8;
+    for (int t = threadIdx.x; t < chunks; t += 256) {
+        const int wv = t % w8, r = (t / w8) % p.NR, c = t / (w8 * p.NR);
+        const int iy = iy0 + r;
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        u32x4_t v = {0u, 0u, 0u, 0u};
+        if (iy >= 0 && iy < H) v = *reinterpret_cast<const u32x4_t*>(x + (static_cast<int64_t>(c) * H + iy) * W + wv * 8);
+        uint16_t* dst = tile + (c * p.NR + r) * p.Wp + a.p2 + wv * 8;
+        dst[0] = static_cast<uint16_t>(v[0]); dst[1] = static_cast<uint16_t>(v[0] >> 16);
+        dst[2] = static_cast<uint16_t>(v[1]); dst[3] = static_cast<uint16_t>(v[1] >> 16);
+        dst[4] = static_cast<uint16_t>(v[2]); dst[5] = static_cast<uint16_t>(v[2] >> 16);
+        dst[6] = static_cast<uint16_t>(v[3]); dst[7] = static_cast<uint16_t>(v[3] >> 16);
+    }
+    if (a.p2 > 0)
+        for (int t = threadIdx.x; t < C * p.NR * 2 * a.p2; t += 256) {
+            const int j = t % (2 * a.p2), row = t / (2 * a.p2);
+            tile[row * p.Wp + (j < a.p2 ? j : W + j)] = 0;
+        }
+    __syncthreads();
+    // ---- emit: octets of the [rows_here * O2, I'] block, consecutive threads -> consecutive 16-byte chunks
+    const int octs = Ip >> 3, total = rows_here * O2 * octs, kk = a.k1 * a.k2;
+    typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t* out = reinterpret_cast<u32x4_t*>(a.out) + (n * O1 * O2 + static_cast<int64_t>(oy0) * O2) * octs;
+    for (int e = threadIdx.x; e < total; e += 256) {
+        const int iv = e % octs, pos = e / octs;
+        const int oyl = pos / O2, ox = pos - oyl * O2;
+        const int i0 = iv * 8;
+        int c = i0 / kk, rem = i0 - c * kk;
+        int ky = rem / a.k2, kx = rem - ky * a.k2;
+        const int base_r = oyl * a.s1, base_x = ox * a.s2;
+        uint32_t w[4];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t bits = tile[(c * p.NR + base_r + ky * a.d1) * p.Wp + base_x + kx * a.d2];
+            if (j & 1) w[j >> 1] |= bits << 16; else w[j >> 1] = bits;
+            if (++kx == a.k2) { kx = 0; if (++ky == a.k1) { ky = 0; ++c; } }
+        }
+        out[e] = u32x4_t{w[0], w[1], w[2], w[3]};
     }
 }
 
@@ -782,6 +850,35 @@ int kf_im2col(void* out, int out_dtype, const void* x, int in_dtype, int64_t b, 
     if (total == 0) return KF_OK;
     const bool two_byte = out_dtype == KF_BF16 || out_dtype == KF_F16;
     if (two_byte && groups == 1 && a.Ip % 8 == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 && total < (1LL << 40)) {
+        if (in_dtype == out_dtype && !append_ones && W % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0) {
+            // largest band of output rows whose input footprint fits 64 KB of LDS (two workgroups per CU)
+            Im2colLdsArgs la;
+            la.a = a;
+            la.Wp = static_cast<int>(W) + 2 * p2;
+            const int64_t row_bytes = C * la.Wp * 2;
+            int rb = 0;
+            for (int cand = static_cast<int>(a.O1); cand >= 1; --cand) {
+                const int64_t nr = static_cast<int64_t>(cand - 1) * s1 + static_cast<int64_t>(k1 - 1) * d1 + 1;
+                if (nr * row_bytes <= 64 * 1024) { rb = cand; break; }
+            }
+            if (rb > 0) {
+                // at least ~2 workgroups per CU: split the image further when the batch is small
+                while (rb > 1 && b * ((a.O1 + rb - 1) / rb) < 512) rb = (rb + 1) / 2;
+                la.RB = rb;
+                la.NR = (rb - 1) * s1 + (k1 - 1) * d1 + 1;
+                const size_t lds = static_cast<size_t>(la.NR) * row_bytes;
+                static bool configured = false;
+                if (!configured) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_lds_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
+                        return KF_ERR_LAUNCH_FAILED;
+                    configured = true;
+                }
+                const int64_t blocks = b * ((a.O1 + rb - 1) / rb);
+                hipLaunchKernelGGL(im2col_lds_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, as_stream(stream), la);
+                return launch_status();
+            }
+        }
         hipLaunchKernelGGL(im2col_vec8_kernel, dim3(stream_grid(total / 8) * 4), dim3(256), 0, as_stream(stream), a);
         return launch_status();
     }
