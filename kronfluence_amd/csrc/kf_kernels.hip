@@ -1029,7 +1029,7 @@ int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int
 }
 
 int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip) {
-    if (R <= 1) return 16;
+    if (R <= 1 && O >= 32) return 16;
     return static_cast<int64_t>(sizeof(float)) * b * O * Ip;
 }
 
@@ -1044,7 +1044,10 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dty
     const int64_t Ip = I + (append_ones ? 1 : 0);
     if (p_k_tile_stride != 0 && (R == 1 || p_dtype != KF_BF16 || (O * Ip) % 64 != 0 || p_k_tile_stride != Q * 64))
         return KF_ERR_INVALID_ARGUMENT;
-    if (R == 1) {
+    // R == 1: the fused kernel tiles (q, 128 rows of o) x 128 samples; with a handful of output rows (a classifier
+    // head) almost the whole tile is padding and one workgroup per query is launched for nothing -- such layers go
+    // through the generic "materialise the rank-one gradients, one GEMM over D" path below instead.
+    if (R == 1 && O >= 32) {
         ScoreArgs a;
         a.scores = scores; a.ld_scores = ld_scores; a.P = P; a.p_dtype = p_dtype; a.G = G; a.A = A; a.in_dtype = in_dtype;
         a.Q = static_cast<int>(Q); a.b = static_cast<int>(b); a.O = static_cast<int>(O); a.I = static_cast<int>(I);

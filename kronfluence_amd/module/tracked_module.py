@@ -101,7 +101,11 @@ class TrackedModule(nn.Module):
     # -- model-facing -------------------------------------------------------------------------------
     def forward(self, inputs: torch.Tensor, *args: Any, **kwargs: Any) -> torch.Tensor:
         outputs = self.original_module(inputs, *args, **kwargs)
-        return outputs if outputs.requires_grad else outputs + self._constant
+        if outputs.requires_grad:
+            return outputs
+        # keep the layer's own output dtype: adding the fp32 parameter to a bf16 (autocast) output would promote the
+        # whole downstream block -- and the next tracked layer's hooked activation -- to fp32
+        return outputs + self._constant.to(dtype=outputs.dtype)
 
     # -- bookkeeping (reference tracked_module.py:170-318) -----------------------------------------
     def prepare_storage(self, device: torch.device) -> None:
