@@ -195,13 +195,15 @@ int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambd
  * P: [q,O,I'] in out_dtype (KF_F32, or KF_BF16 = ScoreArguments.score_dtype of the reference's
  * low-precision presets; all arithmetic and the staging of intermediate results stay fp32).
  * Qa_bf16 [I',I'] and QgT_bf16 = Qg^T [O,O] (bf16, nullable): when given with out_dtype KF_BF16
- * (ScoreArguments.precondition_dtype = bf16) the two back-rotations run on the bf16 MFMA engine.
+ * (ScoreArguments.precondition_dtype = bf16) the two back-rotations run on the bf16 MFMA engine;
+ * with QaT_bf16 = Qa^T [I',I'] (bf16, nullable) and bf16 A without bias column also the forward rotation
+ * A Qa, which costs 2 q R I'^2 flops and dominates for convolutions (R = output positions).
  * workspace (device): kf_precondition_workspace_bytes(q,R,O,I') bytes.
  */
 int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip);
 int kf_precondition(void* P, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q,
                     int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg, const float* Qa,
-                    const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16,
+                    const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16, const void* QaT_bf16,
                     void* workspace, int64_t workspace_bytes, void* stream);
 
 /*

@@ -756,7 +756,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 6; }
+int kf_abi_version(void) { return 7; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -979,7 +979,8 @@ int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t
 
 int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O,
                     int64_t I, int append_ones, const float* Qg, const float* Qa, const float* inv_lambda, float scale,
-                    const void* Qa_bf16, const void* QgT_bf16, void* workspace, int64_t workspace_bytes, void* stream) {
+                    const void* Qa_bf16, const void* QgT_bf16, const void* QaT_bf16, void* workspace, int64_t workspace_bytes,
+                    void* stream) {
     if (!Pout || !G || !A || !Qg || !Qa || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
     if (!float_dtype(in_dtype) || (out_dtype != KF_F32 && out_dtype != KF_BF16)) return KF_ERR_UNSUPPORTED_DTYPE;
     const int64_t Ip = I + (append_ones ? 1 : 0);
@@ -1000,7 +1001,15 @@ int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int
     rc = launch_gemm(Gt, O, 0, make_view(G, in_dtype, 0, O, 1, q * R, O), make_view(Qg, KF_F32, 0, 1, O, O, O), 1, 1.0f, 0.0f, nullptr, 0, st);
     if (rc != KF_OK) return rc;
     // At[(q r), i'] = sum_i [A,1][(q r), i] Qa[i, i']
-    rc = launch_gemm(At, Ip, 0, make_view(A, in_dtype, 0, I, 1, q * R, I, 0, append_ones ? 1 : 0), make_view(Qa, KF_F32, 0, 1, Ip, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
+    if (low && QaT_bf16 && in_dtype == KF_BF16 && !append_ones && R > 1 &&
+        ((reinterpret_cast<uintptr_t>(QaT_bf16) | reinterpret_cast<uintptr_t>(A)) & 15) == 0) {
+        // 2 q R I'^2 flops -- for a convolution the largest term of the whole preconditioner: NT on the bf16 engine
+        rc = launch_gemm(At, Ip, 0, make_view(A, KF_BF16, 0, I, 1, q * R, I), make_view(QaT_bf16, KF_BF16, 0, Ip, 1, Ip, Ip), 1, 1.0f,
+                         0.0f, nullptr, 0, st, KF_F32);
+    } else {
+        rc = launch_gemm(At, Ip, 0, make_view(A, in_dtype, 0, I, 1, q * R, I, 0, append_ones ? 1 : 0),
+                         make_view(Qa, KF_F32, 0, 1, Ip, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
+    }
     if (rc != KF_OK) return rc;
     if (low) {
         uint16_t* rot16 = reinterpret_cast<uint16_t*>(T);            // [q, O, I'] bf16

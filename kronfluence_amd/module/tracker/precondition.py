@@ -43,17 +43,18 @@ class PreconditionTracker(BaseTracker):
     _bf16_q = None
 
     def _bf16_eigenvectors(self):
-        """bf16 copies ``(Q_A, Q_G^T)`` for ``precondition_dtype == bf16`` (the reference casts the eigenvectors to
-        that dtype in ``Ekfac.prepare``, factor/config.py:323-328); ``(None, None)`` otherwise."""
+        """bf16 copies ``(Q_A, Q_G^T, Q_A^T)`` for ``precondition_dtype == bf16`` (the reference casts the eigenvectors to
+        that dtype in ``Ekfac.prepare``, factor/config.py:323-328); ``(None, None, None)`` otherwise."""
         args = self.module.score_args
         if args.precondition_dtype != torch.bfloat16 or args.score_dtype != torch.bfloat16:
-            return None, None
+            return None, None, None
         storage = self.module.storage
         source = storage[ACTIVATION_EIGENVECTORS_NAME]
         if self._bf16_q is None or self._bf16_q[0] is not source:
             self._bf16_q = (source, source.to(torch.bfloat16).contiguous(),
-                            storage[GRADIENT_EIGENVECTORS_NAME].t().contiguous().to(torch.bfloat16))
-        return self._bf16_q[1], self._bf16_q[2]
+                            storage[GRADIENT_EIGENVECTORS_NAME].t().contiguous().to(torch.bfloat16),
+                            source.t().contiguous().to(torch.bfloat16))
+        return self._bf16_q[1], self._bf16_q[2], self._bf16_q[3]
 
     def _store(self, preconditioned: torch.Tensor) -> None:
         """Keeps the ``[q, O, I']`` block, or -- with ``query_gradient_low_rank = k < min(O, I')`` -- its rank-k factors
@@ -101,11 +102,11 @@ class PreconditionTracker(BaseTracker):
                     self._store(rotated)
                     return
                 module.queries_in_eigenbasis = False
-                qa16, qgt16 = self._bf16_eigenvectors()
+                qa16, qgt16, qat16 = self._bf16_eigenvectors()
                 self._store(ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
                                              storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
                                              scale=module.gradient_scale, out_dtype=self._out_dtype(),
-                                             q_a_bf16=qa16, q_g_t_bf16=qgt16))
+                                             q_a_bf16=qa16, q_g_t_bf16=qgt16, q_a_t_bf16=qat16))
             else:
                 module.queries_in_eigenbasis = False
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach())

@@ -343,7 +343,8 @@ def inv_lambda(lam: torch.Tensor, n_lambda: float, damping: Optional[float]) -> 
 
 def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch.Tensor, q_a: torch.Tensor,
                  lam_inv: torch.Tensor, scale: float = 1.0, out_dtype: torch.dtype = torch.float32,
-                 q_a_bf16: Optional[torch.Tensor] = None, q_g_t_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
+                 q_a_bf16: Optional[torch.Tensor] = None, q_g_t_bf16: Optional[torch.Tensor] = None,
+                 q_a_t_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
     """EK-FAC preconditioned per-sample gradient ``[q, O, I']`` from ``g: [q,R,O]`` and ``a: [q,R,I]``
     (tracker/precondition.py:102-123 + factor/config.py:341-353)."""
     nat.require_device(g, "g")
@@ -362,7 +363,8 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
         nat.lib().kf_precondition(out.data_ptr(), nat.dtype_code(out_dtype), g.data_ptr(), a.data_ptr(),
                                   nat.dtype_code(g.dtype), q, r, o, i,
                                   int(append_ones), q_g.data_ptr(), q_a.data_ptr(), lam_inv.data_ptr(), scale,
-                                  _ptr(q_a_bf16), _ptr(q_g_t_bf16), ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
+                                  _ptr(q_a_bf16), _ptr(q_g_t_bf16), _ptr(q_a_t_bf16), ws.data_ptr(), ws_bytes,
+                                  nat.stream_ptr(g.device)),
         "kf_precondition",
     )
     return out

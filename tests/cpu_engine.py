@@ -132,7 +132,8 @@ def _psg(g, a, append_ones):
     return torch.einsum("bro,bri->boi", g.double(), a)
 
 
-def precondition(g, a, append_ones, q_g, q_a, lam_inv, scale=1.0, out_dtype=torch.float32, q_a_bf16=None, q_g_t_bf16=None):
+def precondition(g, a, append_ones, q_g, q_a, lam_inv, scale=1.0, out_dtype=torch.float32, q_a_bf16=None, q_g_t_bf16=None,
+                 q_a_t_bf16=None):
     psg = _psg(g, a, append_ones)
     out = ref.ekfac_precondition(psg, q_a.double(), q_g.double(), lam_inv.double()) * scale
     return out.to(out_dtype).contiguous()

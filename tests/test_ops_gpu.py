@@ -355,6 +355,21 @@ def test_precondition_bf16_back_rotation(ops, q, r, o, i):
     assert got.dtype == torch.bfloat16 and rel(got, want) <= 1.5e-2
 
 
+@pytest.mark.parametrize("q,r,o,i", [(4, 6, 64, 128), (3, 50, 128, 72), (7, 256, 128, 1152)])
+def test_precondition_bf16_forward_and_back_rotation(ops, q, r, o, i):
+    """bf16 inputs + ``Q_A^T`` in bf16: the forward rotation ``A Q_A`` runs on the bf16 engine too (ABI 7)."""
+    g, a = _rand(q, r, o, dtype=torch.bfloat16), _rand(q, r, i, dtype=torch.bfloat16, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].contiguous()
+    q_a = torch.linalg.qr(_rand(i, i, seed=3).double())[0].contiguous()
+    lam_inv = _rand(o, i, seed=4).abs().double() + 0.1
+    want = ref.ekfac_precondition(ref.linear_per_sample_gradient(a.double(), g.double(), False), q_a, q_g, lam_inv)
+    qa_d, qg_d = q_a.float().to(DEV), q_g.float().to(DEV)
+    got = ops.precondition(g.to(DEV), a.to(DEV), False, qg_d, qa_d, lam_inv.float().to(DEV), out_dtype=torch.bfloat16,
+                           q_a_bf16=qa_d.to(torch.bfloat16).contiguous(), q_g_t_bf16=qg_d.t().contiguous().to(torch.bfloat16),
+                           q_a_t_bf16=qa_d.t().contiguous().to(torch.bfloat16))
+    assert got.dtype == torch.bfloat16 and rel(got, want) <= 1.5e-2, rel(got, want)
+
+
 # ---- SURVEY.md 8(f) kernels: row-wise weighted dots, broadcast product, squared-operand GEMM ---------------------
 @pytest.mark.parametrize("rows,d", [(1, 1), (5, 37), (48, 16 * 17), (3, 1 << 20), (1000, 1024 * 8), (7, 4096 + 8)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
