@@ -88,6 +88,122 @@ __global__ __launch_bounds__(EB) void jacobi_round_kernel(double* Wt, double* Vt
     if (threadIdx.x == 0) atomicAdd(rotated, 1);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Block variant of the round kernel for large d.  The scalar kernel streams all of W and V once per
+// round and there are d - 1 rounds per sweep: at d = 2304 that is 390 GB per sweep, so the solver is
+// bound by L2 / Infinity-Cache bandwidth.  Here a workgroup owns a PAIR OF BLOCKS of BS columns: it
+// forms the 2BS x 2BS Gram matrix of its columns (one read of W), diagonalises it with a cyclic
+// two-sided Jacobi sweep held in LDS by one wave (the rotation angles are exactly those of the
+// one-sided method applied to the columns), and applies the accumulated 2BS x 2BS rotation U to its
+// columns of W and V (one read + one write of each).  Rounds per sweep drop from d - 1 to d/BS - 1.
+// The Gram matrix is rebuilt from the actual columns every round, so rounding in the small problem
+// cannot accumulate; convergence is still "a whole sweep without a rotation" on direct dot products.
+// ------------------------------------------------------------------------------------------------
+constexpr int BS = 4, NC = 2 * BS, NG = NC * (NC + 1) / 2;
+
+__global__ __launch_bounds__(EB) void jacobi_block_round_kernel(double* Wt, double* Vt, int64_t d, int nblocks, int players,
+                                                                int round, double tol, double null2, int* rotated) {
+    __shared__ double red[4][NG];
+    __shared__ double Gs[NC][NC];
+    __shared__ double Us[NC][NC];
+    __shared__ int any_rotation;
+    const int k = blockIdx.x, m = players - 1;
+    int P, Q;
+    if (k == 0) { P = round % m; Q = m; }
+    else { P = (round + k) % m; Q = (round - k + m) % m; }
+    if (P >= nblocks && Q >= nblocks) return;
+    int64_t col[NC];
+    bool valid[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int64_t j = static_cast<int64_t>(c < BS ? P : Q) * BS + (c % BS);
+        valid[c] = (c < BS ? P : Q) < nblocks && j < d;
+        col[c] = valid[c] ? j : 0;
+    }
+    // ---- pass 1: Gram matrix of the NC columns
+    double acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = 0.0;
+    for (int64_t i = threadIdx.x; i < d; i += EB) {
+        double x[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) { const double v = Wt[col[c] * d + i]; x[c] = valid[c] ? v : 0.0; }
+        int g = 0;
+#pragma unroll
+        for (int a = 0; a < NC; ++a)
+#pragma unroll
+            for (int b = a; b < NC; ++b) acc[g++] += x[a] * x[b];
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        double v = acc[g];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+        if (lane == 0) red[wave][g] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NC * NC) {
+        const int r = threadIdx.x / NC, c = threadIdx.x % NC;
+        const int a = r < c ? r : c, b = r < c ? c : r;
+        const int g = a * NC - a * (a - 1) / 2 + (b - a);
+        Gs[r][c] = red[0][g] + red[1][g] + red[2][g] + red[3][g];
+        Us[r][c] = r == c ? 1.0 : 0.0;
+    }
+    if (threadIdx.x == 0) any_rotation = 0;
+    __syncthreads();
+    // ---- the small problem: one cyclic sweep over the NC (NC - 1) / 2 pairs, wave 0, lane = (r, c)
+    if (threadIdx.x < NC * NC) {
+        const int r = threadIdx.x / NC, c = threadIdx.x % NC;
+        int did = 0;
+        for (int p = 0; p < NC - 1; ++p)
+            for (int q = p + 1; q < NC; ++q) {
+                const double a = Gs[p][p], b = Gs[q][q], g = Gs[p][q];
+                if (!(fabs(g) > tol * sqrt(a) * sqrt(b)) || !(a > null2) || !(b > null2)) continue;  // uniform
+                const double zeta = (b - a) / (2.0 * g);
+                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+                const double cs = 1.0 / sqrt(1.0 + t * t), sn = cs * t;
+                // columns: G <- G J, U <- U J
+                const double gp = Gs[r][p], gq = Gs[r][q], up = Us[r][p], uq = Us[r][q];
+                __builtin_amdgcn_wave_barrier();
+                if (c == p) { Gs[r][c] = cs * gp - sn * gq; Us[r][c] = cs * up - sn * uq; }
+                if (c == q) { Gs[r][c] = sn * gp + cs * gq; Us[r][c] = sn * up + cs * uq; }
+                __builtin_amdgcn_wave_barrier();
+                // rows: G <- J^T G
+                const double tp = Gs[p][c], tq = Gs[q][c];
+                __builtin_amdgcn_wave_barrier();
+                if (r == p) Gs[r][c] = cs * tp - sn * tq;
+                if (r == q) Gs[r][c] = sn * tp + cs * tq;
+                __builtin_amdgcn_wave_barrier();
+                did = 1;
+            }
+        if (did && threadIdx.x == 0) { any_rotation = 1; atomicAdd(rotated, 1); }
+    }
+    __syncthreads();
+    if (!any_rotation) return;
+    // ---- pass 2: W <- W U, V <- V U on the owned columns
+    double u[NC][NC];
+#pragma unroll
+    for (int a = 0; a < NC; ++a)
+#pragma unroll
+        for (int b = 0; b < NC; ++b) u[a][b] = Us[a][b];
+#pragma unroll 1
+    for (int which = 0; which < 2; ++which) {
+        double* M = which == 0 ? Wt : Vt;
+        for (int64_t i = threadIdx.x; i < d; i += EB) {
+            double x[NC];
+#pragma unroll
+            for (int c = 0; c < NC; ++c) { const double v = M[col[c] * d + i]; x[c] = valid[c] ? v : 0.0; }
+#pragma unroll
+            for (int j = 0; j < NC; ++j) {
+                double y = 0.0;
+#pragma unroll
+                for (int c = 0; c < NC; ++c) y += x[c] * u[c][j];
+                if (valid[j]) M[col[j] * d + i] = y;
+            }
+        }
+    }
+}
+
 // out[0] = ||W||_F^2 (single block)
 __global__ __launch_bounds__(EB) void frob2_kernel(double* out, const double* W, int64_t total) {
     __shared__ double scratch[4];
@@ -273,11 +389,21 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
     const double tol = 4.0 * 2.220446049250313e-16 * sqrt(static_cast<double>(d));
     int sweeps = 0, status = KF_ERR_NOT_CONVERGED;
     const bool verbose = getenv("KF_EIGH_VERBOSE") != nullptr;
+    // large matrices: block rounds (see jacobi_block_round_kernel); KF_EIGH_SCALAR=1 forces the scalar kernel
+    const int nblocks = static_cast<int>((d + BS - 1) / BS);
+    const int block_players = nblocks + (nblocks & 1);
+    const bool use_blocks = d >= 512 && getenv("KF_EIGH_SCALAR") == nullptr;
     if (d == 1) { status = KF_OK; }
     for (; d > 1 && sweeps < max_sweeps; ++sweeps) {
         if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-        for (int r = 0; r < rounds; ++r)
-            hipLaunchKernelGGL(jacobi_round_kernel, dim3(pairs), dim3(EB), 0, st, Wt, Vt, d, npl, r, tol, null2, flag);
+        if (use_blocks) {
+            for (int r = 0; r < block_players - 1; ++r)
+                hipLaunchKernelGGL(jacobi_block_round_kernel, dim3(block_players / 2), dim3(EB), 0, st, Wt, Vt, d, nblocks,
+                                   block_players, r, tol, null2, flag);
+        } else {
+            for (int r = 0; r < rounds; ++r)
+                hipLaunchKernelGGL(jacobi_round_kernel, dim3(pairs), dim3(EB), 0, st, Wt, Vt, d, npl, r, tol, null2, flag);
+        }
         int host_flag = 1;
         if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
         if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;

@@ -138,7 +138,8 @@ def test_per_sample_gradient(ops, b, r, o, i, bias, dtype):
 
 
 # ---- stage 2 -------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,n", [(1, 5), (2, 9), (17, 100), (64, 40), (129, 1000), (300, 150)])
+@pytest.mark.parametrize("d,n", [(1, 5), (2, 9), (17, 100), (64, 40), (129, 1000), (300, 150), (513, 2000), (770, 300),
+                                 (1030, 5000)])  # d >= 512: block rounds (incl. d % 4 != 0 and rank-deficient cases)
 def test_eigh_invariants_and_values(ops, d, n):
     x = _rand(n, d).double()
     cov = (x.t() @ x).float()
