@@ -78,6 +78,10 @@ class TrackedConv2d(TrackedModule, module_type=nn.Conv2d):
         return cov, count
 
     def gradient_factors(self, input_activation, output_gradient):
+        if input_activation.dtype != output_gradient.dtype:
+            # as TrackedLinear: both factors in the gradient's dtype (under autocast the first layer sees an fp32 image
+            # but computes -- and back-propagates -- in bf16)
+            input_activation = input_activation.to(output_gradient.dtype)
         patches = self._patches(input_activation)  # [b, P, I'] incl. the ones column
         grads = output_gradient.flatten(2).transpose(1, 2).contiguous().to(patches.dtype)  # [b, P, O]
         return grads, patches, False

@@ -96,6 +96,20 @@ class PairwiseScoreTracker(BaseTracker):
             yield start, dense_queries([left[start:start + step], right[start:start + step]], score_dtype)
 
     _tiled = None  # (source tensor, k-tile-major bf16 copy) of the held query gradients
+    # bf16 layers whose patch axis is not a multiple of 8 (a first conv layer: 3*3*3 = 27) would fall back to the fp32
+    # engine for the per-sample gradients (7 TFLOP/s on ResNet-9's first layer): zero-pad that axis of both the
+    # activations and the held query gradients to the next multiple of 8 instead -- the contraction is unchanged.
+    PAD_PATCH_AXIS = True
+    _padded = None  # (source tensor, zero-padded copy) of the held query gradients
+
+    def _pad_patch_axis(self, block: torch.Tensor, a: torch.Tensor, g: torch.Tensor, ones: bool):
+        pad = (-a.shape[-1]) % 8
+        if (not self.PAD_PATCH_AXIS or pad == 0 or ones or g.shape[1] == 1 or block.dtype != torch.bfloat16
+                or a.dtype != torch.bfloat16 or g.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0):
+            return block, a
+        if self._padded is None or self._padded[0] is not block:
+            self._padded = (block, torch.nn.functional.pad(block, (0, pad)).contiguous())
+        return self._padded[1], torch.nn.functional.pad(a, (0, pad))
 
     def _tiled_queries(self, preconditioned: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool):
         """k-tile-major copy of the bf16 query gradients, built once per train pass (see
@@ -149,8 +163,9 @@ class PairwiseScoreTracker(BaseTracker):
                     ones = False
                 for first, block in self._query_blocks(preconditioned):
                     rows = scores[first:first + block.shape[0]]
-                    ops.pairwise_score(rows, offset, block, g, a, ones, scale=module.gradient_scale,
-                                       p_tiled=self._tiled_queries(block, g, a, ones))
+                    block, a_in = self._pad_patch_axis(block, a, g, ones)
+                    ops.pairwise_score(rows, offset, block, g, a_in, ones, scale=module.gradient_scale,
+                                       p_tiled=self._tiled_queries(block, g, a_in, ones))
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()
@@ -206,6 +221,7 @@ class PairwiseScoreTracker(BaseTracker):
         self.module.score_sink = None
         self._tiled = None
         self._expanded = None
+        self._padded = None
         self.clear_all_cache()
 
     def release_memory(self) -> None:

@@ -284,3 +284,45 @@ def test_shared_parameters_factors_match_reference_and_scores_match_autograd(tmp
                 want[q, i] += (p * train_grads[i][n]).sum()
     assert rel(scores, want) <= 1e-4, rel(scores, want)
     assert rel(gold["scores/dampNone"], want) > 0.3  # documents the reference's divergence from autograd
+
+
+def test_bf16_conv_with_odd_patch_axis_is_padded_not_demoted(tmp_path):
+    """A first conv layer with 3*3*3 = 27 patch columns under bf16 autocast: the tracker zero-pads that axis to 32 on
+    both sides of the contraction so the bf16 MFMA engine applies; the scores must equal the un-padded (fp32-engine
+    fallback) evaluation of the same bf16 data."""
+    from torch import nn
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1, bias=False), nn.ReLU(),
+                        nn.Conv2d(8, 8, 3, stride=2, padding=1, bias=False), nn.ReLU(),
+                        nn.Flatten(), nn.Linear(8 * 4 * 4, 3))
+    spec = fx.FIXTURES["conv"]
+    task = make_task("conv")
+    analyzer = Analyzer("t", prepare_model(net, task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    train = data.TensorDataset(*fx.make_data("conv", spec.n_train, seed=1))
+    query = data.TensorDataset(*fx.make_data("conv", spec.n_query, seed=2))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16))
+    kw = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
+    args = ScoreArguments(damping_factor=None, amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16)
+    calls = []
+    original = PairwiseScoreTracker._pad_patch_axis
+
+    def spy(self, block, a, g, ones):
+        out = original(self, block, a, g, ones)
+        calls.append((a.shape[-1], out[1].shape[-1]))
+        return out
+
+    PairwiseScoreTracker._pad_patch_axis = spy
+    try:
+        padded = analyzer.compute_pairwise_scores("pad", "f", query, train, score_args=args, **kw)["all_modules"]
+        assert (27, 32) in calls, calls
+        PairwiseScoreTracker.PAD_PATCH_AXIS = False
+        plain = analyzer.compute_pairwise_scores("nopad", "f", query, train, score_args=args, **kw)["all_modules"]
+    finally:
+        PairwiseScoreTracker.PAD_PATCH_AXIS = True
+        PairwiseScoreTracker._pad_patch_axis = original
+    assert rel(padded, plain) <= 2e-3, rel(padded, plain)
