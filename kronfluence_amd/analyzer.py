@@ -1,6 +1,6 @@
 """``prepare_model`` and ``Analyzer``: the user-facing API (reference ``analyzer.py:20-242`` and the
 orchestration subset of ``computer/{computer,factor_computer,score_computer}.py`` that the EK-FAC
-hot path needs: single data/module partition, explicit batch sizes, skip-if-exists, the same
+hot path needs: data/module partitions with aggregation, automatic batch-size search, skip-if-exists, the same
 ``influence_results/<analysis>/factors_<name>/*.safetensors`` layout).
 
 There is no CPU mode: every stage runs on an MI355X through ``libkronfluence_hip.so``.
@@ -46,7 +46,7 @@ from kronfluence_amd.utils.dataset import (
 )
 from kronfluence_amd.utils.exceptions import FactorsNotFoundError, TrackedModuleNotFoundError
 from kronfluence_amd.utils.save import load_json, save_json
-from kronfluence_amd.utils.state import State
+from kronfluence_amd.utils.state import State, release_memory
 
 
 def prepare_model(model: nn.Module, task: Task) -> nn.Module:
@@ -56,6 +56,13 @@ def prepare_model(model: nn.Module, task: Task) -> nn.Module:
     for tensor in list(model.parameters()) + list(model.buffers()):
         tensor.requires_grad = False
     return wrap_tracked_modules(model=model, task=task)
+
+
+def _is_out_of_memory(exc: Exception) -> bool:
+    if isinstance(exc, torch.cuda.OutOfMemoryError):
+        return True
+    text = str(exc).lower()
+    return isinstance(exc, RuntimeError) and ("out of memory" in text or "hiperroroutofmemory" in text)
 
 
 @dataclass
@@ -149,11 +156,35 @@ class Analyzer:
         return data.DataLoader(dataset=dataset, batch_size=per_device_batch_size, sampler=sampler, drop_last=False,
                                shuffle=False, **dataloader_params)
 
-    @staticmethod
-    def _require_batch_size(value: Optional[int], what: str) -> int:
-        if value is None:
-            raise ValueError(f"`{what}` must be given explicitly (automatic batch-size search is not part of this build).")
-        return value
+    def _reset_memory(self) -> None:
+        from kronfluence_amd.module.tracked_module import ModuleMode
+        from kronfluence_amd.module.utils import set_mode
+
+        self.model.zero_grad(set_to_none=True)
+        set_mode(self.model, ModuleMode.DEFAULT, release_memory=True)
+        release_memory()
+
+    def _find_executable_batch_size(self, probe, start: int) -> int:
+        """Largest batch size (halving from ``start``) for which ``probe(batch_size)`` -- one batch through the stage --
+        does not run out of HBM (reference ``utils/dataset.py:66-101``, ``factor_computer.py:110-157``)."""
+        if self.state.use_distributed:
+            raise NotImplementedError("Automatic batch size search is not supported for multi-GPU setting. "
+                                      "Please manually configure the batch size by passing in `per_device_batch_size`.")
+        batch_size = max(int(start), 0)
+        while True:
+            if batch_size == 0:
+                raise RuntimeError("No executable batch size found, reached zero.")
+            try:
+                self._reset_memory()
+                probe(batch_size)
+            except Exception as exc:  # noqa: BLE001 -- only memory exhaustion is retried
+                if not _is_out_of_memory(exc):
+                    raise
+                batch_size //= 2
+                continue
+            self._reset_memory()
+            self.logger.info(f"Executable batch size determined: {batch_size}.")
+            return batch_size
 
     def _partition_plan(self, total_examples: int, data_partitions: int, module_partitions: int,
                         target_data_partitions, target_module_partitions) -> "_PartitionPlan":
@@ -277,7 +308,6 @@ class Analyzer:
                                 target_data_partitions: Optional[Sequence[int]] = None,
                                 target_module_partitions: Optional[Sequence[int]] = None,
                                 overwrite_output_dir: bool = False) -> None:
-        del initial_per_device_batch_size_attempt
         factor_args = factor_args or FactorArguments()
         out = self.factors_output_dir(factors_name)
         if self.state.is_main_process:
@@ -288,7 +318,7 @@ class Analyzer:
         self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)
         if not FactorConfig.CONFIGS[factor_args.strategy].requires_covariance_matrices:
             return
-        batch_size = self._require_batch_size(per_device_batch_size, "per_device_batch_size")
+        batch_size = per_device_batch_size
         total = len(dataset) if factor_args.covariance_max_examples is None else min(factor_args.covariance_max_examples, len(dataset))
         plan = self._partition_plan(total, factor_args.covariance_data_partitions, factor_args.covariance_module_partitions,
                                     target_data_partitions, target_module_partitions)
@@ -296,6 +326,14 @@ class Analyzer:
         for partition, (start, end), module_names in plan.cells():
             if covariance_matrices_exist(out, partition) and not overwrite_output_dir:
                 continue
+            if batch_size is None:
+                def probe(size: int, names=module_names) -> None:
+                    loader = self._get_dataloader(dataset, size, params, indices=list(range(size)), allow_duplicates=True)
+                    fit_covariance_matrices_with_loader(self.model, self.state, self.task, loader, factor_args,
+                                                        tracked_module_names=names)
+
+                batch_size = self._find_executable_batch_size(
+                    probe, min(initial_per_device_batch_size_attempt, total // factor_args.covariance_data_partitions))
             loader = self._get_dataloader(dataset, batch_size, params, indices=list(range(start, end)), allow_duplicates=False)
             with self._timed("fit_covariance"):
                 _, factors = fit_covariance_matrices_with_loader(self.model, self.state, self.task, loader, factor_args,
@@ -346,7 +384,6 @@ class Analyzer:
                             target_module_partitions: Optional[Sequence[int]] = None,
                             overwrite_output_dir: bool = False,
                             load_from_factors_name: Optional[str] = None) -> None:
-        del initial_per_device_batch_size_attempt
         factor_args = factor_args or FactorArguments()
         out = self.factors_output_dir(factors_name)
         if self.state.is_main_process:
@@ -365,7 +402,7 @@ class Analyzer:
                 raise FactorsNotFoundError(f"Eigendecomposition results not found at `{source}`. "
                                            f"To fit Lambda matrices, call `perform_eigendecomposition` first.")
             eigen = load_eigendecomposition(source)
-        batch_size = self._require_batch_size(per_device_batch_size, "per_device_batch_size")
+        batch_size = per_device_batch_size
         total = len(dataset) if factor_args.lambda_max_examples is None else min(factor_args.lambda_max_examples, len(dataset))
         plan = self._partition_plan(total, factor_args.lambda_data_partitions, factor_args.lambda_module_partitions,
                                     target_data_partitions, target_module_partitions)
@@ -373,6 +410,14 @@ class Analyzer:
         for partition, (start, end), module_names in plan.cells():
             if lambda_matrices_exist(out, partition) and not overwrite_output_dir:
                 continue
+            if batch_size is None:
+                def probe(size: int, names=module_names) -> None:
+                    loader = self._get_dataloader(dataset, size, params, indices=list(range(size)), allow_duplicates=True)
+                    fit_lambda_matrices_with_loader(self.model, self.state, self.task, loader, factor_args, eigen,
+                                                    tracked_module_names=names)
+
+                batch_size = self._find_executable_batch_size(
+                    probe, min(initial_per_device_batch_size_attempt, total // factor_args.lambda_data_partitions))
             loader = self._get_dataloader(dataset, batch_size, params, indices=list(range(start, end)), allow_duplicates=False)
             with self._timed("fit_lambda"):
                 _, factors = fit_lambda_matrices_with_loader(self.model, self.state, self.task, loader, factor_args, eigen,
@@ -447,7 +492,6 @@ class Analyzer:
                                 target_data_partitions: Optional[Sequence[int]] = None,
                                 target_module_partitions: Optional[Sequence[int]] = None,
                                 overwrite_output_dir: bool = False) -> Optional[SCORE_TYPE]:
-        del initial_per_device_train_batch_size_attempt
         score_args = score_args or ScoreArguments()
         out = self.scores_output_dir(scores_name)
         if self.state.is_main_process:
@@ -467,7 +511,7 @@ class Analyzer:
         if not loaded and FactorConfig.CONFIGS[factor_args.strategy].requires_lambda_matrices_for_precondition:
             raise FactorsNotFoundError(f"Factors with name `{factors_name}` are incomplete.")
         params = (dataloader_kwargs or self._dataloader_params).to_dict()
-        train_batch = self._require_batch_size(per_device_train_batch_size, "per_device_train_batch_size")
+        train_batch = per_device_train_batch_size
         if query_indices is not None:
             query_dataset = data.Subset(dataset=query_dataset, indices=query_indices)
         if train_indices is not None:
@@ -475,16 +519,29 @@ class Analyzer:
         plan = self._partition_plan(len(train_dataset), score_args.data_partitions, score_args.module_partitions,
                                     target_data_partitions, target_module_partitions)
         scores = None
+        stage = (compute_pairwise_query_aggregated_scores_with_loaders if score_args.aggregate_query_gradients
+                 else compute_pairwise_scores_with_loaders)
         for partition, (start, end), module_names in plan.cells():
             if pairwise_scores_exist(out, partition) and not overwrite_output_dir:
                 continue
+            if train_batch is None:
+                def probe(size: int, names=module_names) -> None:
+                    # one query batch against one train batch of the candidate size (score_computer.py:141-215)
+                    q_size = min(per_device_query_batch_size, len(query_dataset))
+                    ql = self._get_dataloader(query_dataset, q_size, params, indices=list(range(q_size)), allow_duplicates=True)
+                    tl = self._get_dataloader(train_dataset, size, params, indices=list(range(size)), allow_duplicates=True,
+                                              stack=True)
+                    stage(loaded_factors=loaded, model=self.model, state=self.state, task=self.task, query_loader=ql,
+                          per_device_query_batch_size=q_size, train_loader=tl, score_args=score_args,
+                          factor_args=factor_args, tracked_module_names=names)
+
+                train_batch = self._find_executable_batch_size(
+                    probe, min(initial_per_device_train_batch_size_attempt, len(train_dataset) // score_args.data_partitions))
             query_loader = self._get_dataloader(query_dataset, per_device_query_batch_size, params,
                                                 allow_duplicates=not score_args.aggregate_query_gradients)
             train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=list(range(start, end)),
                                                 allow_duplicates=not score_args.aggregate_train_gradients,
                                                 stack=not score_args.aggregate_train_gradients)
-            stage = (compute_pairwise_query_aggregated_scores_with_loaders if score_args.aggregate_query_gradients
-                     else compute_pairwise_scores_with_loaders)
             with self._timed("compute_pairwise_scores"):
                 scores = stage(
                     loaded_factors=loaded, model=self.model, state=self.state, task=self.task, query_loader=query_loader,
@@ -518,7 +575,6 @@ class Analyzer:
                             target_module_partitions: Optional[Sequence[int]] = None,
                             overwrite_output_dir: bool = False) -> Optional[SCORE_TYPE]:
         """Self-influence scores ``[N]`` (reference ``computer/score_computer.py:558-773``)."""
-        del initial_per_device_train_batch_size_attempt
         score_args = score_args or ScoreArguments()
         out = self.scores_output_dir(scores_name)
         if self.state.is_main_process:
@@ -537,7 +593,7 @@ class Analyzer:
         self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
         loaded = self.load_all_factors(factors_name)
         params = (dataloader_kwargs or self._dataloader_params).to_dict()
-        train_batch = self._require_batch_size(per_device_train_batch_size, "per_device_train_batch_size")
+        train_batch = per_device_train_batch_size
         if train_indices is not None:
             train_dataset = data.Subset(dataset=train_dataset, indices=train_indices)
         plan = self._partition_plan(len(train_dataset), score_args.data_partitions, score_args.module_partitions,
@@ -548,6 +604,15 @@ class Analyzer:
         for partition, (start, end), module_names in plan.cells():
             if self_scores_exist(out, partition) and not overwrite_output_dir:
                 continue
+            if train_batch is None:
+                def probe(size: int, names=module_names) -> None:
+                    tl = self._get_dataloader(train_dataset, size, params, indices=list(range(size)), allow_duplicates=True,
+                                              stack=True)
+                    stage(loaded_factors=loaded, model=self.model, state=self.state, task=self.task, train_loader=tl,
+                          score_args=score_args, factor_args=factor_args, tracked_module_names=names)
+
+                train_batch = self._find_executable_batch_size(
+                    probe, min(initial_per_device_train_batch_size_attempt, len(train_dataset) // score_args.data_partitions))
             train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=list(range(start, end)),
                                                 allow_duplicates=True, stack=True)
             with self._timed("compute_self_scores"):

@@ -35,3 +35,46 @@ def test_pipeline_host_logic_reproduces_reference_goldens(kind, tmp_path, cpu_en
                                               per_device_train_batch_size=spec.train_batch,
                                               score_args=ScoreArguments(damping_factor=None))["all_modules"]
     assert rel(scores, gold["scores/dampNone"]) <= 1e-4, rel(scores, gold["scores/dampNone"])
+
+
+def test_automatic_batch_size_search_halves_on_out_of_memory(tmp_path, cpu_engine, monkeypatch):
+    """``per_device_batch_size=None``: the stage is probed with one batch, halving from the initial attempt until it no
+    longer runs out of memory (reference utils/dataset.py:66-101); results equal an explicit-batch-size run."""
+    from kronfluence_amd import FactorArguments, ScoreArguments, ops
+
+    spec, analyzer, train, query = build("mlp", tmp_path)
+    real_syrk, real_score = ops.syrk_accum, ops.pairwise_score
+    seen = {"cov": [], "score": []}
+
+    def syrk(cov, x, n_rows, *args, **kwargs):
+        seen["cov"].append(n_rows)
+        if n_rows > 20:
+            raise RuntimeError("HIP out of memory. Tried to allocate 1.00 GiB")
+        return real_syrk(cov, x, n_rows, *args, **kwargs)
+
+    def score(scores, col_offset, p, g, a, *args, **kwargs):
+        seen["score"].append(g.shape[0])
+        if g.shape[0] > 10:
+            raise torch.cuda.OutOfMemoryError("HIP out of memory")
+        return real_score(scores, col_offset, p, g, a, *args, **kwargs)
+
+    monkeypatch.setattr(ops, "syrk_accum", syrk)
+    monkeypatch.setattr(ops, "pairwise_score", score)
+    args = FactorArguments(use_empirical_fisher=True)
+    analyzer.fit_all_factors("auto", train, factor_args=args, initial_per_device_batch_size_attempt=64)
+    assert max(seen["cov"]) == 48 and 24 in seen["cov"] and 12 in seen["cov"]  # 64 -> min(64, 48) = 48 -> 24 -> 12
+    got = analyzer.compute_pairwise_scores("auto", "auto", query, train, per_device_query_batch_size=3,
+                                           score_args=ScoreArguments(damping_factor=None),
+                                           initial_per_device_train_batch_size_attempt=32)["all_modules"]
+    assert 32 in seen["score"] and 16 in seen["score"] and 8 in seen["score"]
+    monkeypatch.setattr(ops, "syrk_accum", real_syrk)
+    monkeypatch.setattr(ops, "pairwise_score", real_score)
+    analyzer.fit_all_factors("fixed", train, per_device_batch_size=12, factor_args=args)
+    want = analyzer.compute_pairwise_scores("fixed", "fixed", query, train, per_device_query_batch_size=3,
+                                            per_device_train_batch_size=8,
+                                            score_args=ScoreArguments(damping_factor=None))["all_modules"]
+    assert rel(got, want) <= 1e-5
+    # errors that are not memory exhaustion propagate unchanged
+    monkeypatch.setattr(ops, "syrk_accum", lambda *a, **k: (_ for _ in ()).throw(ValueError("boom")))
+    with pytest.raises(ValueError, match="boom"):
+        analyzer.fit_covariance_matrices("bad", train, factor_args=args)
