@@ -45,6 +45,7 @@ from kronfluence_amd.utils.dataset import (
     DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack, make_indices_partition,
 )
 from kronfluence_amd.utils.exceptions import FactorsNotFoundError, TrackedModuleNotFoundError
+from kronfluence_amd.utils.save import load_file as load_safetensors
 from kronfluence_amd.utils.save import load_json, save_json
 from kronfluence_amd.utils.state import State, release_memory
 
@@ -222,19 +223,23 @@ class Analyzer:
             module_targets=targets(target_module_partitions, module_partitions, "module"),
         )
 
+    @staticmethod
+    def _arguments_from_json(cls, path: Path):
+        """Rebuilds an ``Arguments`` dataclass from its JSON form (dtypes are stored as ``"torch.float32"`` strings)."""
+        return cls(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
+                      for k, v in load_json(path).items()})
+
     def _stored_factor_args(self, factors_name: str) -> FactorArguments:
         stored = self.load_factor_args(factors_name)
         if stored is None:
             raise FactorsNotFoundError(f"Factors with name `{factors_name}` not found at `{self.factors_output_dir(factors_name)}`.")
-        return FactorArguments(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
-                                  for k, v in stored.items()})
+        return stored
 
     def _stored_score_args(self, scores_name: str) -> ScoreArguments:
-        path = self.scores_output_dir(scores_name) / "score_arguments.json"
-        if not path.exists():
+        stored = self.load_score_args(scores_name)
+        if stored is None:
             raise ValueError(f"Arguments for scores with name `{scores_name}` were not found.")
-        return ScoreArguments(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
-                                 for k, v in load_json(path).items()})
+        return stored
 
     @torch.no_grad()
     def _aggregate_factors(self, factors_name: str, data_partitions: int, module_partitions: int, exist_fnc, load_fnc,
@@ -450,9 +455,34 @@ class Analyzer:
                                  initial_per_device_batch_size_attempt=initial_per_device_batch_size_attempt,
                                  dataloader_kwargs=dataloader_kwargs, **common)
 
-    def load_factor_args(self, factors_name: str) -> Optional[Dict]:
+    def load_factor_args(self, factors_name: str) -> Optional[FactorArguments]:
+        """The ``FactorArguments`` the factors were fitted with (reference ``computer/computer.py:335-341``)."""
         path = self.factors_output_dir(factors_name) / "factor_arguments.json"
-        return load_json(path) if path.exists() else None
+        return self._arguments_from_json(FactorArguments, path) if path.exists() else None
+
+    def load_score_args(self, scores_name: str) -> Optional[ScoreArguments]:
+        """The ``ScoreArguments`` the scores were computed with (reference ``computer/computer.py:371-377``)."""
+        path = self.scores_output_dir(scores_name) / "score_arguments.json"
+        return self._arguments_from_json(ScoreArguments, path) if path.exists() else None
+
+    @staticmethod
+    def load_file(path: Union[str, Path]) -> Dict[str, torch.Tensor]:
+        """Loads one ``.safetensors`` file of factors or scores (reference ``analyzer.py:199-220``)."""
+        path = Path(path).resolve() if isinstance(path, str) else path
+        if not path.exists():
+            raise FileNotFoundError(f"File not found: {path}.")
+        return load_safetensors(path)
+
+    @staticmethod
+    def get_module_summary(model: nn.Module) -> str:
+        """Names and reprs of the leaf modules that own parameters -- the candidates for
+        ``Task.get_influence_tracked_modules`` (reference ``analyzer.py:222-242``)."""
+        lines = ["==Model Summary=="]
+        for name, module in model.named_modules():
+            if any(True for _ in module.children()) or not any(True for _ in module.parameters()):
+                continue
+            lines.append(f"Module Name: `{name}`, Module: {repr(module)}")
+        return "\n".join(lines)
 
     def load_covariance_matrices(self, factors_name: str) -> Optional[FACTOR_TYPE]:
         out = self.factors_output_dir(factors_name)
@@ -469,7 +499,7 @@ class Analyzer:
     def load_all_factors(self, factors_name: str) -> FACTOR_TYPE:
         """Everything the strategy needs for preconditioning (reference ``computer/computer.py:387-434``)."""
         stored = self.load_factor_args(factors_name)
-        strategy = stored["strategy"] if stored else "ekfac"
+        strategy = stored.strategy if stored else "ekfac"
         config = FactorConfig.CONFIGS[strategy]
         loaded: FACTOR_TYPE = {}
         if config.requires_covariance_matrices_for_precondition:

@@ -78,3 +78,25 @@ def test_automatic_batch_size_search_halves_on_out_of_memory(tmp_path, cpu_engin
     monkeypatch.setattr(ops, "syrk_accum", lambda *a, **k: (_ for _ in ()).throw(ValueError("boom")))
     with pytest.raises(ValueError, match="boom"):
         analyzer.fit_covariance_matrices("bad", train, factor_args=args)
+
+
+def test_analyzer_bookkeeping_helpers(tmp_path, cpu_engine):
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments
+
+    spec, analyzer, train, query = build("mlp", tmp_path)
+    assert analyzer.load_factor_args("f") is None and analyzer.load_score_args("s") is None
+    args = FactorArguments(use_empirical_fisher=True, lambda_dtype=torch.bfloat16)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=16, factor_args=args)
+    assert analyzer.load_factor_args("f") == args
+    sargs = ScoreArguments(damping_factor=None, score_dtype=torch.bfloat16)
+    analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=3, per_device_train_batch_size=12,
+                                     score_args=sargs)
+    assert analyzer.load_score_args("s") == sargs
+    with pytest.raises(ValueError):  # same name, different arguments, no overwrite
+        analyzer.compute_self_scores("s", "f", train, per_device_train_batch_size=12, score_args=ScoreArguments())
+    stored = Analyzer.load_file(analyzer.scores_output_dir("s") / "pairwise_scores.safetensors")
+    assert stored["all_modules"].shape == (spec.n_query, spec.n_train) and stored["all_modules"].dtype == torch.bfloat16
+    with pytest.raises(FileNotFoundError):
+        Analyzer.load_file(str(tmp_path / "missing.safetensors"))
+    summary = Analyzer.get_module_summary(fx.make_model("conv"))
+    assert summary.startswith("==Model Summary==") and "Module Name: `0`" in summary and "ReLU" not in summary
