@@ -160,7 +160,35 @@ def run_widen(kind: str, out_path: str) -> None:
     print(f"{out_path}: {len(out)} tensors: " + ", ".join(f"{k}{tuple(v.shape)}" for k, v in out.items() if "/" not in k or k.endswith(("scores", "self"))))
 
 
+def run_presets(out_path: str) -> None:
+    """Field values of every argument preset of ``kronfluence/utils/common`` (plus the dataclass defaults)."""
+    import dataclasses
+    import json
+
+    from kronfluence.utils.common import factor_arguments as rf, score_arguments as rs
+
+    def plain(obj):
+        return {k: (str(v) if isinstance(v, torch.dtype) else v) for k, v in dataclasses.asdict(obj).items()}
+
+    out = {"FactorArguments()": plain(FactorArguments()), "ScoreArguments()": plain(ScoreArguments())}
+    for module, tag in ((rf, "factor"), (rs, "score")):
+        for name in sorted(dir(module)):
+            if name.endswith("_arguments"):
+                out[f"{tag}/{name}()"] = plain(getattr(module, name)())
+    for name in sorted(dir(rs)):
+        if name.endswith("_arguments"):
+            out[f"score/{name}(query_gradient_low_rank=32)"] = plain(getattr(rs, name)(query_gradient_low_rank=32))
+    out["factor/extreme_reduce_memory_factor_arguments(module_partitions=3)"] = plain(
+        rf.extreme_reduce_memory_factor_arguments(module_partitions=3))
+    with open(out_path, "w", encoding="utf-8") as handle:
+        json.dump(out, handle, indent=1, sort_keys=True)
+    print(f"{out_path}: {len(out)} presets")
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "presets":
+        run_presets(os.path.join(HERE, "presets.json"))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "widen":
         torch.manual_seed(0)
         for kind in fx.FIXTURES:

@@ -144,3 +144,28 @@ def test_hooks_fail_loudly_without_gpu():
     set_mode(model, ModuleMode.COVARIANCE)
     with pytest.raises(KfError):
         model(torch.randn(4, 12)).sum().backward()
+
+
+def test_argument_defaults_and_presets_equal_the_references():
+    """tests/golden/presets.json holds the field values of the reference's dataclass defaults and of every preset in
+    ``kronfluence/utils/common`` (generated by tests/golden/make_golden.py presets)."""
+    import dataclasses
+    import json
+    import os
+
+    from kronfluence_amd.utils.common import factor_arguments as mf, score_arguments as ms
+
+    with open(os.path.join(os.path.dirname(__file__), "golden", "presets.json"), encoding="utf-8") as handle:
+        gold = json.load(handle)
+
+    def plain(obj):
+        return {k: (str(v) if isinstance(v, torch.dtype) else v) for k, v in dataclasses.asdict(obj).items()}
+
+    assert plain(FactorArguments()) == gold.pop("FactorArguments()")
+    assert plain(ScoreArguments()) == gold.pop("ScoreArguments()")
+    assert len(gold) >= 19
+    for key, want in gold.items():
+        tag, call = key.split("/", 1)
+        module = mf if tag == "factor" else ms
+        got = eval(f"module.{call}", {"module": module})  # noqa: S307 -- keys are our own fixture's function calls
+        assert plain(got) == want, key
