@@ -96,20 +96,29 @@ class PairwiseScoreTracker(BaseTracker):
             yield start, dense_queries([left[start:start + step], right[start:start + step]], score_dtype)
 
     _tiled = None  # (source tensor, k-tile-major bf16 copy) of the held query gradients
-    # bf16 layers whose patch axis is not a multiple of 8 (a first conv layer: 3*3*3 = 27) would fall back to the fp32
-    # engine for the per-sample gradients (7 TFLOP/s on ResNet-9's first layer): zero-pad that axis of both the
-    # activations and the held query gradients to the next multiple of 8 instead -- the contraction is unchanged.
+    # bf16 layers whose augmented input axis I' is not a multiple of 8 -- a first conv layer (3*3*3 = 27 patch columns),
+    # or ANY Linear with a bias applied to sequences (I' = I + 1: BERT / GPT-2 shapes) -- would fall back to the fp32
+    # engine for the per-sample gradients and the score contraction (about 8x slower than the bf16 MFMA engine).
+    # Instead that axis is zero-padded to the next multiple of 8 on both sides of the contraction (the bias column of
+    # ones is materialised first): <P_q, g_n> is unchanged, P is padded once per train pass.
     PAD_PATCH_AXIS = True
     _padded = None  # (source tensor, zero-padded copy) of the held query gradients
 
     def _pad_patch_axis(self, block: torch.Tensor, a: torch.Tensor, g: torch.Tensor, ones: bool):
-        pad = (-a.shape[-1]) % 8
-        if (not self.PAD_PATCH_AXIS or pad == 0 or ones or g.shape[1] == 1 or block.dtype != torch.bfloat16
-                or a.dtype != torch.bfloat16 or g.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0):
-            return block, a
+        """-> ``(block, a, ones)`` with ``a`` and the last axis of ``block`` padded when that unlocks the bf16 engine."""
+        width = a.shape[-1] + int(ones)
+        pad = (-width) % 8
+        if (not self.PAD_PATCH_AXIS or pad == 0 or g.shape[1] == 1 or block.dtype != torch.bfloat16
+                or a.dtype != torch.bfloat16 or g.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0
+                or block.shape[-1] != width):
+            return block, a, ones
         if self._padded is None or self._padded[0] is not block:
             self._padded = (block, torch.nn.functional.pad(block, (0, pad)).contiguous())
-        return self._padded[1], torch.nn.functional.pad(a, (0, pad))
+        if ones:
+            a = torch.cat([a, a.new_ones(a.shape[:-1] + (1,)), a.new_zeros(a.shape[:-1] + (pad,))], dim=-1)
+        else:
+            a = torch.nn.functional.pad(a, (0, pad))
+        return self._padded[1], a, False
 
     def _tiled_queries(self, preconditioned: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool):
         """k-tile-major copy of the bf16 query gradients, built once per train pass (see
@@ -163,9 +172,9 @@ class PairwiseScoreTracker(BaseTracker):
                     ones = False
                 for first, block in self._query_blocks(preconditioned):
                     rows = scores[first:first + block.shape[0]]
-                    block, a_in = self._pad_patch_axis(block, a, g, ones)
-                    ops.pairwise_score(rows, offset, block, g, a_in, ones, scale=module.gradient_scale,
-                                       p_tiled=self._tiled_queries(block, g, a_in, ones))
+                    block, a_in, ones_in = self._pad_patch_axis(block, a, g, ones)
+                    ops.pairwise_score(rows, offset, block, g, a_in, ones_in, scale=module.gradient_scale,
+                                       p_tiled=self._tiled_queries(block, g, a_in, ones_in))
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()

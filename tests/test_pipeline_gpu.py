@@ -313,13 +313,66 @@ def test_bf16_conv_with_odd_patch_axis_is_padded_not_demoted(tmp_path):
 
     def spy(self, block, a, g, ones):
         out = original(self, block, a, g, ones)
-        calls.append((a.shape[-1], out[1].shape[-1]))
+        calls.append((a.shape[-1] + int(ones), out[1].shape[-1]))
         return out
 
     PairwiseScoreTracker._pad_patch_axis = spy
     try:
         padded = analyzer.compute_pairwise_scores("pad", "f", query, train, score_args=args, **kw)["all_modules"]
         assert (27, 32) in calls, calls
+        PairwiseScoreTracker.PAD_PATCH_AXIS = False
+        plain = analyzer.compute_pairwise_scores("nopad", "f", query, train, score_args=args, **kw)["all_modules"]
+    finally:
+        PairwiseScoreTracker.PAD_PATCH_AXIS = True
+        PairwiseScoreTracker._pad_patch_axis = original
+    assert rel(padded, plain) <= 2e-3, rel(padded, plain)
+
+
+
+def test_bf16_sequence_linear_with_bias_is_padded_not_demoted(tmp_path):
+    """Linear layers WITH bias on ``[b, T, d]`` activations (BERT / GPT-2 shapes: ``I' = I + 1`` is odd) under bf16: the
+    ones column is materialised and the axis padded to a multiple of 8 so the bf16 MFMA engine applies; same scores as
+    the fp32-engine fallback on the same bf16 data."""
+    from torch import nn
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+
+    class Tiny(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.embed = nn.Embedding(20, 16)
+            self.fc1 = nn.Linear(16, 24)
+            self.fc2 = nn.Linear(24, 16)
+            self.head = nn.Linear(16, 24)
+
+        def forward(self, ids):
+            h = self.embed(ids)
+            h = h + self.fc2(torch.tanh(self.fc1(h)))
+            return self.head(h)[..., :20]
+
+    torch.manual_seed(0)
+    spec = fx.FIXTURES["seq"]
+    task = make_task("seq")
+    analyzer = Analyzer("t", prepare_model(Tiny(), task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    train = data.TensorDataset(*fx.make_data("seq", spec.n_train, seed=1))
+    query = data.TensorDataset(*fx.make_data("seq", spec.n_query, seed=2))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=spec.factor_batch,
+                             factor_args=FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16))
+    kw = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
+    args = ScoreArguments(damping_factor=None, amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16)
+    calls = []
+    original = PairwiseScoreTracker._pad_patch_axis
+
+    def spy(self, block, a, g, ones):
+        out = original(self, block, a, g, ones)
+        calls.append((a.shape[-1] + int(ones), out[1].shape[-1], out[2]))
+        return out
+
+    PairwiseScoreTracker._pad_patch_axis = spy
+    try:
+        padded = analyzer.compute_pairwise_scores("pad", "f", query, train, score_args=args, **kw)["all_modules"]
+        assert (17, 24, False) in calls and (25, 32, False) in calls, calls
         PairwiseScoreTracker.PAD_PATCH_AXIS = False
         plain = analyzer.compute_pairwise_scores("nopad", "f", query, train, score_args=args, **kw)["all_modules"]
     finally:
