@@ -169,7 +169,8 @@ def _pipeline_two_ranks(rank, world, out_dir):
     results = {}
     for name, kw in (("plain", {}), ("aggq", dict(aggregate_query_gradients=True)),
                      ("aggt", dict(aggregate_train_gradients=True)), ("tok", dict(compute_per_token_scores=True)),
-                     ("parts", dict(data_partitions=2, module_partitions=2))):
+                     ("parts", dict(data_partitions=2, module_partitions=2)),
+                     ("lowrank", dict(query_gradient_low_rank=4, query_gradient_accumulation_steps=2))):
         out = analyzer.compute_pairwise_scores(name, "f", query, train, score_args=ScoreArguments(damping_factor=None, **kw),
                                                **common)
         if rank == 0:
@@ -212,7 +213,8 @@ def test_whole_stages_on_two_ranks_match_single_process(tmp_path, cpu_engine):
     assert close(got["plain"], plain) and close(got["parts"], plain)
     assert plain.shape == (spec.n_query - 1, spec.n_train - 1)
     for name, kw in (("aggq", dict(aggregate_query_gradients=True)), ("aggt", dict(aggregate_train_gradients=True)),
-                     ("tok", dict(compute_per_token_scores=True))):
+                     ("tok", dict(compute_per_token_scores=True)),
+                     ("lowrank", dict(query_gradient_low_rank=4))):  # factor pairs gathered + interleaved across ranks
         want = analyzer.compute_pairwise_scores(name, "f", query, train, score_args=ScoreArguments(damping_factor=None, **kw),
                                                 **common)["all_modules"]
         assert close(got[name], want, 1e-4), name

@@ -100,3 +100,23 @@ def test_analyzer_bookkeeping_helpers(tmp_path, cpu_engine):
         Analyzer.load_file(str(tmp_path / "missing.safetensors"))
     summary = Analyzer.get_module_summary(fx.make_model("conv"))
     assert summary.startswith("==Model Summary==") and "Module Name: `0`" in summary and "ReLU" not in summary
+
+
+# ---- GPU scenarios re-run for their HOST logic (the arithmetic below the ops boundary is the stand-in's) -----------
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_stage_isolated_scores_and_batching_invariances_host_logic(kind, tmp_path, cpu_engine):
+    from test_pipeline_gpu import test_stage_isolated_scores_on_reference_factors as scenario
+
+    scenario(kind, tmp_path)
+
+
+def test_shared_parameters_host_logic(tmp_path, cpu_engine):
+    from test_pipeline_gpu import test_shared_parameters_factors_match_reference_and_scores_match_autograd as scenario
+
+    scenario(tmp_path)
+
+
+def test_conv8_fp32_host_logic(tmp_path, cpu_engine):
+    from test_pipeline_gpu import test_conv8_fp32_matches_reference_goldens as scenario
+
+    scenario(tmp_path)
