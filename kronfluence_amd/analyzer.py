@@ -304,6 +304,24 @@ class Analyzer:
             else:
                 save_json(arguments.to_dict(), path)
 
+    def _save_dataset_metadata(self, name: str, dataset: data.Dataset, output_dir: Path,
+                               indices: Optional[Sequence[int]] = None, overwrite: bool = False) -> None:
+        """``<name>_dataset_metadata.json`` next to the results (type, size, index subset): a later call on the same
+        output directory with a different dataset is an error unless overwriting (reference ``computer.py:160-191``)."""
+        if not self.state.is_main_process:
+            return
+        path = output_dir / f"{name}_dataset_metadata.json"
+        metadata = {"type": type(dataset).__name__, "dataset_size": len(dataset),
+                    "indices": None if indices is None else list(indices)}
+        if path.exists() and not overwrite:
+            stored = load_json(path)
+            if stored != metadata:
+                raise ValueError("Attempting to use the dataset that differs from the one already saved. Please set "
+                                 f"`overwrite_output_dir=True` to overwrite existing experiment.\nNew metadata: {metadata}."
+                                 f"\nSaved metadata: {stored}.")
+        else:
+            save_json(metadata, path)
+
     # -- factors -----------------------------------------------------------------------------------
     def fit_covariance_matrices(self, factors_name: str, dataset: data.Dataset,
                                 per_device_batch_size: Optional[int] = None,
@@ -323,6 +341,7 @@ class Analyzer:
         self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)
         if not FactorConfig.CONFIGS[factor_args.strategy].requires_covariance_matrices:
             return
+        self._save_dataset_metadata("covariance", dataset, out, overwrite=overwrite_output_dir)
         batch_size = per_device_batch_size
         total = len(dataset) if factor_args.covariance_max_examples is None else min(factor_args.covariance_max_examples, len(dataset))
         plan = self._partition_plan(total, factor_args.covariance_data_partitions, factor_args.covariance_module_partitions,
@@ -400,6 +419,7 @@ class Analyzer:
         config = FactorConfig.CONFIGS[factor_args.strategy]
         if not config.requires_lambda_matrices:
             return
+        self._save_dataset_metadata("lambda", dataset, out, overwrite=overwrite_output_dir)
         eigen = None
         if config.requires_eigendecomposition_for_lambda:
             source = self.factors_output_dir(load_from_factors_name) if load_from_factors_name else out
@@ -542,6 +562,8 @@ class Analyzer:
             raise FactorsNotFoundError(f"Factors with name `{factors_name}` are incomplete.")
         params = (dataloader_kwargs or self._dataloader_params).to_dict()
         train_batch = per_device_train_batch_size
+        self._save_dataset_metadata("query", query_dataset, out, query_indices, overwrite_output_dir)
+        self._save_dataset_metadata("train", train_dataset, out, train_indices, overwrite_output_dir)
         if query_indices is not None:
             query_dataset = data.Subset(dataset=query_dataset, indices=query_indices)
         if train_indices is not None:
@@ -624,6 +646,7 @@ class Analyzer:
         loaded = self.load_all_factors(factors_name)
         params = (dataloader_kwargs or self._dataloader_params).to_dict()
         train_batch = per_device_train_batch_size
+        self._save_dataset_metadata("train", train_dataset, out, train_indices, overwrite_output_dir)
         if train_indices is not None:
             train_dataset = data.Subset(dataset=train_dataset, indices=train_indices)
         plan = self._partition_plan(len(train_dataset), score_args.data_partitions, score_args.module_partitions,
