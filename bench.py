@@ -16,6 +16,9 @@ Workloads (synthetic random-weight models of the BASELINE.json layer shapes, SUR
   resnet9    configs[1] (DEFAULT): CIFAR-10 ResNet-9 (Conv2d tracked), 50 000 train x 1 000 query,
              bf16 autocast, bf16 query gradients (the reference's all_low_precision preset)
   mnist_mlp  configs[0]: 784-1024-1024-1024-10 MLP, 1 000 train x 100 query, fp32
+  gpt2_small GPT-2-small-shaped decoder (12 x [c_attn 768->2304, c_proj 768->768, c_fc 768->3072, c_proj 3072->768],
+             nn.Linear with bias, T = 512; D = 85.0 M), bf16; scaled down to 2 048 train x 256 query sequences
+             (the reference's WikiText-2 example: 4.6 k x 481); only the 48 block Linears are tracked, as there
 
 The ``roofline`` object times the dominant kernel launches (the pairwise-score contraction) with HIP
 events on the launch stream inside the timed region; ``cpu_baseline`` times the CPU oracle
@@ -86,6 +89,85 @@ def resnet9() -> nn.Module:
     )
 
 
+class _GPT2Block(nn.Module):
+    def __init__(self, width: int, heads: int) -> None:
+        super().__init__()
+        self.heads = heads
+        self.ln_1, self.ln_2 = nn.LayerNorm(width), nn.LayerNorm(width)
+        self.c_attn = nn.Linear(width, 3 * width)
+        self.attn_proj = nn.Linear(width, width)
+        self.c_fc = nn.Linear(width, 4 * width)
+        self.mlp_proj = nn.Linear(4 * width, width)
+
+    def forward(self, x):
+        b, t, d = x.shape
+        q, k, v = self.c_attn(self.ln_1(x)).split(d, dim=-1)
+        q, k, v = (z.reshape(b, t, self.heads, d // self.heads).transpose(1, 2) for z in (q, k, v))
+        y = F.scaled_dot_product_attention(q, k, v, is_causal=True).transpose(1, 2).reshape(b, t, d)
+        x = x + self.attn_proj(y)
+        return x + self.mlp_proj(F.gelu(self.c_fc(self.ln_2(x)), approximate="tanh"))
+
+
+class GPT2(nn.Module):
+    """GPT-2-shaped decoder with ``nn.Linear`` layers (the reference's example converts HF's ``Conv1D`` to ``Linear``
+    first, examples/wikitext/pipeline.py:13-39); random init, no hub access."""
+
+    def __init__(self, layers: int = 12, width: int = 768, heads: int = 12, vocab: int = 50257, positions: int = 512) -> None:
+        super().__init__()
+        self.wte, self.wpe = nn.Embedding(vocab, width), nn.Embedding(positions, width)
+        self.h = nn.ModuleList(_GPT2Block(width, heads) for _ in range(layers))
+        self.ln_f = nn.LayerNorm(width)
+        self.lm_head = nn.Linear(width, vocab, bias=False)
+
+    def forward(self, ids):
+        x = self.wte(ids) + self.wpe(torch.arange(ids.shape[1], device=ids.device))
+        for block in self.h:
+            x = block(x)
+        return self.lm_head(self.ln_f(x))
+
+    def tracked_names(self) -> List[str]:
+        return [f"h.{i}.{name}" for i in range(len(self.h)) for name in ("c_attn", "attn_proj", "c_fc", "mlp_proj")]
+
+
+def gpt2_small() -> nn.Module:
+    return GPT2()
+
+
+def lm_loss(model, batch) -> torch.Tensor:
+    """Summed next-token cross-entropy (examples/wikitext/analyze.py:85-103)."""
+    ids = batch[0]
+    logits = model(ids)[:, :-1]
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), ids[:, 1:].reshape(-1), reduction="sum")
+
+
+def make_lm_task(tracked: List[str]):
+    from kronfluence_amd import Task
+
+    class LanguageModelingTask(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            if not sample:
+                return lm_loss(model, batch)
+            ids = batch[0]
+            logits = model(ids)[:, :-1]
+            flat = logits.reshape(-1, logits.shape[-1])
+            with torch.no_grad():
+                drawn = torch.multinomial(torch.softmax(flat.detach().float(), dim=-1), 1).flatten()
+            return F.cross_entropy(flat.float(), drawn, reduction="sum")
+
+        def compute_measurement(self, batch, model):
+            return lm_loss(model, batch)
+
+        def get_influence_tracked_modules(self):
+            return tracked
+
+    return LanguageModelingTask()
+
+
+def synth_tokens(spec, n: int, seed: int, device) -> Tuple[torch.Tensor, ...]:
+    gen = torch.Generator().manual_seed(seed)
+    return (torch.randint(0, spec["vocab"], (n, spec["tokens"]), generator=gen).to(device),)
+
+
 WORKLOADS = {
     "mnist_mlp": dict(model=mnist_mlp, shape=(1, 28, 28), classes=10, n_train=1000, n_query=100, amp=None,
                       factor_batch=1000, train_batch=1000, query_batch=100,
@@ -93,6 +175,9 @@ WORKLOADS = {
     "resnet9": dict(model=resnet9, shape=(3, 32, 32), classes=10, n_train=50_000, n_query=1000, amp=torch.bfloat16,
                     factor_batch=1000, train_batch=1000, query_batch=250,
                     cpu_sample=dict(n_train=192, n_query=32, n_fit=64)),
+    "gpt2_small": dict(model=gpt2_small, lm=True, vocab=50257, tokens=512, n_train=2048, n_query=256, amp=torch.bfloat16,
+                       factor_batch=16, train_batch=16, query_batch=16,
+                       cpu_sample=dict(n_train=8, n_query=2, n_fit=4)),
 }
 
 
@@ -166,10 +251,13 @@ def main() -> None:
     n_query = args.n_query or spec["n_query"]
 
     torch.manual_seed(0)
-    task = make_task()
-    model = prepare_model(spec["model"](), task).to(dev)
-    train = synth(spec, n_train, 1, dev)
-    query = synth(spec, n_query, 2, dev)
+    raw_model = spec["model"]()
+    is_lm = bool(spec.get("lm"))
+    task = make_lm_task(raw_model.tracked_names()) if is_lm else make_task()
+    model = prepare_model(raw_model, task).to(dev)
+    make_data = synth_tokens if is_lm else synth
+    train = make_data(spec, n_train, 1, dev)
+    query = make_data(spec, n_query, 2, dev)
     amp = spec["amp"]
     low = amp == torch.bfloat16  # the reference's all_low_precision preset: bf16 factors / gradients
     # (covariances stay fp32: at least the reference's precision, and the fp64 eigensolver converges faster on them)
@@ -292,13 +380,13 @@ def main() -> None:
         cpu_model = spec["model"]()
         cpu_model.load_state_dict({k.replace(".original_module", ""): v.cpu() for k, v in model.state_dict().items()
                                    if "_constant" not in k})
-        engine = ref.OracleEngine(cpu_model)
-        loss = lambda m, b: F.cross_entropy(m(b[0]), b[1], reduction="sum")  # noqa: E731
-        ctrain = (train[0][:ct].cpu(), train[1][:ct].cpu())
-        cquery = (query[0][:cq].cpu(), query[1][:cq].cpu())
+        engine = ref.OracleEngine(cpu_model, module_names=raw_model.tracked_names() if is_lm else None)
+        loss = lm_loss if is_lm else (lambda m, b: F.cross_entropy(m(b[0]), b[1], reduction="sum"))  # noqa: E731
+        ctrain = tuple(t[:ct].cpu() for t in train)
+        cquery = tuple(t[:cq].cpu() for t in query)
 
         def chunks(d, bs):
-            return [(d[0][i:i + bs], d[1][i:i + bs]) for i in range(0, d[0].shape[0], bs)]
+            return [tuple(t[i:i + bs] for t in d) for i in range(0, d[0].shape[0], bs)]
 
         cpu_eig = {k: {n: v.float() for n, v in d.items()} for k, d in eig.items()}
         cpu_lam = {k: {n: (v.float() if v.is_floating_point() else v) for n, v in d.items()} for k, d in lam.items()}
@@ -307,7 +395,7 @@ def main() -> None:
         cscores = engine.pairwise_scores(chunks(cquery, min(cq, 100)), chunks(ctrain, tb), loss, loss, cpu_eig, cpu_lam, 1e-8)
         cpu_pair_s = time.perf_counter() - t0
         nf = min(cs["n_fit"], n_train)
-        fit_sample = (train[0][:nf].cpu(), train[1][:nf].cpu())
+        fit_sample = tuple(t[:nf].cpu() for t in train)
         t0 = time.perf_counter()
         ccov = engine.fit_covariance(chunks(fit_sample, tb), loss)
         engine.fit_lambda(chunks(fit_sample, tb), loss, cpu_eig)

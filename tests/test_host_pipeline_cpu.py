@@ -147,3 +147,39 @@ def test_dataset_metadata_guards_the_output_directory(tmp_path, cpu_engine):
     with pytest.raises(ValueError, match="differs from the one already saved"):
         analyzer.fit_lambda_matrices("f", shorter, per_device_batch_size=10, factor_args=args)
     analyzer.fit_lambda_matrices("f", shorter, per_device_batch_size=10, factor_args=args, overwrite_output_dir=True)
+
+
+def test_gpt2_shaped_workload_host_logic_matches_oracle(tmp_path, cpu_engine):
+    """bench.py's GPT-2-shaped decoder (tiny instance): only the block Linears are tracked (Task.get_influence_tracked_modules),
+    sequence activations with bias, causal attention in between -- scores against the CPU oracle on the same weights."""
+    import bench
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from oracle import ekfac_ref as ref
+    from torch.utils import data
+
+    torch.manual_seed(0)
+    raw = bench.GPT2(layers=2, width=16, heads=2, vocab=40, positions=8)
+    twin = bench.GPT2(layers=2, width=16, heads=2, vocab=40, positions=8)
+    twin.load_state_dict(raw.state_dict())
+    names = raw.tracked_names()
+    task = bench.make_lm_task(names)
+    spec = dict(vocab=40, tokens=8)
+    train, query = bench.synth_tokens(spec, 24, 1, "cpu"), bench.synth_tokens(spec, 4, 2, "cpu")
+    analyzer = Analyzer("t", prepare_model(raw, task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    from kronfluence_amd.module.utils import get_tracked_module_names
+    assert get_tracked_module_names(analyzer.model) == names and len(names) == 8
+    args = FactorArguments(use_empirical_fisher=True)
+    analyzer.fit_all_factors("f", data.TensorDataset(*train), per_device_batch_size=8, factor_args=args)
+    got = analyzer.compute_pairwise_scores("s", "f", data.TensorDataset(*query), data.TensorDataset(*train),
+                                           per_device_query_batch_size=2, per_device_train_batch_size=6,
+                                           score_args=ScoreArguments(damping_factor=None))["all_modules"]
+    engine = ref.OracleEngine(twin.double(), module_names=names)
+    chunks = lambda d, bs: [tuple(t[i:i + bs] for t in d) for i in range(0, d[0].shape[0], bs)]  # noqa: E731
+    cov = engine.fit_covariance(chunks(train, 8), bench.lm_loss)
+    eig = engine.eigendecomposition(cov)
+    lam = engine.fit_lambda(chunks(train, 8), bench.lm_loss, eig)
+    want = engine.pairwise_scores(chunks(query, 2), chunks(train, 6), bench.lm_loss, bench.lm_loss, eig, lam, None)
+    mine = analyzer.load_covariance_matrices("f")
+    for module in names:
+        assert rel(mine["activation_covariance"][module], cov["activation_covariance"][module]) <= 1e-5, module
+    assert got.shape == (4, 24) and rel(got, want) <= 2e-3, rel(got, want)
