@@ -1,4 +1,10 @@
-"""Tracker base: per-``ModuleMode`` hook logic of a ``TrackedModule`` (reference ``tracker/base.py``)."""
+"""Tracker base: the per-``ModuleMode`` hook logic of a ``TrackedModule``.
+
+One tracker object exists per (module, mode).  The protocol -- ``register_hooks`` ... ``release_memory`` -- carries the
+reference's method names (``module/tracker/base.py:8-88``) because ``TrackedModule`` and the model-wide helpers of
+``module/utils.py`` dispatch on them; everything else here (the activation stack shared by the forward and backward
+hooks of one iteration) is this engine's own plumbing.
+"""
 
 from __future__ import annotations
 
@@ -8,60 +14,79 @@ import torch
 from torch.utils.hooks import RemovableHandle
 
 
+def _remove_all(handles: List[RemovableHandle]) -> List[RemovableHandle]:
+    for handle in reversed(handles):
+        handle.remove()
+    return []
+
+
 class BaseTracker:
     def __init__(self, module: "torch.nn.Module") -> None:
         self.module = module
-        self.registered_hooks: List[RemovableHandle] = []
-        self.cached_hooks: List[RemovableHandle] = []
+        self.registered_hooks: List[RemovableHandle] = []   # forward hooks, alive while the mode is active
+        self.cached_hooks: List[RemovableHandle] = []       # tensor (backward) hooks of the current iteration
         self.cached_activations: Optional[Union[List[torch.Tensor], torch.Tensor]] = None
         self.cached_per_sample_gradient: Optional[torch.Tensor] = None
 
+    # -- protocol, overridden per mode ---------------------------------------------------------------------
+    def register_hooks(self) -> None:
+        """Install the mode's forward hook(s) on the wrapped module."""
+
+    def finalize_iteration(self) -> None:
+        """After one forward/backward: consume what the hooks accumulated (shared-parameter sums)."""
+
+    def exist(self) -> bool:
+        """Whether the mode's result is present in ``module.storage``."""
+        return False
+
+    def synchronize(self, num_processes: int) -> None:
+        """Exchange the mode's result between ranks."""
+
+    def truncate(self, keep_size: int) -> None:
+        """Drop the wrap-around padding rows of the last distributed query batch."""
+
+    def accumulate_iterations(self) -> None:
+        """Move one iteration's result into the multi-iteration accumulator."""
+
+    def finalize_all_iterations(self) -> None:
+        """After the last iteration of a pass."""
+
+    def release_memory(self) -> None:
+        """Free everything the mode keeps in ``module.storage``."""
+
+    # -- shared plumbing ---------------------------------------------------------------------------------------
     def release_hooks(self) -> None:
         self.clear_all_cache()
-        for handle in reversed(self.registered_hooks):
-            handle.remove()
-        self.registered_hooks = []
+        self.registered_hooks = _remove_all(self.registered_hooks)
 
     def clear_all_cache(self) -> None:
-        self.cached_activations, self.cached_per_sample_gradient = None, None
-        for handle in reversed(self.cached_hooks):
-            handle.remove()
-        self.cached_hooks = []
+        self.cached_activations = None
+        self.cached_per_sample_gradient = None
+        self.cached_hooks = _remove_all(self.cached_hooks)
 
     def _raise_cache_not_found_exception(self) -> None:
         raise RuntimeError(
-            f"Module '{self.module.name}' has no cached activations. This can occur if:\n"
-            f"1. The module was not used during the forward pass, or\n"
-            f"2. The module was encountered multiple times in the forward pass.\n"
-            f"For case 2, set 'has_shared_parameters=True' to enable parameter sharing."
+            f"No cached activation for module '{self.module.name}' when its backward hook fired. Either the module "
+            "did not take part in the forward pass, or it ran more than once per forward pass -- in that case enable "
+            "`FactorArguments.has_shared_parameters` so that activations are stacked per use."
         )
 
-    def _take_activation(self) -> torch.Tensor:
-        """Pops the activation cached by the forward hook (LIFO when parameters are shared)."""
-        if self.cached_activations is None:
-            self._raise_cache_not_found_exception()
-        if isinstance(self.cached_activations, list):
-            if not self.cached_activations:
-                self._raise_cache_not_found_exception()
-            return self.cached_activations.pop()
-        activation, self.cached_activations = self.cached_activations, None
-        return activation
-
     def _cache_activation(self, activation: torch.Tensor) -> None:
-        if self.module.factor_args.has_shared_parameters:
-            if self.cached_activations is None:
-                self.cached_activations = []
-            self.cached_activations.append(activation)
-        else:
+        """Forward hook side: one slot, or a LIFO stack when the module's parameters are shared between uses."""
+        if not self.module.factor_args.has_shared_parameters:
             self.cached_activations = activation
+        elif self.cached_activations is None:
+            self.cached_activations = [activation]
+        else:
+            self.cached_activations.append(activation)
 
-    # -- overridable protocol (names as in the reference) ---------------------------------------
-    def register_hooks(self) -> None: ...
-    def finalize_iteration(self) -> None: ...
-    def exist(self) -> bool:
-        return False
-    def synchronize(self, num_processes: int) -> None: ...
-    def truncate(self, keep_size: int) -> None: ...
-    def accumulate_iterations(self) -> None: ...
-    def finalize_all_iterations(self) -> None: ...
-    def release_memory(self) -> None: ...
+    def _take_activation(self) -> torch.Tensor:
+        """Backward hook side: the activation of the use whose gradient just arrived (last in, first out)."""
+        held = self.cached_activations
+        if isinstance(held, list):
+            if held:
+                return held.pop()
+        elif held is not None:
+            self.cached_activations = None
+            return held
+        self._raise_cache_not_found_exception()
