@@ -183,6 +183,37 @@ def ekfac_precondition(g: torch.Tensor, q_a: torch.Tensor, q_g: torch.Tensor, la
     return torch.matmul(q_g, torch.matmul(rotated, q_a.t()))
 
 
+def kfac_inverse_lambda(evals_a: torch.Tensor, evals_g: torch.Tensor, damping: Optional[float],
+                        out_dtype: torch.dtype) -> torch.Tensor:
+    """factor/config.py:264-276 (K-FAC ``prepare``) -- ``1 / (lambda_G (x) lambda_A + damping)``, fp64."""
+    work = torch.kron(evals_a.to(dtype=LAMBDA_DTYPE).unsqueeze(0), evals_g.to(dtype=LAMBDA_DTYPE).unsqueeze(-1))
+    if damping is None:
+        damping = HEURISTIC_DAMPING_SCALE * torch.mean(work)
+    work.add_(damping)
+    work.reciprocal_()
+    return work.to(dtype=out_dtype).contiguous()
+
+
+def diagonal_lambda_update(lam: torch.Tensor, psg: torch.Tensor) -> None:
+    """module/tracker/factor.py:227-229 -- without an eigenbasis Lambda accumulates the squared gradient itself."""
+    lam.add_(psg.square().sum(dim=0))
+
+
+def precondition_with_strategy(strategy: str, g: torch.Tensor, q_a: Optional[torch.Tensor], q_g: Optional[torch.Tensor],
+                               lam_inv: Optional[torch.Tensor]) -> torch.Tensor:
+    """``FactorConfig.precondition_gradient`` of the four strategies (factor/config.py:128-353)."""
+    if strategy == "identity":
+        return g
+    if strategy == "diagonal":
+        return g * lam_inv
+    return ekfac_precondition(g, q_a, q_g, lam_inv)  # ekfac and kfac differ only in lam_inv
+
+
+def self_score(preconditioned: torch.Tensor, psg: torch.Tensor) -> torch.Tensor:
+    """module/tracker/self_score.py:61-62 (and :164 for the measurement variant) -- ``sum(P o g)`` per sample."""
+    return (preconditioned * psg).sum(dim=(1, 2))
+
+
 def linear_pairwise_score(p: torch.Tensor, a: torch.Tensor, g: torch.Tensor, has_bias: bool) -> torch.Tensor:
     """module/linear.py:112-122 -- ``"qio,b...i,b...o->qb"``.
 
@@ -382,14 +413,98 @@ class OracleEngine:
         self._remove()
         return out
 
-    # ---- stage 3: pairwise scores (score/pairwise.py:133-293, score/dot_product.py:39-153) ---
-    def precondition_queries(self, query_batches: Iterable[object], measure_fn: LossFn, eig: Factors,
-                             lam: Factors, damping: Optional[float]) -> Dict[str, torch.Tensor]:
+    # ---- other strategies, self-influence ---------------------------------------------
+    def fit_diagonal_lambda(self, batches: Iterable[object], loss_fn: LossFn) -> Factors:
+        """``strategy="diagonal"``: Lambda in parameter space (factor/eigen.py:345-462 with
+        ``requires_eigendecomposition_for_lambda = False``)."""
         d = self.dtypes
-        q_a = {n: eig["activation_eigenvectors"][n].to(dtype=d.precondition) for n in self.layers}
-        q_g = {n: eig["gradient_eigenvectors"][n].to(dtype=d.precondition) for n in self.layers}
-        lam_inv = {n: ekfac_inverse_lambda(lam["lambda_matrix"][n], lam["num_lambda_processed"][n],
-                                           damping, d.precondition) for n in self.layers}
+        out: Factors = {"lambda_matrix": {}, "num_lambda_processed": {}}
+
+        def on_forward(name, mod, x):
+            cached = x.to(dtype=d.per_sample_gradient, copy=True)
+
+            def on_backward(g):
+                psg = self._per_sample_gradient(mod, cached, g.to(dtype=d.per_sample_gradient)).to(dtype=d.lambda_)
+                if name not in out["lambda_matrix"]:
+                    out["lambda_matrix"][name] = torch.zeros(psg.shape[1], psg.shape[2], dtype=psg.dtype)
+                    out["num_lambda_processed"][name] = torch.zeros(1, dtype=torch.int64)
+                out["num_lambda_processed"][name].add_(psg.shape[0])
+                diagonal_lambda_update(out["lambda_matrix"][name], psg)
+
+            return on_backward
+
+        self._install(on_forward)
+        for batch in batches:
+            self._backward(loss_fn(self.model, batch))
+        self._remove()
+        return out
+
+    def _strategy_state(self, strategy: str, eig: Optional[Factors], lam: Optional[Factors], damping: Optional[float]):
+        """Per-layer ``(Q_A, Q_G, Lambda^-1)`` as ``FactorConfig.prepare`` leaves them (factor/config.py)."""
+        d = self.dtypes
+        state = {}
+        for n in self.layers:
+            q_a = q_g = lam_inv = None
+            if strategy in ("ekfac", "kfac"):
+                q_a = eig["activation_eigenvectors"][n].to(dtype=d.precondition)
+                q_g = eig["gradient_eigenvectors"][n].to(dtype=d.precondition)
+            if strategy == "ekfac":
+                lam_inv = ekfac_inverse_lambda(lam["lambda_matrix"][n], lam["num_lambda_processed"][n], damping, d.precondition)
+            elif strategy == "kfac":
+                lam_inv = kfac_inverse_lambda(eig["activation_eigenvalues"][n], eig["gradient_eigenvalues"][n], damping,
+                                              d.precondition)
+            elif strategy == "diagonal":
+                lam_inv = ekfac_inverse_lambda(lam["lambda_matrix"][n], lam["num_lambda_processed"][n], damping, d.precondition)
+            state[n] = (q_a, q_g, lam_inv)
+        return state
+
+    def self_scores(self, train_batches: Iterable[object], loss_fn: LossFn, eig: Optional[Factors], lam: Optional[Factors],
+                    damping: Optional[float] = 1e-8, strategy: str = "ekfac", measure_fn: LossFn = None) -> torch.Tensor:
+        """score/self.py:135-290; with ``measure_fn`` the measurement variant of :293-443 (two backward passes)."""
+        d = self.dtypes
+        state = self._strategy_state(strategy, eig, lam, damping)
+        held: Dict[str, torch.Tensor] = {}
+        per_layer: Dict[str, torch.Tensor] = {}
+
+        def gradient_of(name, mod, x, g):
+            return self._per_sample_gradient(mod, x, g.to(dtype=d.per_sample_gradient)).to(dtype=d.precondition)
+
+        def measure_forward(name, mod, x):
+            cached = x.to(dtype=d.per_sample_gradient, copy=True)
+
+            def on_backward(g):
+                held[name] = precondition_with_strategy(strategy, gradient_of(name, mod, cached, g), *state[name]).to(dtype=d.score)
+
+            return on_backward
+
+        def loss_forward(name, mod, x):
+            cached = x.to(dtype=d.per_sample_gradient, copy=True)
+
+            def on_backward(g):
+                psg = gradient_of(name, mod, cached, g)
+                pre = held[name] if measure_fn is not None else precondition_with_strategy(strategy, psg, *state[name])
+                per_layer[name] = self_score(pre.to(dtype=d.score), psg.to(dtype=d.score))
+
+            return on_backward
+
+        chunks: List[torch.Tensor] = []
+        for batch in train_batches:
+            if measure_fn is not None:
+                self._install(measure_forward)
+                self._backward(measure_fn(self.model, batch))
+            self._install(loss_forward)
+            self._backward(loss_fn(self.model, batch))
+            chunks.append(sum(per_layer[n] for n in self.layers))
+            per_layer.clear()
+            held.clear()
+        self._remove()
+        return torch.cat(chunks, dim=0)
+
+    # ---- stage 3: pairwise scores (score/pairwise.py:133-293, score/dot_product.py:39-153) ---
+    def precondition_queries(self, query_batches: Iterable[object], measure_fn: LossFn, eig: Optional[Factors],
+                             lam: Optional[Factors], damping: Optional[float], strategy: str = "ekfac") -> Dict[str, torch.Tensor]:
+        d = self.dtypes
+        state = self._strategy_state(strategy, eig, lam, damping)
         held: Dict[str, List[torch.Tensor]] = {n: [] for n in self.layers}
 
         def on_forward(name, mod, x):
@@ -398,7 +513,7 @@ class OracleEngine:
             def on_backward(g):  # tracker/precondition.py:102-123
                 g = g.to(dtype=d.per_sample_gradient)
                 psg = self._per_sample_gradient(mod, cached, g).to(dtype=d.precondition)
-                held[name].append(ekfac_precondition(psg, q_a[name], q_g[name], lam_inv[name]).to(dtype=d.score))
+                held[name].append(precondition_with_strategy(strategy, psg, *state[name]).to(dtype=d.score))
 
             return on_backward
 
@@ -409,10 +524,10 @@ class OracleEngine:
         return {n: torch.cat(v, dim=0).contiguous() for n, v in held.items()}
 
     def pairwise_scores(self, query_batches: Iterable[object], train_batches: Iterable[object],
-                        measure_fn: LossFn, loss_fn: LossFn, eig: Factors, lam: Factors,
-                        damping: Optional[float] = 1e-8) -> torch.Tensor:
+                        measure_fn: LossFn, loss_fn: LossFn, eig: Optional[Factors], lam: Optional[Factors],
+                        damping: Optional[float] = 1e-8, strategy: str = "ekfac") -> torch.Tensor:
         d = self.dtypes
-        precond = self.precondition_queries(query_batches, measure_fn, eig, lam, damping)
+        precond = self.precondition_queries(query_batches, measure_fn, eig, lam, damping, strategy)
         per_layer: Dict[str, torch.Tensor] = {}
 
         def on_forward(name, mod, x):

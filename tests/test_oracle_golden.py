@@ -124,3 +124,28 @@ def test_oracle_matches_conv8_golden():
                                  fx.measurement("conv8"), fx.train_loss("conv8"),
                                  _nested(gold, "eig"), _nested(gold, "lam"), None)
     assert _relerr(got, gold["scores/dampNone"]) <= 5e-5
+
+
+# ---- the oracle's other strategies and self-influence, pinned to the reference (fp64) ---------
+@pytest.mark.parametrize("strategy", ["ekfac", "kfac", "diagonal", "identity"])
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_oracle_strategies_and_self_scores_match_reference(kind, strategy):
+    gold = load_file(os.path.join(GOLDEN, f"widen_{kind}_fp64.safetensors"))
+    spec = fx.FIXTURES[kind]
+    engine, cov, eig, lam, train, query, loss, measure = _run(kind, torch.float64)
+    if strategy == "diagonal":
+        lam = engine.fit_diagonal_lambda(fx.batches(train, spec.factor_batch), loss)
+        for key, want in gold.items():
+            if key.startswith("strategy/diagonal/lam/lambda_matrix/"):
+                assert _relerr(lam["lambda_matrix"][key.rsplit("/", 1)[1]], want) <= 1e-10, key
+    scores = engine.pairwise_scores(fx.batches(query, spec.query_batch), fx.batches(train, spec.train_batch), measure, loss,
+                                    eig, lam, None, strategy=strategy)
+    # kfac / ekfac go through LAPACK's eigenbasis, which is unique only up to rotations inside (near-)degenerate
+    # eigenspaces; everything downstream is invariant to those for K-FAC but conditioning amplifies rounding
+    tol = 1e-10 if strategy in ("identity", "diagonal") else 1e-7
+    assert _relerr(scores, gold[f"strategy/{strategy}/scores"]) <= tol, _relerr(scores, gold[f"strategy/{strategy}/scores"])
+    own = engine.self_scores(fx.batches(train, spec.train_batch), loss, eig, lam, None, strategy=strategy)
+    assert _relerr(own, gold[f"strategy/{strategy}/self"]) <= tol, _relerr(own, gold[f"strategy/{strategy}/self"])
+    if strategy == "ekfac":
+        measured = engine.self_scores(fx.batches(train, spec.train_batch), loss, eig, lam, None, measure_fn=measure)
+        assert _relerr(measured, gold["self_measurement"]) <= tol
