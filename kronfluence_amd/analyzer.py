@@ -125,6 +125,21 @@ class Analyzer:
         if self.state.device.type == "cuda":
             torch.cuda.synchronize(self.state.device)
 
+    def _write_profile_summary(self, name: str) -> None:
+        """``profile=True``: append the stage wall times measured so far (device-synchronised, see ``_timed``) to
+        ``<output_dir>/profiler_output/<name>_summary_rank_<r>.txt`` -- the counterpart of the reference's profiler
+        summaries (``computer/computer.py:323-333``), reduced to what the hot path needs: one line per stage."""
+        if not self.profile or not self.timings:
+            return
+        directory = self.output_dir / "profiler_output"
+        os.makedirs(directory, exist_ok=True)
+        total = sum(self.timings.values())
+        lines = [f"{'Action':<32}|{'Total time (s)':>16} |{'Percentage %':>14}"]
+        for label, seconds in sorted(self.timings.items(), key=lambda item: -item[1]):
+            lines.append(f"{label:<32}|{seconds:>16.4f} |{100.0 * seconds / total:>14.2f}")
+        with open(directory / f"{name}_summary_rank_{self.state.process_index}.txt", "w", encoding="utf-8") as handle:
+            handle.write("\n".join(lines) + "\n")
+
     def _timed(self, label: str):
         analyzer = self
 
@@ -474,6 +489,7 @@ class Analyzer:
         self.fit_lambda_matrices(dataset=dataset, per_device_batch_size=per_device_batch_size,
                                  initial_per_device_batch_size_attempt=initial_per_device_batch_size_attempt,
                                  dataloader_kwargs=dataloader_kwargs, **common)
+        self._write_profile_summary(f"factors_{factors_name}")
 
     def load_factor_args(self, factors_name: str) -> Optional[FactorArguments]:
         """The ``FactorArguments`` the factors were fitted with (reference ``computer/computer.py:335-341``)."""
@@ -607,6 +623,7 @@ class Analyzer:
             if self.state.is_main_process:
                 scores = self.aggregate_pairwise_scores(scores_name)
             self.state.wait_for_everyone()
+        self._write_profile_summary(f"scores_{scores_name}_pairwise")
         return scores if self.state.is_main_process else None
 
     def aggregate_pairwise_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
@@ -680,6 +697,7 @@ class Analyzer:
             if self.state.is_main_process:
                 scores = self.aggregate_self_scores(scores_name)
             self.state.wait_for_everyone()
+        self._write_profile_summary(f"scores_{scores_name}_self")
         return scores if self.state.is_main_process else None
 
     def aggregate_self_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:

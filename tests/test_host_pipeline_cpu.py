@@ -183,3 +183,20 @@ def test_gpt2_shaped_workload_host_logic_matches_oracle(tmp_path, cpu_engine):
     for module in names:
         assert rel(mine["activation_covariance"][module], cov["activation_covariance"][module]) <= 1e-5, module
     assert got.shape == (4, 24) and rel(got, want) <= 2e-3, rel(got, want)
+
+
+def test_profile_flag_writes_stage_timing_summaries(tmp_path, cpu_engine):
+    import fixtures as fx
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from test_pipeline_gpu import make_task
+    from torch.utils import data
+
+    task = make_task("mlp")
+    analyzer = Analyzer("t", prepare_model(fx.make_model("mlp"), task), task, output_dir=str(tmp_path), profile=True)
+    train = data.TensorDataset(*fx.make_data("mlp", 24, seed=1))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=8, factor_args=FactorArguments(use_empirical_fisher=True))
+    analyzer.compute_self_scores("s", "f", train, per_device_train_batch_size=8, score_args=ScoreArguments(damping_factor=None))
+    out = analyzer.output_dir / "profiler_output"
+    text = (out / "factors_f_summary_rank_0.txt").read_text()
+    assert all(stage in text for stage in ("fit_covariance", "perform_eigendecomposition", "fit_lambda"))
+    assert "compute_self_scores" in (out / "scores_s_self_summary_rank_0.txt").read_text()
