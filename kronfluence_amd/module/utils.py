@@ -142,14 +142,21 @@ def synchronize_modules(model: nn.Module, tracked_module_names: List[str], num_p
         m.synchronize(num_processes=num_processes)
 
 
+FACTOR_BUCKET_BYTES = 1 << 30  # per all-reduce: large enough to run at xGMI link speed, small enough to stage in HBM
+
+
 def synchronize_factors(model: nn.Module, factor_names: List[str], tracked_module_names: List[str],
-                        device: torch.device, extra: Optional[List[torch.Tensor]] = None) -> None:
-    """C1-C3 as ONE exchange: every floating factor of every layer is packed into one flat fp32
-    bucket, every int64 counter (plus ``extra``) into one int64 bucket, and each bucket is summed
-    with a single all-reduce (RCCL over xGMI on GPU, gloo in the CPU tests).  The reference issues
-    4 (resp. 2) ``dist.reduce`` calls per layer (``tracker/factor.py:136-142, 315-321``)."""
+                        device: torch.device, extra: Optional[List[torch.Tensor]] = None,
+                        bucket_bytes: Optional[int] = None) -> None:
+    """C1-C3 as a handful of large exchanges: the floating factors of all layers are packed, in order, into flat fp32
+    buckets of at most ``bucket_bytes`` (default 1 GiB; a factor larger than that is reduced in place, on its own),
+    every int64 counter (plus ``extra``) into one int64 bucket, and each bucket is summed with a single all-reduce
+    (RCCL over xGMI on GPU, gloo in the CPU tests).  The reference issues 4 (resp. 2) ``dist.reduce`` calls per layer
+    (``tracker/factor.py:136-142, 315-321``); one flat buffer for everything would double the footprint of
+    Llama-scale covariances (85 GB)."""
     if not (dist.is_available() and dist.is_initialized()):
         return
+    limit = FACTOR_BUCKET_BYTES if bucket_bytes is None else bucket_bytes
     floats, ints = [], list(extra or [])
     for m in _tracked(model, tracked_module_names):
         for name in factor_names:
@@ -157,10 +164,11 @@ def synchronize_factors(model: nn.Module, factor_names: List[str], tracked_modul
             if t is None:
                 continue
             (floats if t.is_floating_point() else ints).append((m, name, t))
-    for group, dtype in ((floats, torch.float32), (ints, torch.int64)):
+
+    def reduce_bucket(group, dtype) -> None:
         tensors = [item[2] if isinstance(item, tuple) else item for item in group]
         if not tensors:
-            continue
+            return
         flat = torch.cat([t.reshape(-1).to(device=device, dtype=dtype) for t in tensors])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         offset = 0
@@ -169,10 +177,25 @@ def synchronize_factors(model: nn.Module, factor_names: List[str], tracked_modul
             reduced = flat[offset:offset + n].reshape(t.shape)
             offset += n
             if isinstance(item, tuple):
-                m, name, _ = item
-                m.set_factor(name, reduced.to(device=t.device, dtype=t.dtype).clone())
+                owner, name, _ = item
+                owner.set_factor(name, reduced.to(device=t.device, dtype=t.dtype).clone())
             else:
                 t.copy_(reduced.to(device=t.device, dtype=t.dtype))
+
+    bucket, held = [], 0
+    for item in floats:
+        t = item[2]
+        size = t.numel() * 4
+        if size > limit and t.dtype == torch.float32 and t.device == device and t.is_contiguous():
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)  # big enough on its own: no staging copy
+            continue
+        if bucket and held + size > limit:
+            reduce_bucket(bucket, torch.float32)
+            bucket, held = [], 0
+        bucket.append(item)
+        held += size
+    reduce_bucket(bucket, torch.float32)
+    reduce_bucket(ints, torch.int64)
 
 
 def truncate(model: nn.Module, tracked_module_names: List[str], keep_size: int) -> None:

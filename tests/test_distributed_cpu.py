@@ -70,14 +70,18 @@ def _factor_allreduce(rank, world, out_dir):
         m.storage["num_lambda_processed"] = torch.tensor([5 + rank])
     seen = torch.tensor([11 + rank])
     names = get_tracked_module_names(model)
-    synchronize_factors(model, COVARIANCE_FACTOR_NAMES, names, torch.device("cpu"), extra=[seen])
-    synchronize_factors(model, LAMBDA_FACTOR_NAMES, names, torch.device("cpu"))
+    # a 64-byte bucket cap forces several buckets AND the in-place path for the factors above the cap
+    cap = int(os.environ.get("KF_TEST_BUCKET_BYTES", "0")) or None
+    synchronize_factors(model, COVARIANCE_FACTOR_NAMES, names, torch.device("cpu"), extra=[seen], bucket_bytes=cap)
+    synchronize_factors(model, LAMBDA_FACTOR_NAMES, names, torch.device("cpu"), bucket_bytes=cap)
     state = {f"{m.name}/{k}": m.storage[k] for m in mods for k in COVARIANCE_FACTOR_NAMES + LAMBDA_FACTOR_NAMES}
     state["seen"] = seen
     torch.save(state, os.path.join(out_dir, f"rank{rank}.pt"))
 
 
-def test_bucketed_factor_allreduce_matches_sum(tmp_path):
+@pytest.mark.parametrize("cap", [0, 64])
+def test_bucketed_factor_allreduce_matches_sum(tmp_path, cap, monkeypatch):
+    monkeypatch.setenv("KF_TEST_BUCKET_BYTES", str(cap))
     _run("_factor_allreduce", tmp_path)
     got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(2)]
     # every rank holds the SUM (all-reduce, not reduce-to-0), and it equals the sum of the two locals
