@@ -258,7 +258,7 @@ class Analyzer:
 
     @torch.no_grad()
     def _aggregate_factors(self, factors_name: str, data_partitions: int, module_partitions: int, exist_fnc, load_fnc,
-                           save_fnc) -> Optional[FACTOR_TYPE]:
+                           save_fnc, metadata: Optional[Dict[str, str]] = None) -> Optional[FACTOR_TYPE]:
         """Sum over data partitions, union over module partitions (reference ``factor_computer.py:57-108``);
         nothing happens until every partition file exists."""
         out = self.factors_output_dir(factors_name)
@@ -276,7 +276,7 @@ class Analyzer:
                         held[module_name].add_(tensor)
                     else:
                         held[module_name] = tensor.clone()
-        save_fnc(out, total)
+        save_fnc(out, total, metadata=metadata)  # the per-partition files carry the same metadata
         return total
 
     @torch.no_grad()
@@ -310,31 +310,35 @@ class Analyzer:
         return total
 
     def _save_arguments(self, path: Path, arguments, overwrite: bool) -> None:
-        if self.state.is_main_process:
-            if path.exists() and not overwrite:
-                stored = load_json(path)
-                if stored != arguments.to_dict():
-                    raise ValueError(f"Arguments stored at `{path}` differ from the ones provided; pass "
-                                     f"`overwrite_output_dir=True` or use a different name.")
-            else:
-                save_json(arguments.to_dict(), path)
+        """Every rank compares (read-only) so that a mismatch raises everywhere -- a rank-0-only ``ValueError`` would
+        leave the other ranks waiting in the stage's first collective; only the main process writes."""
+        exists = path.exists()
+        self.state.wait_for_everyone()  # nobody inspects the directory after rank 0 has started writing into it
+        if exists and not overwrite:
+            stored = load_json(path)
+            if stored != arguments.to_dict():
+                raise ValueError(f"Arguments stored at `{path}` differ from the ones provided; pass "
+                                 f"`overwrite_output_dir=True` or use a different name.")
+        elif self.state.is_main_process:
+            save_json(arguments.to_dict(), path)
 
     def _save_dataset_metadata(self, name: str, dataset: data.Dataset, output_dir: Path,
                                indices: Optional[Sequence[int]] = None, overwrite: bool = False) -> None:
         """``<name>_dataset_metadata.json`` next to the results (type, size, index subset): a later call on the same
-        output directory with a different dataset is an error unless overwriting (reference ``computer.py:160-191``)."""
-        if not self.state.is_main_process:
-            return
+        output directory with a different dataset is an error unless overwriting (reference ``computer.py:160-191``).
+        Compared on every rank, written by the main process (see ``_save_arguments``)."""
         path = output_dir / f"{name}_dataset_metadata.json"
         metadata = {"type": type(dataset).__name__, "dataset_size": len(dataset),
                     "indices": None if indices is None else list(indices)}
-        if path.exists() and not overwrite:
+        exists = path.exists()
+        self.state.wait_for_everyone()
+        if exists and not overwrite:
             stored = load_json(path)
             if stored != metadata:
                 raise ValueError("Attempting to use the dataset that differs from the one already saved. Please set "
                                  f"`overwrite_output_dir=True` to overwrite existing experiment.\nNew metadata: {metadata}."
                                  f"\nSaved metadata: {stored}.")
-        else:
+        elif self.state.is_main_process:
             save_json(metadata, path)
 
     # -- factors -----------------------------------------------------------------------------------
@@ -389,7 +393,8 @@ class Analyzer:
         """Aggregates the partitioned covariance files once all of them exist (reference ``factor_computer.py:350-378``)."""
         factor_args = self._stored_factor_args(factors_name)
         self._aggregate_factors(factors_name, factor_args.covariance_data_partitions, factor_args.covariance_module_partitions,
-                                covariance_matrices_exist, load_covariance_matrices, save_covariance_matrices)
+                                covariance_matrices_exist, load_covariance_matrices, save_covariance_matrices,
+                                metadata=factor_args.to_str_dict())
 
     def perform_eigendecomposition(self, factors_name: str, factor_args: Optional[FactorArguments] = None,
                                    overwrite_output_dir: bool = False,
@@ -474,7 +479,8 @@ class Analyzer:
         """Aggregates the partitioned Lambda files once all of them exist (reference ``factor_computer.py:704-732``)."""
         factor_args = self._stored_factor_args(factors_name)
         self._aggregate_factors(factors_name, factor_args.lambda_data_partitions, factor_args.lambda_module_partitions,
-                                lambda_matrices_exist, load_lambda_matrices, save_lambda_matrices)
+                                lambda_matrices_exist, load_lambda_matrices, save_lambda_matrices,
+                                metadata=factor_args.to_str_dict())
 
     def fit_all_factors(self, factors_name: str, dataset: data.Dataset, per_device_batch_size: Optional[int] = None,
                         initial_per_device_batch_size_attempt: int = 4096,

@@ -72,21 +72,34 @@ class BaseTracker:
         )
 
     def _cache_activation(self, activation: torch.Tensor) -> None:
-        """Forward hook side: one slot, or a LIFO stack when the module's parameters are shared between uses."""
+        """Forward hook side: one slot, or a LIFO stack when the module's parameters are shared between uses.
+        The hooked input is held by reference (``.detach()``, no copy -- reference ``tracker/pairwise_score.py:58``)
+        together with its version counter: all parameters are frozen, so autograd would NOT notice a later in-place
+        write to this tensor; ``_take_activation`` does, and raises instead of scoring a corrupted activation."""
+        entry = (activation, activation._version)
         if not self.module.factor_args.has_shared_parameters:
-            self.cached_activations = activation
+            self.cached_activations = entry
         elif self.cached_activations is None:
-            self.cached_activations = [activation]
+            self.cached_activations = [entry]
         else:
-            self.cached_activations.append(activation)
+            self.cached_activations.append(entry)
 
     def _take_activation(self) -> torch.Tensor:
         """Backward hook side: the activation of the use whose gradient just arrived (last in, first out)."""
         held = self.cached_activations
+        entry = None
         if isinstance(held, list):
             if held:
-                return held.pop()
+                entry = held.pop()
         elif held is not None:
             self.cached_activations = None
-            return held
-        self._raise_cache_not_found_exception()
+            entry = held
+        if entry is None:
+            self._raise_cache_not_found_exception()
+        activation, version = entry
+        if activation._version != version:
+            raise RuntimeError(
+                f"The input of module '{self.module.name}' was modified in place after its forward pass; the influence "
+                "hooks hold that tensor by reference.  Make the offending operation out-of-place (e.g. `inplace=False`)."
+            )
+        return activation

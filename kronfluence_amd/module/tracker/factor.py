@@ -172,7 +172,7 @@ class LambdaTracker(BaseTracker):
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
             del mod
-            self._cache_activation(inputs[0].detach().clone())
+            self._cache_activation(inputs[0].detach())
             self.cached_hooks.append(
                 outputs.register_hook(shared_backward_hook if module.factor_args.has_shared_parameters else backward_hook))
 

@@ -26,7 +26,7 @@ class GradientTracker(BaseTracker):
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
             del mod
-            self._cache_activation(inputs[0].detach().clone())
+            self._cache_activation(inputs[0].detach())
             self.cached_hooks.append(outputs.register_hook(backward_hook))
 
         @torch.no_grad()

@@ -137,7 +137,7 @@ class PairwiseScoreTracker(BaseTracker):
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
             del mod
-            self._cache_activation(inputs[0].detach().clone())
+            self._cache_activation(inputs[0].detach())
             self.cached_hooks.append(outputs.register_hook(backward_hook))
 
         @torch.no_grad()
@@ -166,9 +166,12 @@ class PairwiseScoreTracker(BaseTracker):
                 if per_token:  # "qio,bti,bto->qbt" (linear.py:100-111): every token is a rank-one "sample"
                     g, a = g.reshape(-1, 1, g.shape[-1]), a.reshape(-1, 1, a.shape[-1])
                 if module.queries_in_eigenbasis:  # see PreconditionTracker.EIGENBASIS_QUERIES
-                    n = g.shape[0]
-                    g = ops.matmul_nn(g.reshape(n, -1), storage[GRADIENT_EIGENVECTORS_NAME]).unsqueeze(1)
-                    a = ops.matmul_nn(a.reshape(n, -1), storage[ACTIVATION_EIGENVECTORS_NAME], append_ones=ones).unsqueeze(1)
+                    # rotated row by row, keeping the R axis: the held queries had one row per sample, the train
+                    # batch may have several (single-token queries against sequence batches)
+                    n, r = g.shape[0], g.shape[1]
+                    g = ops.matmul_nn(g.reshape(n * r, -1), storage[GRADIENT_EIGENVECTORS_NAME]).reshape(n, r, -1)
+                    a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
+                                      append_ones=ones).reshape(n, r, -1)
                     ones = False
                 for first, block in self._query_blocks(preconditioned):
                     rows = scores[first:first + block.shape[0]]

@@ -78,7 +78,7 @@ class SelfScoreTracker(_SelfScoreBase):
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
             del mod
-            self._cache_activation(inputs[0].detach().clone())
+            self._cache_activation(inputs[0].detach())
             self.cached_hooks.append(
                 outputs.register_hook(shared_backward_hook if module.factor_args.has_shared_parameters else backward_hook))
 
@@ -125,7 +125,7 @@ class SelfScoreWithMeasurementTracker(_SelfScoreBase):
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
             del mod
-            self._cache_activation(inputs[0].detach().clone())
+            self._cache_activation(inputs[0].detach())
             self.cached_hooks.append(outputs.register_hook(backward_hook))
 
         @torch.no_grad()
@@ -139,9 +139,12 @@ class SelfScoreWithMeasurementTracker(_SelfScoreBase):
             if module.per_sample_gradient_process_fnc is None:
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 if module.queries_in_eigenbasis:  # see PreconditionTracker.EIGENBASIS_QUERIES
-                    n = g.shape[0]
-                    g = ops.matmul_nn(g.reshape(n, -1), storage[GRADIENT_EIGENVECTORS_NAME]).unsqueeze(1)
-                    a = ops.matmul_nn(a.reshape(n, -1), storage[ACTIVATION_EIGENVECTORS_NAME], append_ones=ones).unsqueeze(1)
+                    # rotated row by row, keeping the R axis: the held queries had one row per sample, the train
+                    # batch may have several (single-token queries against sequence batches)
+                    n, r = g.shape[0], g.shape[1]
+                    g = ops.matmul_nn(g.reshape(n * r, -1), storage[GRADIENT_EIGENVECTORS_NAME]).reshape(n, r, -1)
+                    a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
+                                      append_ones=ones).reshape(n, r, -1)
                     ones = False
                 psg = ops.per_sample_gradient(g, a, ones)
             else:

@@ -65,12 +65,16 @@ def get_tracked_module_names(model: nn.Module) -> List[str]:
 
 
 def make_modules_partition(total_module_names: List[str], partition_size: int) -> List[List[str]]:
+    """Near-equal consecutive groups, remainder spread over the leading groups (reference ``module/utils.py:125-131``)."""
     if len(total_module_names) < partition_size:
         raise ValueError("The total modules must be equal to or greater than the partition size.")
-    base = len(total_module_names) // partition_size
-    bounds = [(i * base, (i + 1) * base) for i in range(partition_size)]
-    bounds[-1] = (bounds[-1][0], len(total_module_names))
-    return [total_module_names[s:e] for s, e in bounds]
+    from kronfluence_amd.utils.dataset import partition_sizes
+
+    groups, start = [], 0
+    for size in partition_sizes(len(total_module_names), partition_size):
+        groups.append(total_module_names[start:start + size])
+        start += size
+    return groups
 
 
 def update_factor_args(model: nn.Module, factor_args: FactorArguments) -> None:

@@ -78,6 +78,9 @@ def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tenso
     n = x.numel() // d_in
     if mask is not None and mask.numel() != n:
         mask = None  # linear.py:33 -- the mask applies only when it matches the row count
+    if mask is not None and mask.dtype not in (torch.float32, torch.int64, torch.uint8, torch.bool):
+        # the reference multiplies by the mask whatever its dtype (``mul_``): bf16 / fp16 / int32 masks are widened
+        mask = mask.to(torch.float32)
     syrk_accum(cov, x, n, d_in, max(n, 1), 0, d_in, 1, mask, has_bias, 1.0, count)
 
 

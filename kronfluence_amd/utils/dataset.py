@@ -11,6 +11,7 @@ from __future__ import annotations
 
 import math
 from dataclasses import dataclass
+from collections.abc import Mapping
 from typing import Any, Callable, Dict, Iterator, List, Optional, Tuple
 
 import torch
@@ -35,40 +36,66 @@ class DataLoaderKwargs:
         return dict(vars(self))
 
 
+def partition_sizes(total: int, parts: int) -> List[int]:
+    """Sizes of ``parts`` near-equal bins covering ``total`` items: the first ``total % parts`` bins hold one
+    item more (what ``np.array_split`` / the divmod slices of the reference produce,
+    ``utils/dataset.py:54-63`` and ``module/utils.py:125-131``) -- per-partition files are therefore
+    interchangeable with the reference's."""
+    base, extra = divmod(total, parts)
+    return [base + (1 if i < extra else 0) for i in range(parts)]
+
+
 def make_indices_partition(total_data_examples: int, partition_size: int) -> List[Tuple[int, int]]:
-    """``[start, end)`` ranges of near-equal size; the last one absorbs the remainder."""
+    """``[start, end)`` ranges of near-equal size (remainder spread over the leading ranges)."""
     if total_data_examples < partition_size:
         raise ValueError("The total data examples must be equal to or greater than the partition size.")
-    base = total_data_examples // partition_size
-    bounds = [(i * base, (i + 1) * base) for i in range(partition_size)]
-    bounds[-1] = (bounds[-1][0], total_data_examples)
+    bounds, start = [], 0
+    for size in partition_sizes(total_data_examples, partition_size):
+        bounds.append((start, start + size))
+        start += size
     return bounds
 
 
 def find_batch_size(batch: Any) -> int:
-    """Leading dimension of the first tensor found in a (possibly nested) batch."""
+    """Leading dimension of the first tensor found in a (possibly nested) batch -- tensors, any ``Mapping``
+    (HF ``BatchEncoding`` is a ``UserDict``), lists / tuples / namedtuples."""
+    size = _find_batch_size(batch)
+    if size is None:
+        raise TypeError(f"Cannot find the batch size of a batch of type {type(batch).__name__}: no tensor inside.")
+    return size
+
+
+def _find_batch_size(batch: Any) -> Optional[int]:
     if isinstance(batch, torch.Tensor):
-        return batch.shape[0]
-    if isinstance(batch, dict):
-        for value in batch.values():
-            size = find_batch_size(value)
-            if size is not None:
-                return size
+        return batch.shape[0] if batch.dim() > 0 else None
+    if isinstance(batch, Mapping):
+        batch = list(batch.values())
     if isinstance(batch, (list, tuple)):
         for value in batch:
-            size = find_batch_size(value)
+            size = _find_batch_size(value)
             if size is not None:
                 return size
     return None
 
 
 def send_to_device(batch: Any, device: torch.device) -> Any:
+    """Moves every tensor of a nested batch; containers keep their type (namedtuples included), any object with a
+    ``.to(device)`` method (``BatchEncoding``) is asked to move itself."""
     if isinstance(batch, torch.Tensor):
         return batch.to(device, non_blocking=True)
-    if isinstance(batch, dict):
-        return type(batch)({k: send_to_device(v, device) for k, v in batch.items()})
+    if isinstance(batch, tuple) and hasattr(batch, "_fields"):  # namedtuple: positional constructor
+        return type(batch)(*(send_to_device(v, device) for v in batch))
     if isinstance(batch, (list, tuple)):
         return type(batch)(send_to_device(v, device) for v in batch)
+    if isinstance(batch, dict):
+        return type(batch)({k: send_to_device(v, device) for k, v in batch.items()})
+    if hasattr(batch, "to") and callable(batch.to):
+        try:
+            return batch.to(device)
+        except TypeError:
+            pass
+    if isinstance(batch, Mapping):
+        return {k: send_to_device(v, device) for k, v in batch.items()}
     return batch
 
 

@@ -16,6 +16,7 @@ from kronfluence_amd.module.utils import (
 from kronfluence_amd.utils import constants as C
 from kronfluence_amd.utils.dataset import (
     DistributedEvalSampler, DistributedSamplerWithStack, ResidentLoader, find_batch_size, make_indices_partition,
+    send_to_device,
 )
 from kronfluence_amd.utils.exceptions import IllegalTaskConfigurationError
 
@@ -79,11 +80,36 @@ def test_samplers_shard_like_the_reference(n, world):
 
 
 def test_partitions_and_batch_size_helpers():
-    assert make_indices_partition(10, 3) == [(0, 3), (3, 6), (6, 10)]
+    import collections
+
+    import numpy as np
+
+    # the reference's split (np.array_split / divmod slices): remainder spread over the LEADING partitions
+    assert make_indices_partition(10, 3) == [(0, 4), (4, 7), (7, 10)]
+    for total, parts in ((199, 100), (7, 4), (10, 10), (67349, 7), (5, 1)):
+        sizes = [len(chunk) for chunk in np.array_split(range(total), parts)]
+        got = make_indices_partition(total, parts)
+        assert [e - s for s, e in got] == sizes and got[0][0] == 0 and got[-1][1] == total
+        assert all(a[1] == b[0] for a, b in zip(got, got[1:]))
+        names = [str(i) for i in range(total)] if total < 1000 else None
+        if names is not None:
+            groups = make_modules_partition(names, parts)
+            assert [len(g) for g in groups] == sizes and sum(groups, []) == names
     with pytest.raises(ValueError):
         make_indices_partition(2, 3)
-    assert make_modules_partition(["a", "b", "c", "d", "e"], 2) == [["a", "b"], ["c", "d", "e"]]
+    assert make_modules_partition(["a", "b", "c", "d", "e"], 2) == [["a", "b", "c"], ["d", "e"]]
+    assert make_modules_partition(list("abcdefg"), 4) == [["a", "b"], ["c", "d"], ["e", "f"], ["g"]]
     assert find_batch_size({"x": torch.zeros(4, 2)}) == 4 and find_batch_size([torch.zeros(3), 1]) == 3
+    # Mapping that is not a dict (HF BatchEncoding is a UserDict), namedtuples, objects with .to
+    encoding = collections.UserDict(input_ids=torch.zeros(5, 3, dtype=torch.int64), attention_mask=torch.ones(5, 3))
+    assert find_batch_size(encoding) == 5
+    moved = send_to_device(encoding, torch.device("cpu"))
+    assert set(moved.keys()) == {"input_ids", "attention_mask"} and moved["input_ids"].shape == (5, 3)
+    Pair = collections.namedtuple("Pair", ["x", "y"])
+    moved = send_to_device(Pair(torch.zeros(2), torch.ones(2)), torch.device("cpu"))
+    assert isinstance(moved, Pair) and moved.y.tolist() == [1.0, 1.0] and find_batch_size(moved) == 2
+    with pytest.raises(TypeError):
+        find_batch_size({"meta": "no tensors here"})
     loader = ResidentLoader((torch.arange(10), torch.arange(10) * 2), 4, indices=[9, 1, 3])
     batches = list(loader)
     assert len(loader) == 1 and len(loader.dataset) == 10 and len(loader.sampler) == 3
