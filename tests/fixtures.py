@@ -52,8 +52,33 @@ class _SharedMLP(nn.Module):
         return self.last(h)
 
 
+def is_regression(kind: str) -> bool:
+    """``*_mse`` fixtures: the same three layer flavours with smooth activations, a summed squared-error loss and many
+    more fitted rows than factor dimensions.  Cross-entropy gives the last layer's gradient covariance an exact null
+    vector (softmax gradients sum to zero) and ReLU units that never fire give exact zero rows, so at the reference's
+    DEFAULT damping 1e-8 ``1 / (Lambda / n + 1e-8)`` amplifies fp32 round-off by 1e8 there and even the reference
+    disagrees with itself (fp32 vs fp64) at the 1e-2 level.  These fixtures are well conditioned, which makes the
+    default damping testable at the north-star bound of 1e-4."""
+    return kind.endswith("_mse")
+
+
+def _act(kind: str) -> nn.Module:
+    return nn.Tanh() if is_regression(kind) else nn.ReLU()
+
+
 def make_model(kind: str, seed: int = 0) -> nn.Module:
     torch.manual_seed(seed)
+    if kind == "mlp_mse":
+        return nn.Sequential(nn.Linear(12, 16), nn.Tanh(), nn.Linear(16, 16, bias=False), nn.Tanh(), nn.Linear(16, 3))
+    if kind == "conv_mse":
+        return nn.Sequential(
+            nn.Conv2d(3, 4, 3, padding=1, bias=False), nn.Tanh(),
+            nn.Conv2d(4, 8, 5, stride=2, padding=2, bias=True), nn.Tanh(),
+            nn.Conv2d(8, 6, 3, padding=1, groups=2, bias=True), nn.Tanh(),
+            nn.Flatten(), nn.Linear(6 * 4 * 4, 3),
+        )
+    if kind == "seq_mse":
+        return _SeqModel()
     if kind == "shared":
         return _SharedMLP()
     if kind == "mlp":
@@ -82,6 +107,16 @@ def make_model(kind: str, seed: int = 0) -> nn.Module:
 
 def make_data(kind: str, n: int, seed: int) -> Batch:
     gen = torch.Generator().manual_seed(seed)
+    if kind == "mlp_mse":
+        return (torch.randn(n, 12, generator=gen), torch.randn(n, 3, generator=gen))
+    if kind == "conv_mse":
+        return (torch.randn(n, 3, 8, 8, generator=gen), torch.randn(n, 3, generator=gen))
+    if kind == "seq_mse":
+        t = 6
+        ids = torch.randint(0, 20, (n, t), generator=gen)
+        lengths = torch.randint(2, t + 1, (n,), generator=gen)
+        mask = (torch.arange(t)[None, :] < lengths[:, None]).to(torch.int64)
+        return (ids, mask, torch.randn(n, t, 20, generator=gen))
     if kind in ("mlp", "shared"):
         return (torch.randn(n, 12, generator=gen), torch.randint(0, 3, (n,), generator=gen))
     if kind == "conv":
@@ -109,6 +144,14 @@ def train_loss(kind: str) -> Callable[[nn.Module, Batch], torch.Tensor]:
     """Summed cross-entropy with the true labels (empirical Fisher; deterministic)."""
 
     def loss(model: nn.Module, batch: Batch) -> torch.Tensor:
+        if kind == "seq_mse":  # padded tokens contribute no loss, hence no gradient (the reference relies on that)
+            ids, mask, target = batch
+            out = model(ids)
+            return 0.5 * (((out - target.to(out.dtype)) ** 2).sum(-1) * mask.to(out.dtype)).sum()
+        if is_regression(kind):
+            x, target = batch
+            out = model(_inputs_to(model, x))
+            return 0.5 * ((out - target.to(out.dtype)) ** 2).sum()
         if kind == "seq":
             ids, _mask, labels = batch
             logits = model(ids)
@@ -124,6 +167,14 @@ def measurement(kind: str) -> Callable[[nn.Module, Batch], torch.Tensor]:
     """A measurement that differs from the loss: summed correct-class margin."""
 
     def measure(model: nn.Module, batch: Batch) -> torch.Tensor:
+        if kind == "seq_mse":
+            ids, mask, target = batch
+            out = model(ids)
+            return ((out * target.to(out.dtype)).sum(-1) * mask.to(out.dtype)).sum()
+        if is_regression(kind):
+            x, target = batch
+            out = model(_inputs_to(model, x))
+            return (out * target.to(out.dtype)).sum()
         if kind == "seq":
             ids, mask, labels = batch
             logits = model(ids)
@@ -140,7 +191,7 @@ def measurement(kind: str) -> Callable[[nn.Module, Batch], torch.Tensor]:
 
 
 def attention_mask(kind: str) -> Optional[Callable[[Batch], Optional[torch.Tensor]]]:
-    if kind == "seq":
+    if kind in ("seq", "seq_mse"):
         return lambda batch: batch[1]
     return None
 
@@ -165,7 +216,21 @@ FIXTURES: Dict[str, Fixture] = {
     "conv": Fixture("conv", 40, 6, 8, 10, 3),
     "seq": Fixture("seq", 48, 6, 16, 12, 3),
 }
+# well-conditioned regression fixtures for the default damping 1e-8 (see ``is_regression``)
+MSE_FIXTURES: Dict[str, Fixture] = {
+    "mlp_mse": Fixture("mlp_mse", 256, 6, 64, 64, 3),
+    "conv_mse": Fixture("conv_mse", 256, 6, 32, 32, 3),
+    "seq_mse": Fixture("seq_mse", 192, 6, 48, 48, 3),
+}
 # bf16-engine fixture: not part of FIXTURES (the generic parametrised tests run fp32); see test_pipeline_gpu.py
 BF16_FIXTURE = Fixture("conv8", 256, 8, 64, 64, 4)
 # shared-parameter fixture (FactorArguments.has_shared_parameters=True)
 SHARED_FIXTURE = Fixture("shared", 48, 6, 16, 12, 3)
+
+
+def spec_of(kind: str) -> Fixture:
+    if kind in FIXTURES:
+        return FIXTURES[kind]
+    if kind in MSE_FIXTURES:
+        return MSE_FIXTURES[kind]
+    return {"conv8": BF16_FIXTURE, "shared": SHARED_FIXTURE}[kind]

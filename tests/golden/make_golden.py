@@ -59,7 +59,7 @@ def make_task(kind: str) -> Task:
 
 
 def run(kind: str, dtype: torch.dtype, out_path: str) -> None:
-    spec = fx.FIXTURES.get(kind) or {"conv8": fx.BF16_FIXTURE, "shared": fx.SHARED_FIXTURE}[kind]
+    spec = fx.FIXTURES.get(kind) or fx.MSE_FIXTURES.get(kind) or {"conv8": fx.BF16_FIXTURE, "shared": fx.SHARED_FIXTURE}[kind]
     model = fx.make_model(kind).to(dtype=dtype)
     train = data.TensorDataset(*fx.make_data(kind, spec.n_train, seed=1))
     query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
@@ -188,6 +188,12 @@ def run_presets(out_path: str) -> None:
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "presets":
         run_presets(os.path.join(HERE, "presets.json"))
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "mse":  # well-conditioned fixtures for the default damping 1e-8
+        torch.manual_seed(0)
+        for kind in fx.MSE_FIXTURES:
+            for tag, dtype in (("fp64", torch.float64), ("fp32", torch.float32)):
+                run(kind, dtype, os.path.join(HERE, f"{kind}_{tag}.safetensors"))
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "widen":
         torch.manual_seed(0)

@@ -110,6 +110,20 @@ def test_stage_isolated_scores_and_batching_invariances_host_logic(kind, tmp_pat
     scenario(kind, tmp_path)
 
 
+@pytest.mark.parametrize("kind", list(fx.MSE_FIXTURES))
+def test_default_damping_host_logic(kind, tmp_path, cpu_engine):
+    from test_pipeline_gpu import test_default_damping_matches_reference_goldens as scenario
+
+    scenario(kind, tmp_path)
+
+
+@pytest.mark.parametrize("kind", list(fx.FIXTURES))
+def test_default_damping_ill_conditioned_host_logic(kind, tmp_path, cpu_engine):
+    from test_pipeline_gpu import test_default_damping_on_ill_conditioned_fixtures as scenario
+
+    scenario(kind, tmp_path)
+
+
 def test_shared_parameters_host_logic(tmp_path, cpu_engine):
     from test_pipeline_gpu import test_shared_parameters_factors_match_reference_and_scores_match_autograd as scenario
 
@@ -200,3 +214,36 @@ def test_profile_flag_writes_stage_timing_summaries(tmp_path, cpu_engine):
     text = (out / "factors_f_summary_rank_0.txt").read_text()
     assert all(stage in text for stage in ("fit_covariance", "perform_eigendecomposition", "fit_lambda"))
     assert "compute_self_scores" in (out / "scores_s_self_summary_rank_0.txt").read_text()
+
+
+def test_in_place_write_to_a_hooked_activation_is_detected(tmp_path, cpu_engine):
+    """The hooks hold the layer input by reference (no clone, as the reference); with all parameters frozen autograd
+    would not notice a later in-place write to it, the tracker does."""
+    import torch
+    from torch import nn
+
+    from kronfluence_amd import FactorArguments, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.utils.state import State
+    from test_pipeline_gpu import make_task
+
+    class Clobber(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(12, 16), nn.Linear(16, 3)
+
+        def forward(self, x):
+            h = self.a(x) + 1.0  # an op that does not save its output: autograd will not notice the write below
+            out = self.b(h)
+            h.mul_(2.0)  # in-place write to the input of `b` after `b` has run
+            return out
+
+    task = make_task("mlp")
+    model = prepare_model(Clobber(), task)
+    state, fargs = State(), FactorArguments(use_empirical_fisher=True)
+    batches = fx.batches(fx.make_data("mlp", 16, seed=1), 8)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, batches, fargs)  # covariance consumes inputs at once
+    eig = perform_eigendecomposition(cov, model, state, fargs)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        fit_lambda_matrices_with_loader(model, state, task, batches, fargs, eig)

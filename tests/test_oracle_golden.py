@@ -27,7 +27,7 @@ def _relerr(a, b):
 
 
 def _run(kind, dtype):
-    spec = fx.FIXTURES[kind]
+    spec = fx.spec_of(kind)
     model = fx.make_model(kind).to(dtype=dtype)
     train = fx.make_data(kind, spec.n_train, seed=1)
     query = fx.make_data(kind, spec.n_query, seed=2)
@@ -98,6 +98,33 @@ def test_stage_isolated_scores_with_reference_factors(kind, tag, dtype, damp_key
                                  _nested(gold, "eig"), _nested(gold, "lam"), damping)
     err = _relerr(got, gold[f"scores/{damp_key}"])
     assert err <= tol, err
+
+
+@pytest.mark.parametrize("kind", list(fx.MSE_FIXTURES))
+@pytest.mark.parametrize("tag,dtype,tol", [("fp64", torch.float64, 1e-10), ("fp32", torch.float32, 2e-5)])
+def test_oracle_matches_reference_goldens_at_default_damping(kind, tag, dtype, tol):
+    """Well-conditioned fixtures (``fixtures.is_regression``): the oracle reproduces the reference END TO END at the
+    reference's default damping 1e-8 -- 1e-8 in fp64, 2e-4 in fp32 (the reference's fp32 run itself sits 7e-6 .. 5e-5
+    from its fp64 run there) -- and stage-isolated on the reference's factors to 5e-5 in fp32."""
+    gold = load_file(os.path.join(GOLDEN, f"{kind}_{tag}.safetensors"))
+    spec = fx.MSE_FIXTURES[kind]
+    engine, cov, eig, lam, train, query, loss, measure = _run(kind, dtype)
+    for factor, per_module in _nested(gold, "cov").items():
+        for module, want in per_module.items():
+            got = cov[factor][module]
+            if want.dtype == torch.int64:
+                assert torch.equal(got.reshape(-1), want.reshape(-1)), (factor, module)
+            else:
+                assert _relerr(got, want) <= tol, (factor, module)
+    for module, want in _nested(gold, "lam")["lambda_matrix"].items():
+        assert _relerr(lam["lambda_matrix"][module], want) <= max(tol * 50, 1e-8), module
+    q, t = fx.batches(query, spec.query_batch), fx.batches(train, spec.train_batch)
+    for key, damping in (("scores/damp1e-8", 1e-8), ("scores/dampNone", None)):
+        got = engine.pairwise_scores(q, t, measure, loss, eig, lam, damping)
+        bound = 1e-8 if dtype == torch.float64 else 2e-4
+        assert got.shape == gold[key].shape and _relerr(got, gold[key]) <= bound, (key, _relerr(got, gold[key]))
+        iso = engine.pairwise_scores(q, t, measure, loss, _nested(gold, "eig"), _nested(gold, "lam"), damping)
+        assert _relerr(iso, gold[key]) <= (2e-9 if dtype == torch.float64 else 5e-5), (key, _relerr(iso, gold[key]))
 
 
 def test_eigh_invariants():
