@@ -58,7 +58,11 @@ def _loss_scale(factor_args: FactorArguments) -> float:
 
 def _fit_covariance_matrices_with_loader_impl(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
                                         factor_args: FactorArguments, tracked_module_names: Optional[List[str]] = None,
-                                        disable_tqdm: bool = False) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+                                        disable_tqdm: bool = False, all_ranks: bool = False,
+                                        cpu: bool = True) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+    """``all_ranks`` / ``cpu`` are this engine's additions: the covariances are ALL-reduced (not reduced to rank 0), so
+    every rank already holds the sums -- ``all_ranks=True`` returns them everywhere (the reference hands factors to the
+    other ranks through the file system) and ``cpu=False`` leaves them in HBM for the next stage."""
     del disable_tqdm
     update_factor_args(model, factor_args)
     if tracked_module_names is None:
@@ -84,11 +88,11 @@ def _fit_covariance_matrices_with_loader_impl(model: nn.Module, state: State, ta
     if state.use_distributed:
         synchronize_factors(model, COVARIANCE_FACTOR_NAMES, tracked_module_names, state.device, extra=[num_data_processed])
     saved: FACTOR_TYPE = {}
-    if state.is_main_process:
+    if state.is_main_process or all_ranks:
         dtypes = {ACTIVATION_COVARIANCE_MATRIX_NAME: factor_args.activation_covariance_dtype,
                   GRADIENT_COVARIANCE_MATRIX_NAME: factor_args.gradient_covariance_dtype}
         for name in COVARIANCE_FACTOR_NAMES:
-            factor = load_factors(model, name, tracked_module_names, cpu=True, dtype=dtypes.get(name))
+            factor = load_factors(model, name, tracked_module_names, cpu=cpu, dtype=dtypes.get(name))
             if len(factor) == 0:
                 raise ValueError(f"Factor `{name}` has not been computed.")
             saved[name] = factor

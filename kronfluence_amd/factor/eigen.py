@@ -83,12 +83,12 @@ def lambda_matrices_exist(output_dir: Path, partition=None) -> bool:
 
 @torch.no_grad()
 def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module, state: State,
-                               factor_args: FactorArguments, disable_tqdm: bool = False) -> FACTOR_TYPE:
+                               factor_args: FactorArguments, disable_tqdm: bool = False, cpu: bool = True) -> FACTOR_TYPE:
     """``eigh(0.5 (C + C^T) / count)`` in fp64 for both factors of every tracked layer, on the MI355X
     (``kf_eigh_f64``).  The 2L matrices are independent: with several ranks they are dealt
     round-robin and the results are exchanged by broadcast, instead of rank 0 doing all of them while
     the others wait at a barrier (reference ``factor_computer.py:449-470``).  Results are cast back
-    to the covariance dtype and returned on the CPU (``eigen.py:214-219``)."""
+    to the covariance dtype and returned on the CPU (``eigen.py:214-219``), or left in HBM with ``cpu=False``."""
     del disable_tqdm
     out: FACTOR_TYPE = {name: {} for name in EIGENDECOMPOSITION_FACTOR_NAMES}
     jobs = []
@@ -140,28 +140,34 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
                 future.result()
         torch.cuda.synchronize(state.device)
 
+    # Results travel in the factor's own dtype (fp32 unless the covariances were fp64): half the bytes of the fp64
+    # solver output, tensor broadcasts over RCCL (no pickling), one per matrix.
     for index, (module_name, cov_name, count_name, vec_name, val_name) in enumerate(jobs):
         cov = covariance_factors[cov_name][module_name]
         original_dtype = cov.dtype
         owner = index % world
         d = cov.shape[0]
         if (module_name, cov_name) in results:
-            evals, evecs = results[(module_name, cov_name)]
+            evals, evecs = results.pop((module_name, cov_name))
+            evals, evecs = evals.to(original_dtype), evecs.to(original_dtype).contiguous()
         else:
-            evals = torch.empty(d, dtype=torch.float64, device=state.device)
-            evecs = torch.empty((d, d), dtype=torch.float64, device=state.device)
+            evals = torch.empty(d, dtype=original_dtype, device=state.device)
+            evecs = torch.empty((d, d), dtype=original_dtype, device=state.device)
         if world > 1:
             dist.broadcast(evals, src=owner)
             dist.broadcast(evecs, src=owner)
-        out[val_name][module_name] = evals.to(dtype=original_dtype, device="cpu").contiguous()
-        out[vec_name][module_name] = evecs.to(dtype=original_dtype, device="cpu").contiguous()
+        target = "cpu" if cpu else state.device
+        out[val_name][module_name] = evals.to(device=target).contiguous()
+        out[vec_name][module_name] = evecs.to(device=target).contiguous()
     return out
 
 
 def _fit_lambda_matrices_with_loader_impl(model: nn.Module, state: State, task: Task, loader: data.DataLoader,
                                     factor_args: FactorArguments, eigen_factors: Optional[FACTOR_TYPE] = None,
                                     tracked_module_names: Optional[List[str]] = None,
-                                    disable_tqdm: bool = False) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+                                    disable_tqdm: bool = False, all_ranks: bool = False,
+                                    cpu: bool = True) -> Tuple[torch.Tensor, FACTOR_TYPE]:
+    """``all_ranks`` / ``cpu``: see ``fit_covariance_matrices_with_loader``."""
     del disable_tqdm
     update_factor_args(model, factor_args)
     if tracked_module_names is None:
@@ -189,9 +195,9 @@ def _fit_lambda_matrices_with_loader_impl(model: nn.Module, state: State, task: 
     if state.use_distributed:
         synchronize_factors(model, LAMBDA_FACTOR_NAMES, tracked_module_names, state.device, extra=[num_data_processed])
     saved: FACTOR_TYPE = {}
-    if state.is_main_process:
+    if state.is_main_process or all_ranks:
         for name in LAMBDA_FACTOR_NAMES:
-            factor = load_factors(model, name, tracked_module_names, cpu=True,
+            factor = load_factors(model, name, tracked_module_names, cpu=cpu,
                                   dtype=factor_args.lambda_dtype if name == LAMBDA_MATRIX_NAME else None)
             if len(factor) == 0:
                 raise ValueError(f"Factor `{name}` has not been computed.")

@@ -66,12 +66,44 @@ LOW_RANK_EXPANSION_BYTES = 4 << 30
 
 def dense_queries(preconditioned, score_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """The held query gradients as one dense ``[Q, O, I']`` tensor (expands low-rank factors)."""
+    if isinstance(preconditioned, TiledQueries):
+        return preconditioned.dense()
     if isinstance(preconditioned, list):
         dense = ops.low_rank_product(preconditioned[0], preconditioned[1])
         return ops.cast(dense, torch.bfloat16) if score_dtype == torch.bfloat16 else dense
     if preconditioned.dtype not in (torch.float32, torch.bfloat16):
         return preconditioned.to(torch.float32)
     return preconditioned
+
+
+class TiledQueries:
+    """The held bf16 query gradients of one layer in the layout the bf16 score contraction streams best: k-tile-major
+    ``[D'/64, Q, 64]`` with ``D' = O * I'_pad`` (``I'`` zero-padded to a multiple of 8, see ``PAD_PATCH_AXIS``).  Built
+    ONCE per train pass, in query chunks, and it REPLACES the dense ``[Q, O, I']`` block in ``module.storage``: at BERT /
+    GPT-2 scale the dense block is 150-175 GB, a second (let alone a padded third) copy does not fit 288 GB."""
+
+    CHUNK = 64  # queries converted at a time (bounds the padded temporary)
+
+    def __init__(self, dense: torch.Tensor, pad: int) -> None:
+        q, o, ip = dense.shape
+        self.num_queries, self.rows, self.width, self.pad = q, o, ip + pad, pad
+        d = o * self.width
+        assert dense.dtype == torch.bfloat16 and d % 64 == 0
+        self.tiled = torch.empty((d // 64, q, 64), dtype=torch.bfloat16, device=dense.device)
+        for start in range(0, q, self.CHUNK):
+            block = dense[start:start + self.CHUNK]
+            if pad:
+                block = torch.nn.functional.pad(block, (0, pad))
+            self.tiled[:, start:start + block.shape[0]] = block.reshape(block.shape[0], d // 64, 64).transpose(0, 1)
+
+    @property
+    def shape(self):
+        return (self.num_queries, self.rows, self.width)
+
+    def dense(self) -> torch.Tensor:
+        """Back to ``[Q, O, I']`` (rare paths only)."""
+        full = self.tiled.transpose(0, 1).reshape(self.num_queries, self.rows, self.width)
+        return full[:, :, :self.width - self.pad].contiguous()
 
 
 class PairwiseScoreTracker(BaseTracker):
@@ -95,40 +127,36 @@ class PairwiseScoreTracker(BaseTracker):
         for start in range(0, q, step):
             yield start, dense_queries([left[start:start + step], right[start:start + step]], score_dtype)
 
-    _tiled = None  # (source tensor, k-tile-major bf16 copy) of the held query gradients
     # bf16 layers whose augmented input axis I' is not a multiple of 8 -- a first conv layer (3*3*3 = 27 patch columns),
     # or ANY Linear with a bias applied to sequences (I' = I + 1: BERT / GPT-2 shapes) -- would fall back to the fp32
     # engine for the per-sample gradients and the score contraction (about 8x slower than the bf16 MFMA engine).
     # Instead that axis is zero-padded to the next multiple of 8 on both sides of the contraction (the bias column of
-    # ones is materialised first): <P_q, g_n> is unchanged, P is padded once per train pass.
+    # ones is materialised first): <P_q, g_n> is unchanged, P is padded once per train pass (inside ``TiledQueries``).
     PAD_PATCH_AXIS = True
-    _padded = None  # (source tensor, zero-padded copy) of the held query gradients
 
-    def _pad_patch_axis(self, block: torch.Tensor, a: torch.Tensor, g: torch.Tensor, ones: bool):
-        """-> ``(block, a, ones)`` with ``a`` and the last axis of ``block`` padded when that unlocks the bf16 engine."""
-        width = a.shape[-1] + int(ones)
-        pad = (-width) % 8
-        if (not self.PAD_PATCH_AXIS or pad == 0 or g.shape[1] == 1 or block.dtype != torch.bfloat16
-                or a.dtype != torch.bfloat16 or g.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0
-                or block.shape[-1] != width):
-            return block, a, ones
-        if self._padded is None or self._padded[0] is not block:
-            self._padded = (block, torch.nn.functional.pad(block, (0, pad)).contiguous())
-        if ones:
-            a = torch.cat([a, a.new_ones(a.shape[:-1] + (1,)), a.new_zeros(a.shape[:-1] + (pad,))], dim=-1)
-        else:
-            a = torch.nn.functional.pad(a, (0, pad))
-        return self._padded[1], a, False
-
-    def _tiled_queries(self, preconditioned: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool):
-        """k-tile-major copy of the bf16 query gradients, built once per train pass (see
-        ``ops.k_tile_major``); ``None`` when the fast layout does not apply."""
-        d = preconditioned.shape[1] * preconditioned.shape[2]
-        if preconditioned.dtype != torch.bfloat16 or g.shape[1] == 1 or d % 64 != 0 or g.dtype != torch.bfloat16:
-            return None
-        if self._tiled is None or self._tiled[0] is not preconditioned:
-            self._tiled = (preconditioned, ops.k_tile_major(preconditioned))
-        return self._tiled[1]
+    def _fast_layout(self, preconditioned, g: torch.Tensor, a: torch.Tensor, ones: bool):
+        """-> ``(TiledQueries, a, ones)`` when the bf16 k-tile-major score engine applies to this layer (bf16 queries and
+        factors, several rows per sample, ``O % 8 == 0``, ``O * I'_pad % 64 == 0``), else ``None``.  The first call of a
+        train pass converts the held dense block and replaces it in ``module.storage``."""
+        tiled = preconditioned if isinstance(preconditioned, TiledQueries) else None
+        if tiled is None:
+            if (not torch.is_tensor(preconditioned) or preconditioned.dtype != torch.bfloat16 or g.shape[1] == 1
+                    or g.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0):
+                return None
+            width = a.shape[-1] + int(ones)
+            pad = (-width) % 8 if self.PAD_PATCH_AXIS else 0
+            if preconditioned.shape[-1] != width or (width + pad) % 8 != 0 or (g.shape[-1] * (width + pad)) % 64 != 0:
+                return None
+            tiled = TiledQueries(preconditioned, pad)
+            self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = tiled  # the dense block is released
+        if tiled.pad or ones:  # materialise the ones column and the zero padding on the train side as well
+            parts = [a]
+            if ones:
+                parts.append(a.new_ones(a.shape[:-1] + (1,)))
+            if tiled.pad:
+                parts.append(a.new_zeros(a.shape[:-1] + (tiled.pad,)))
+            a = torch.cat(parts, dim=-1)
+        return tiled, a, False
 
     def register_hooks(self) -> None:
         module = self.module
@@ -148,6 +176,8 @@ class PairwiseScoreTracker(BaseTracker):
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
             num_queries = preconditioned[0].shape[0] if isinstance(preconditioned, list) else preconditioned.shape[0]
+            if isinstance(preconditioned, TiledQueries) and module.per_sample_gradient_process_fnc is not None:
+                preconditioned = preconditioned.dense()
             batch = output_gradient.shape[0]
             per_token = module.score_args.compute_per_token_scores and activation.dim() == 3 and module.score_sink is not None
             if module.score_sink is not None:
@@ -173,11 +203,14 @@ class PairwiseScoreTracker(BaseTracker):
                     a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
                                       append_ones=ones).reshape(n, r, -1)
                     ones = False
-                for first, block in self._query_blocks(preconditioned):
-                    rows = scores[first:first + block.shape[0]]
-                    block, a_in, ones_in = self._pad_patch_axis(block, a, g, ones)
-                    ops.pairwise_score(rows, offset, block, g, a_in, ones_in, scale=module.gradient_scale,
-                                       p_tiled=self._tiled_queries(block, g, a_in, ones_in))
+                fast = self._fast_layout(preconditioned, g, a, ones)
+                if fast is not None:
+                    tiled, a_in, ones_in = fast
+                    ops.pairwise_score(scores, offset, tiled, g, a_in, ones_in, scale=module.gradient_scale)
+                else:
+                    for first, block in self._query_blocks(preconditioned):
+                        rows = scores[first:first + block.shape[0]]
+                        ops.pairwise_score(rows, offset, block, g, a, ones, scale=module.gradient_scale)
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()
@@ -231,9 +264,7 @@ class PairwiseScoreTracker(BaseTracker):
         self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.module.score_sink = None
-        self._tiled = None
         self._expanded = None
-        self._padded = None
         self.clear_all_cache()
 
     def release_memory(self) -> None:

@@ -61,13 +61,15 @@ def syrk_accum(cov: torch.Tensor, x: torch.Tensor, n_rows: int, d_in: int, rows_
     if count is not None:
         nat.require_device(count, "count")
         assert count.dtype == torch.int64
-    nat.check(
-        nat.lib().kf_syrk_accum(cov.data_ptr(), cov.shape[1], x.data_ptr(), nat.dtype_code(x.dtype), n_rows, d_in,
-                                rows_inner, outer_stride, row_stride, col_stride, _ptr(mask),
-                                nat.dtype_code(mask.dtype) if mask is not None else 0, int(append_ones), alpha,
-                                _ptr(count), nat.stream_ptr(x.device)),
-        "kf_syrk_accum",
-    )
+    d = d_in + int(append_ones)
+    with _Timed("syrk_accum", x.device, float(n_rows) * d * (d + 1), float(n_rows) * d_in * x.element_size()):
+        nat.check(
+            nat.lib().kf_syrk_accum(cov.data_ptr(), cov.shape[1], x.data_ptr(), nat.dtype_code(x.dtype), n_rows, d_in,
+                                    rows_inner, outer_stride, row_stride, col_stride, _ptr(mask),
+                                    nat.dtype_code(mask.dtype) if mask is not None else 0, int(append_ones), alpha,
+                                    _ptr(count), nat.stream_ptr(x.device)),
+            "kf_syrk_accum",
+        )
 
 
 def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor],
@@ -320,11 +322,13 @@ def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, 
     assert gt.is_contiguous() and at.is_contiguous()
     o, ip = lam.shape
     assert gt.numel() == b * r * o and at.numel() == b * r * ip
-    nat.check(
-        nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), nat.dtype_code(gt.dtype), b, r, o, ip, scale,
-                                  nat.stream_ptr(lam.device)),
-        "kf_lambda_accum",
-    )
+    # the product of the rotated factors, squared and summed (the rotations themselves are kf_gemm calls)
+    with _Timed("lambda_accum", lam.device, 2.0 * b * r * o * ip, float(b) * r * (o + ip) * gt.element_size()):
+        nat.check(
+            nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), nat.dtype_code(gt.dtype), b, r, o, ip,
+                                      scale, nat.stream_ptr(lam.device)),
+            "kf_lambda_accum",
+        )
 
 
 # ---------------------------------------------------------------------------------------------
@@ -373,21 +377,44 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     return out
 
 
-# When set to a list, every pairwise_score call appends (start_event, end_event, algorithmic_flops):
-# bench.py uses it to time the dominant kernel with HIP events on the launch stream.
-SCORE_EVENT_LOG: Optional[list] = None
+# When set to a dict, the instrumented entry points append ``(start_event, end_event, algorithmic_flops,
+# algorithmic_bytes)`` under their name: bench.py times the hot kernels with HIP events on the launch stream.
+EVENT_LOG: Optional[dict] = None
 
 
-def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: torch.Tensor, a: torch.Tensor,
-                   append_ones: bool, scale: float = 1.0, p_tiled: Optional[torch.Tensor] = None) -> None:
+class _Timed:
+    """``with _Timed(name, device, flops, bytes):`` brackets a C-ABI call with HIP events when ``EVENT_LOG`` is on."""
+
+    def __init__(self, name: str, device, flops: float, nbytes: float) -> None:
+        self.name, self.device, self.flops, self.nbytes = name, device, flops, nbytes
+        self.start = None
+
+    def __enter__(self):
+        if EVENT_LOG is not None:
+            self.start, self.end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream(self.device))
+        return self
+
+    def __exit__(self, kind, value, trace):
+        if self.start is not None and kind is None and EVENT_LOG is not None:
+            self.end.record(torch.cuda.current_stream(self.device))
+            EVENT_LOG.setdefault(self.name, []).append((self.start, self.end, self.flops, self.nbytes))
+        return False
+
+
+def pairwise_score(scores: torch.Tensor, col_offset: int, p, g: torch.Tensor, a: torch.Tensor,
+                   append_ones: bool, scale: float = 1.0) -> None:
     """``scores[:, col_offset:col_offset+b] += scale * <P_q, g_n>`` (kf_pairwise_score).
 
     ``scores``: fp32 ``[Q, N]`` device buffer shared by all layers and all train batches of a shard.
-    ``p_tiled``: optional ``k_tile_major(p)`` copy (bf16, ``R > 1``, ``O*I' % 64 == 0``)."""
+    ``p``: dense ``[Q, O, I']`` (fp32 / bf16), or an object with ``.tiled`` (bf16 k-tile-major ``[O*I'/64, Q, 64]``, see
+    ``k_tile_major``) and ``.shape == (Q, O, I')`` -- ``R > 1`` only."""
     nat.require_device(scores, "scores")
-    nat.require_device(p, "p")
-    assert scores.dtype == torch.float32 and p.dtype in (torch.float32, torch.bfloat16)
-    assert scores.is_contiguous() and p.is_contiguous()
+    tiled = getattr(p, "tiled", None)
+    storage = tiled if tiled is not None else p
+    nat.require_device(storage, "p")
+    assert scores.dtype == torch.float32 and storage.dtype in (torch.float32, torch.bfloat16)
+    assert scores.is_contiguous() and storage.is_contiguous()
     g, a = _contig(g), _contig(a)
     assert g.dtype == a.dtype
     b, r, o = g.shape
@@ -397,21 +424,17 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p: torch.Tensor, g: to
     assert p.shape[1] == o and p.shape[2] == ip and scores.shape[0] == q and col_offset + b <= scores.shape[1]
     ws_bytes = nat.lib().kf_pairwise_workspace_bytes(b, r, o, ip)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
-    if SCORE_EVENT_LOG is not None:
-        start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        start.record(torch.cuda.current_stream(g.device))
-    nat.check(
-        nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1],
-                                    (p_tiled if p_tiled is not None else p).data_ptr(), nat.dtype_code(p.dtype),
-                                    q * 64 if p_tiled is not None else 0, q, g.data_ptr(),
-                                    a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
-                                    ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
-        "kf_pairwise_score",
-    )
-    if SCORE_EVENT_LOG is not None:
-        end.record(torch.cuda.current_stream(g.device))
-        flops = 2.0 * q * b * o * ip + (2.0 * b * r * o * ip if r > 1 else 0.0)
-        SCORE_EVENT_LOG.append((start, end, flops))
+    flops = 2.0 * q * b * o * ip + (2.0 * b * r * o * ip if r > 1 else 0.0)
+    # B_pair of SURVEY.md 8(d) for one call: the hooked factors once, P once, the score block read-modify-write
+    nbytes = b * r * (o + i) * g.element_size() + q * o * ip * storage.element_size() + 2.0 * q * b * 4
+    with _Timed("pairwise_score", g.device, flops, nbytes):
+        nat.check(
+            nat.lib().kf_pairwise_score(scores.data_ptr() + 4 * col_offset, scores.shape[1], storage.data_ptr(),
+                                        nat.dtype_code(storage.dtype), q * 64 if tiled is not None else 0, q, g.data_ptr(),
+                                        a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
+                                        ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
+            "kf_pairwise_score",
+        )
 
 
 def rowwise_dot(out: torch.Tensor, x: torch.Tensor, y: torch.Tensor, weight: Optional[torch.Tensor] = None,

@@ -139,7 +139,10 @@ def precondition(g, a, append_ones, q_g, q_a, lam_inv, scale=1.0, out_dtype=torc
     return out.to(out_dtype).contiguous()
 
 
-def pairwise_score(scores, col_offset, p, g, a, append_ones, scale=1.0, p_tiled=None) -> None:
+def pairwise_score(scores, col_offset, p, g, a, append_ones, scale=1.0) -> None:
+    if hasattr(p, "tiled"):  # TiledQueries: [D/64, Q, 64] -> dense [Q, O, I']
+        q, o, ip = p.shape
+        p = p.tiled.transpose(0, 1).reshape(q, o, ip)
     psg = _psg(g, a, append_ones)
     block = torch.einsum("qoi,boi->qb", p.double(), psg) * scale
     scores[:, col_offset:col_offset + psg.shape[0]] += block.to(scores.dtype)

@@ -199,6 +199,50 @@ def test_gpt2_shaped_workload_host_logic_matches_oracle(tmp_path, cpu_engine):
     assert got.shape == (4, 24) and rel(got, want) <= 2e-3, rel(got, want)
 
 
+def test_bert_shaped_workload_host_logic_matches_oracle(tmp_path, cpu_engine):
+    """bench.py's BERT-shaped classifier (tiny instance): every Linear tracked, ``[b, T, d]`` activations with random-length
+    padding masks (``Task.get_attention_mask``) for the encoder layers, one row per sample for pooler / classifier (the
+    mask then does not match the row count and is ignored, reference linear.py:33) -- factors and scores against the CPU
+    oracle on the same weights."""
+    import bench
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.module.utils import get_tracked_module_names
+    from oracle import ekfac_ref as ref
+    from torch.utils import data
+
+    torch.manual_seed(0)
+    kw = dict(layers=2, width=16, heads=2, inter=24, vocab=40, positions=8)
+    raw, twin = bench.Bert(**kw), bench.Bert(**kw)
+    twin.load_state_dict(raw.state_dict())
+    task = bench.make_glue_task()
+    spec = dict(vocab=40, tokens=8)
+    train, query = bench.synth_glue(spec, 24, 1, "cpu"), bench.synth_glue(spec, 4, 2, "cpu")
+    assert int(train[1].sum()) < train[1].numel()  # there IS padding
+    analyzer = Analyzer("t", prepare_model(raw, task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    names = get_tracked_module_names(analyzer.model)
+    assert len(names) == 2 * 6 + 2 and names[-2:] == ["pooler", "classifier"]
+    args = FactorArguments(use_empirical_fisher=True)
+    analyzer.fit_all_factors("f", data.TensorDataset(*train), per_device_batch_size=8, factor_args=args)
+    got = analyzer.compute_pairwise_scores("s", "f", data.TensorDataset(*query), data.TensorDataset(*train),
+                                           per_device_query_batch_size=2, per_device_train_batch_size=6,
+                                           score_args=ScoreArguments(damping_factor=None))["all_modules"]
+    engine = ref.OracleEngine(twin.double())
+    chunks = lambda d, bs: [tuple(t[i:i + bs] for t in d) for i in range(0, d[0].shape[0], bs)]  # noqa: E731
+    cov = engine.fit_covariance(chunks(train, 8), bench.glue_loss, lambda batch: batch[1])
+    eig = engine.eigendecomposition(cov)
+    lam = engine.fit_lambda(chunks(train, 8), bench.glue_loss, eig)
+    want = engine.pairwise_scores(chunks(query, 2), chunks(train, 6), bench.glue_margin, bench.glue_loss, eig, lam, None)
+    mine = analyzer.load_covariance_matrices("f")
+    for module in names:
+        assert rel(mine["activation_covariance"][module], cov["activation_covariance"][module]) <= 1e-5, module
+        assert torch.equal(mine["num_activation_covariance_processed"][module].reshape(-1),
+                           cov["num_activation_covariance_processed"][module].reshape(-1)), module
+    tokens = int(train[1].sum())
+    assert int(mine["num_activation_covariance_processed"]["layers.0.query"]) == tokens  # masked token count
+    assert int(mine["num_activation_covariance_processed"]["pooler"]) == 24            # one row per sample
+    assert got.shape == (4, 24) and rel(got, want) <= 2e-3, rel(got, want)
+
+
 def test_profile_flag_writes_stage_timing_summaries(tmp_path, cpu_engine):
     import fixtures as fx
     from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model

@@ -276,11 +276,14 @@ def test_pairwise_score_k_tile_major_layout(ops, q, b, r, o, i):
     p = _rand(q, o, i, seed=7).to(torch.bfloat16)
     g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
     want = ref.linear_pairwise_score(p.double(), a.double(), g.double(), False)
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
     pd = p.to(DEV)
-    tiled = ops.k_tile_major(pd)
-    assert tiled.shape == (o * i // 64, q, 64)
+    tiled = TiledQueries(pd, 0)
+    assert tiled.tiled.shape == (o * i // 64, q, 64) and torch.equal(tiled.tiled, ops.k_tile_major(pd))
+    assert torch.equal(tiled.dense(), pd)
     scores = torch.zeros(q, b, device=DEV)
-    ops.pairwise_score(scores, 0, pd, g.to(DEV), a.to(DEV), False, p_tiled=tiled)
+    ops.pairwise_score(scores, 0, tiled, g.to(DEV), a.to(DEV), False)
     plain = torch.zeros(q, b, device=DEV)
     ops.pairwise_score(plain, 0, pd, g.to(DEV), a.to(DEV), False)
     assert rel(scores, want) <= 4e-3 and rel(scores, plain) <= 2e-5

@@ -374,14 +374,14 @@ def test_bf16_conv_with_odd_patch_axis_is_padded_not_demoted(tmp_path):
     kw = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
     args = ScoreArguments(damping_factor=None, amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16)
     calls = []
-    original = PairwiseScoreTracker._pad_patch_axis
+    original = PairwiseScoreTracker._fast_layout
 
-    def spy(self, block, a, g, ones):
-        out = original(self, block, a, g, ones)
-        calls.append((a.shape[-1] + int(ones), out[1].shape[-1]))
+    def spy(self, preconditioned, g, a, ones):
+        out = original(self, preconditioned, g, a, ones)
+        calls.append((a.shape[-1] + int(ones), None if out is None else out[1].shape[-1]))
         return out
 
-    PairwiseScoreTracker._pad_patch_axis = spy
+    PairwiseScoreTracker._fast_layout = spy
     try:
         padded = analyzer.compute_pairwise_scores("pad", "f", query, train, score_args=args, **kw)["all_modules"]
         assert (27, 32) in calls, calls
@@ -389,7 +389,7 @@ def test_bf16_conv_with_odd_patch_axis_is_padded_not_demoted(tmp_path):
         plain = analyzer.compute_pairwise_scores("nopad", "f", query, train, score_args=args, **kw)["all_modules"]
     finally:
         PairwiseScoreTracker.PAD_PATCH_AXIS = True
-        PairwiseScoreTracker._pad_patch_axis = original
+        PairwiseScoreTracker._fast_layout = original
     assert rel(padded, plain) <= 2e-3, rel(padded, plain)
 
 
@@ -427,14 +427,14 @@ def test_bf16_sequence_linear_with_bias_is_padded_not_demoted(tmp_path):
     kw = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
     args = ScoreArguments(damping_factor=None, amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16)
     calls = []
-    original = PairwiseScoreTracker._pad_patch_axis
+    original = PairwiseScoreTracker._fast_layout
 
-    def spy(self, block, a, g, ones):
-        out = original(self, block, a, g, ones)
-        calls.append((a.shape[-1] + int(ones), out[1].shape[-1], out[2]))
+    def spy(self, preconditioned, g, a, ones):
+        out = original(self, preconditioned, g, a, ones)
+        calls.append((a.shape[-1] + int(ones), None if out is None else out[1].shape[-1], None if out is None else out[2]))
         return out
 
-    PairwiseScoreTracker._pad_patch_axis = spy
+    PairwiseScoreTracker._fast_layout = spy
     try:
         padded = analyzer.compute_pairwise_scores("pad", "f", query, train, score_args=args, **kw)["all_modules"]
         assert (17, 24, False) in calls and (25, 32, False) in calls, calls
@@ -442,5 +442,5 @@ def test_bf16_sequence_linear_with_bias_is_padded_not_demoted(tmp_path):
         plain = analyzer.compute_pairwise_scores("nopad", "f", query, train, score_args=args, **kw)["all_modules"]
     finally:
         PairwiseScoreTracker.PAD_PATCH_AXIS = True
-        PairwiseScoreTracker._pad_patch_axis = original
+        PairwiseScoreTracker._fast_layout = original
     assert rel(padded, plain) <= 2e-3, rel(padded, plain)

@@ -72,12 +72,12 @@ with torch.no_grad():
             model(x)
     torch.cuda.synchronize(); print(f"model fwd alone: {(time.perf_counter()-t0)*100:.2f} ms/batch")
 # per-layer pairwise_score timing on one train batch
-ops.SCORE_EVENT_LOG = []
+ops.EVENT_LOG = {}
 set_mode(model, "default", release_memory=True)
 def step1():
     return compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query, 250), 250, ResidentLoader((train[0][:1000], train[1][:1000]), 1000), sargs, fargs, None)
-step1(); ops.SCORE_EVENT_LOG = []
+step1(); ops.EVENT_LOG = {}
 step1(); torch.cuda.synchronize()
-for i, (s, e, f) in enumerate(ops.SCORE_EVENT_LOG):
+for i, (s, e, f, _) in enumerate(ops.EVENT_LOG['pairwise_score']):
     ms = s.elapsed_time(e)
     print(f"  score call {i}: {ms:.3f} ms  {f/ms/1e9:.0f} TFLOP/s  ({f/1e9:.1f} GF)")

@@ -18,8 +18,9 @@ for name, (o, i) in {"gpt2 c_fc (3072,768+1)": (3072, 768), "gpt2 c_attn (2304,7
         e.record(); torch.cuda.synchronize(); return s.elapsed_time(e) / 3, scores
     t_plain, s_plain = run(lambda sc: ops.pairwise_score(sc, 0, p, g, a, True))
     pad = (-(i + 1)) % 8
-    pp = F.pad(p, (0, pad)).contiguous(); tiled = ops.k_tile_major(pp)
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+    tiled = TiledQueries(p, pad)
     ap = torch.cat([a, a.new_ones(b, r, 1), a.new_zeros(b, r, pad)], dim=-1)
-    t_pad, s_pad = run(lambda sc: ops.pairwise_score(sc, 0, pp, g, ap, False, p_tiled=tiled))
+    t_pad, s_pad = run(lambda sc: ops.pairwise_score(sc, 0, tiled, g, ap, False))
     err = float((s_pad - s_plain).norm() / s_plain.norm())
     print(f"{name}: fp32-engine fallback {t_plain:.2f} ms ({fl/t_plain/1e9:.0f} TF/s) -> padded bf16 {t_pad:.2f} ms ({fl/t_pad/1e9:.0f} TF/s), rel diff {err:.1e}")

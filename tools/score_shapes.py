@@ -5,6 +5,7 @@ k-tile-major path, the NT score GEMM alone (-> the TN per-sample-gradient GEMM b
 import sys, os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kronfluence_amd import ops
+from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 dev = "cuda:0"
 shapes = {"l2": (128, 1600, 256), "l3": (128, 1152, 256), "l6": (256, 2304, 64), "lin": (10, 128, 1), "l1": (64, 27, 1024)}
 which = sys.argv[1:] or list(shapes)
@@ -14,12 +15,13 @@ for name in which:
     p = torch.randn(Q, o, i, device=dev).bfloat16()
     g = torch.randn(b, r, o, device=dev).bfloat16(); a = torch.randn(b, r, i, device=dev).bfloat16()
     scores = torch.zeros(Q, b, device=dev)
-    tiled = ops.k_tile_major(p) if (o * i) % 64 == 0 and r > 1 else None
-    for _ in range(2): ops.pairwise_score(scores, 0, p, g, a, False, p_tiled=tiled)
+    tq = TiledQueries(p, 0) if (o * i) % 64 == 0 and r > 1 else None
+    tiled = tq.tiled if tq is not None else None
+    for _ in range(2): ops.pairwise_score(scores, 0, tq if tq is not None else p, g, a, False)
     torch.cuda.synchronize()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
-    for _ in range(5): ops.pairwise_score(scores, 0, p, g, a, False, p_tiled=tiled)
+    for _ in range(5): ops.pairwise_score(scores, 0, tq if tq is not None else p, g, a, False)
     e.record(); torch.cuda.synchronize()
     ms = s.elapsed_time(e) / 5
     fl = 2.0 * Q * b * o * i + (2.0 * b * r * o * i if r > 1 else 0)
