@@ -130,6 +130,12 @@ int kf_gemm(float* C, int64_t ldc, int64_t c_batch_stride, const kf_view* A, con
 int kf_gemm_out(void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const kf_view* A,
                 const kf_view* B, int64_t batch, float alpha, void* stream);
 
+/* C[m, n] = sum_k A(m, k) B(n, k) + (n < bias_n ? bias[n] : 0), bf16 [A.rows, B.rows] with row stride ldc; bf16 operands,
+ * both K-contiguous (NT bf16 MFMA engine).  With B = the first I columns of Q^T (zero rows for padding) and bias = Q[I, :]
+ * this is "[X, 1] Q" -- the rotation of bias-augmented activations (module/linear.py:56-61 + tracker/factor.py:218-226)
+ * without materialising the ones column, at a padded output width. */
+int kf_gemm_bias_out(void* C, int64_t ldc, const kf_view* A, const kf_view* B, const float* bias, int64_t bias_n, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 2 -- eigendecomposition and Lambda
  * ------------------------------------------------------------------------------------------- */
@@ -166,12 +172,13 @@ int kf_eigh_small_batched(const float* G, int64_t batch, int l, float* evals, fl
  * into the eigenbasis (two kf_gemm calls).  Identical mathematics to
  * module/tracker/factor.py:218-226 (Qg^T (g_b Qa), square_, sum(0)) because
  * Qg^T (sum_r g_r a_r^T) Qa = (G Qg)^T (A' Qa); costs 2 R (I'^2 + O^2 + O I') instead of
- * 2 O I' (I' + O + R) flops per sample.  Gt: [b,R,O], At: [b,R,I'] contiguous, dtype KF_F32, or KF_BF16
- * (FactorArguments.lambda_dtype = bf16 of the reference's low-precision preset: bf16 MFMA engine, fp32
- * accumulation; needs R > 1, O % 8 == 0, I' % 8 == 0).
+ * 2 O I' (I' + O + R) flops per sample.  Gt: [b,R,O], At: [b,R,ld_at] contiguous (ld_at >= I': rows of At may carry
+ * zero padding), dtype KF_F32 (ld_at == I'), or KF_BF16 (FactorArguments.lambda_dtype = bf16 of the reference's
+ * low-precision preset: bf16 MFMA engine, fp32 accumulation; needs R > 1, O % 8 == 0, ld_at % 8 == 0 -- an odd I' is
+ * carried zero-padded).
  * scale multiplies the per-sample gradient (gradient_scale, factor.py:269-270).
  */
-int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gt, const void* At, int dtype,
+int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gt, const void* At, int64_t ld_at, int dtype,
                     int64_t b, int64_t R, int64_t O, int64_t Ip, float scale, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
@@ -194,17 +201,19 @@ int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambd
  * G: [q,R,O], A: [q,R,I] (in_dtype, contiguous), Qg [O,O], Qa [I',I'], inv_lambda [O,I'] fp32.
  * P: [q,O,I'] in out_dtype (KF_F32, or KF_BF16 = ScoreArguments.score_dtype of the reference's
  * low-precision presets; all arithmetic and the staging of intermediate results stay fp32).
- * Qa_bf16 [I',I'] and QgT_bf16 = Qg^T [O,O] (bf16, nullable): when given with out_dtype KF_BF16
- * (ScoreArguments.precondition_dtype = bf16) the two back-rotations run on the bf16 MFMA engine;
- * with QaT_bf16 = Qa^T [I',I'] (bf16, nullable) and bf16 A without bias column also the forward rotation
- * A Qa, which costs 2 q R I'^2 flops and dominates for convolutions (R = output positions).
+ * ldp: elements between consecutive rows (o) of P; I' for a compact block.
+ * Qa_bf16, QaT_bf16 = Qa^T (bf16 [ldq, ldq], zero-padded from [I', I']; ldq = I' rounded up to a multiple of 8) and
+ * QgT_bf16 = Qg^T (bf16 [O, O]); all three nullable.  When given with out_dtype KF_BF16, bf16 inputs, R > 1 and
+ * ldp == ldq (ScoreArguments.precondition_dtype = bf16), all five contractions run on the bf16 MFMA engine at width
+ * ldq: P comes out with ldq - I' zero columns per row, which is how the score kernels want an odd I' (a Linear with bias
+ * on sequences, I' = I + 1) -- the bias column is the row Qa[I, :] added in an epilogue, not a torch.cat.
  * workspace (device): kf_precondition_workspace_bytes(q,R,O,I') bytes.
  */
 int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip);
-int kf_precondition(void* P, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q,
+int kf_precondition(void* P, int out_dtype, int64_t ldp, const void* G, const void* A, int in_dtype, int64_t q,
                     int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg, const float* Qa,
                     const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16, const void* QaT_bf16,
-                    void* workspace, int64_t workspace_bytes, void* stream);
+                    int64_t ldq, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * scores[q, n] += scale * sum_{o,i} P[q,o,i] * ( sum_r G[n,r,o] * A'[n,r,i] )   for n < b
@@ -224,6 +233,40 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dty
                       int64_t p_k_tile_stride, int64_t Q, const void* G, const void* A, int in_dtype,
                       int64_t b, int64_t R, int64_t O, int64_t I, int append_ones, float scale,
                       void* workspace, int64_t workspace_bytes, void* stream);
+
+/*
+ * Second-generation bf16 score path (ABI 8): the same contraction as kf_pairwise_score for R > 1, with P handed over
+ * k-tile-major ([D/64][Q][64] bf16) and both kernels fed by LDS-DMA (global_load_lds_dwordx4), which needs K-contiguous
+ * operands.  The per-sample gradients are formed k-tile-major in `workspace` and contracted with P by a 256 x 256-tile
+ * MFMA kernel (8 waves, split-K, fp32 atomics into the shared [Q, ld_scores] block).
+ *
+ * kf_pairwise_score_conv2d -- IMPLICIT im2col: replaces module/conv2d.py:15-64 (extract_patches / F.unfold),
+ * :134-177 (per-sample gradient einsum) and :179-209 (score einsum) without ever materialising the [b, P, I'] patch
+ * tensor.  G_nchw is the hooked output gradient as autograd delivers it, [b, O, O1, O2] bf16 contiguous (its
+ * (o, p) rows are already K-contiguous -- no `b c h w -> b (h w) c` copy, conv2d.py:130-132); x is the hooked layer
+ * input [b, C, H, W] bf16 contiguous.  A zero-padded, column-phase-split copy of x (s2 copies, ~1.3x the input instead of
+ * the k1 k2 / (s1 s2)-fold patch tensor) is written to the workspace and the gradient kernel fetches row
+ * i = (ky, kx, c) of A'^T straight from it.  THE PATCH AXIS OF P IS ORDERED (ky, kx, c), d = o * I' + (ky * k2 + kx) * C + c
+ * (the reference's is (c, ky, kx); the host permutes once when it builds the k-tile-major P).
+ * Needs groups == 1, no bias, O2 % 8 == 0, O1 * O2 % 64 == 0, C % 8 == 0, O * I' % 64 == 0, 16-byte aligned pointers;
+ * returns KF_ERR_INVALID_ARGUMENT otherwise (the host then uses kf_im2col + kf_pairwise_score).
+ *
+ * kf_pairwise_score_rows -- Linear layers on [b, R, .] activations (module/linear.py:68-77, :112-122): G [b, R, O] and
+ * A [b, R, I] bf16 contiguous are transposed to [b, O, R] / [b, I'p, R] in the workspace (the ones row of the bias column,
+ * linear.py:56-61, and the zero rows that pad I' to I'p, a multiple of 8, are generated there -- no torch.cat); P is
+ * [O * I'p / 64][Q][64] with the same padding.  Needs R % 64 == 0, O % 8 == 0, I % 8 == 0, I'p % 8 == 0,
+ * I'p >= I + append_ones, O * I'p % 64 == 0, b <= 65535.
+ */
+int64_t kf_pairwise_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2,
+                                           int s1, int s2, int p1, int p2, int d1, int d2);
+int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G_nchw,
+                             const void* x, int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2,
+                             int s1, int s2, int p1, int p2, int d1, int d2, float scale, void* workspace,
+                             int64_t workspace_bytes, void* stream);
+int64_t kf_pairwise_rows_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip);
+int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G, const void* A,
+                           int64_t b, int64_t R, int64_t O, int64_t I, int64_t Ip, int append_ones, float scale,
+                           void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * out[r] (+)= scale * sum_i X[r,i] * Y[r,i] * (W ? W[i] : 1)      r < rows, i < D

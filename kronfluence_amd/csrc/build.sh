@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 flags=(--offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics -Wall -Wno-unused-function)
 mkdir -p "${here}/obj"
 pids=()
-for src in kf_kernels kf_eigh; do
+for src in kf_kernels kf_eigh kf_score_v2; do
   stale=0
   [[ -f "${here}/obj/${src}.o" ]] || stale=1
   for dep in "${here}/${src}.hip" "${here}"/*.h "${here}/../../include/kronfluence_hip.h"; do
@@ -19,5 +19,5 @@ for src in kf_kernels kf_eigh; do
   fi
 done
 for p in "${pids[@]:-}"; do [[ -n "${p}" ]] && wait "${p}"; done
-"${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${here}/obj/kf_kernels.o" "${here}/obj/kf_eigh.o" -o "${out}"
+"${HIPCC}" --offload-arch=gfx950 -shared -fPIC "${here}/obj/kf_kernels.o" "${here}/obj/kf_eigh.o" "${here}/obj/kf_score_v2.o" -o "${out}"
 echo "built ${out}"

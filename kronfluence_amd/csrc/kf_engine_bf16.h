@@ -53,7 +53,20 @@ struct HalfGemmArgs {
     int symmetric;                  // TN only, A == B: upper-triangular tile pairs, both triangles written (SYRK)
     int64_t c_tile_stride;          // != 0: C[z] is one ROW (index z) of a k-tile-major matrix whose k index is
                                     // d = m*ldc + n:  element at (d/64)*c_tile_stride + z*64 + d%64
+    // epilogue extras (all nullable): v = alpha * acc + row_add[n] (n < row_add_n: the bias row of an eigenvector
+    // matrix, "[A, 1] Q = A Q[:I] + Q[I]"), then v *= mul[m * ld_mul + n] for n < mul_n and v = 0 for n >= mul_n
+    // (the EK-FAC Lambda^-1 on a column-padded output)
+    const float* row_add; int row_add_n;
+    const float* mul; int64_t ld_mul; int mul_n;
 };
+
+__device__ __forceinline__ float bf16_epilogue(const HalfGemmArgs& a, float acc, int m, int n) {
+    float v = a.alpha * acc;
+    if (m >= a.M || n >= a.N) return v;  // tile padding: never stored, and the side inputs must not be read there
+    if (a.row_add && n < a.row_add_n) v += a.row_add[n];
+    if (a.mul) v = n < a.mul_n ? v * a.mul[static_cast<int64_t>(m) * a.ld_mul + n] : 0.0f;
+    return v;
+}
 
 // Native 4-dword vector (not HIP's uint4 struct): keeps the staging registers in VGPRs -- with the
 // struct type hipcc demoted the arrays below to scratch memory (measured: 8 % of the bf16 peak).
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int ml = acc_row(wm, ti, r, lane), nl = acc_col(wn, tj, lane);
-                    uint32_t u = __float_as_uint(a.alpha * acc[ti][tj][r]);
+                    uint32_t u = __float_as_uint(bf16_epilogue(a, acc[ti][tj][r], m0 + ml, n0 + nl));
                     if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;
                     else u += 0x7fffu + ((u >> 16) & 1u);
                     *reinterpret_cast<uint16_t*>(hsm + ml * OP + nl * 2) = static_cast<uint16_t>(u >> 16);
@@ -265,7 +278,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
                 const int m = m0 + acc_row(wm, ti, r, lane), n = n0 + acc_col(wn, tj, lane);
                 if (m < a.M && n < a.N) {
                     const int64_t idx = cz + static_cast<int64_t>(m) * a.ldc + n;
-                    const float v = a.alpha * acc[ti][tj][r];
+                    const float v = bf16_epilogue(a, acc[ti][tj][r], m, n);
                     float* dst = reinterpret_cast<float*>(a.C) + idx;
                     if (a.atomic) atomicAdd(dst, v);
                     else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;

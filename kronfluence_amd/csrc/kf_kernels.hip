@@ -8,6 +8,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "../../include/kronfluence_hip.h"
 #include "kf_engine.h"
@@ -146,17 +147,18 @@ int bf16_engine_mode(const kf_view& A, const kf_view& B, const float* mul) {
     return 0;
 }
 
+// epilogue side inputs of the bf16 engine (see HalfGemmArgs)
+struct HalfExtras {
+    const float* row_add = nullptr; int row_add_n = 0;
+    const float* mul = nullptr; int64_t ld_mul = 0; int mul_n = 0;
+};
+
+int configure_kernels();  // defined after the kernels it configures
+
 int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const kf_view& A, const kf_view& B,
-                     int64_t batch, float alpha, float beta, hipStream_t st, int64_t c_tile_stride, bool symmetric = false) {
-    static bool configured = false;
-    if (!configured) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                HSMEM_BYTES) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                HSMEM_BYTES) != hipSuccess)
-            return KF_ERR_LAUNCH_FAILED;
-        configured = true;
-    }
+                     int64_t batch, float alpha, float beta, hipStream_t st, int64_t c_tile_stride, bool symmetric = false,
+                     const HalfExtras* extras = nullptr) {
+    if (configure_kernels() != KF_OK) return KF_ERR_LAUNCH_FAILED;
     const int64_t M = A.rows, N = B.rows, K = A.depth;
     const bool batch_sum = (c_batch_stride == 0 && batch > 1 && c_tile_stride == 0);
     const int64_t tm = cdiv(M, 128), tn = cdiv(N, 128);
@@ -183,6 +185,10 @@ int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batc
     h.ksplit = static_cast<int>(ksplit); h.kchunk = static_cast<int>(kchunk); h.alpha = alpha; h.beta = beta; h.atomic = atomic ? 1 : 0;
     h.tiles_m = static_cast<int>(tm); h.tiles_n = static_cast<int>(tn); h.chunks = static_cast<int>(batch * ksplit);
     h.symmetric = symmetric ? 1 : 0;
+    const HalfExtras none;
+    const HalfExtras& ex = extras ? *extras : none;
+    h.row_add = ex.row_add; h.row_add_n = ex.row_add_n; h.mul = ex.mul; h.ld_mul = ex.ld_mul; h.mul_n = ex.mul_n;
+    if ((ex.row_add || ex.mul) && (atomic || beta != 0.0f)) return KF_ERR_INVALID_ARGUMENT;  // applied once, on the full sum
     const int64_t nblocks = 8 * cdiv(batch * ksplit * (symmetric ? tm * (tm + 1) / 2 : tm * tn), 8);
     if (nblocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
     const dim3 grid(static_cast<unsigned>(nblocks));
@@ -738,6 +744,21 @@ __global__ void cast_kernel(void* dst, int dd, const void* src, int sd, int64_t 
     }
 }
 
+// One-time kernel attribute set-up, thread-safe (the header promises re-entrancy).
+int configure_kernels() {
+    static std::once_flag flag;
+    static int status = KF_OK;
+    std::call_once(flag, [] {
+        const bool ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
+        if (!ok) status = KF_ERR_LAUNCH_FAILED;
+    });
+    return status;
+}
+
 inline unsigned stream_grid(int64_t n) { return static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048))); }
 
 kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, int64_t rows, int64_t depth,
@@ -756,7 +777,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 7; }
+int kf_abi_version(void) { return 8; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -867,13 +888,7 @@ int kf_im2col(void* out, int out_dtype, const void* x, int in_dtype, int64_t b, 
                 la.RB = rb;
                 la.NR = (rb - 1) * s1 + (k1 - 1) * d1 + 1;
                 const size_t lds = static_cast<size_t>(la.NR) * row_bytes;
-                static bool configured = false;
-                if (!configured) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_lds_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess)
-                        return KF_ERR_LAUNCH_FAILED;
-                    configured = true;
-                }
+                if (configure_kernels() != KF_OK) return KF_ERR_LAUNCH_FAILED;
                 const int64_t blocks = b * ((a.O1 + rb - 1) / rb);
                 hipLaunchKernelGGL(im2col_lds_kernel, dim3(static_cast<unsigned>(blocks)), dim3(256), lds, as_stream(stream), la);
                 return launch_status();
@@ -899,33 +914,41 @@ int kf_gemm_out(void* C, int c_dtype, int64_t ldc, int64_t c_batch_stride, const
     return launch_gemm(C, ldc, c_batch_stride, *A, *B, batch, alpha, 0.0f, nullptr, 0, as_stream(stream), c_dtype);
 }
 
-int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gtv, const void* Atv, int dtype, int64_t b, int64_t R,
+int kf_gemm_bias_out(void* C, int64_t ldc, const kf_view* A, const kf_view* B, const float* bias, int64_t bias_n, void* stream) {
+    if (!C || !A || !B || !bias || bias_n < 0 || bias_n > B->rows) return KF_ERR_INVALID_ARGUMENT;
+    if (A->rows <= 0 || B->rows <= 0) return KF_OK;
+    if (A->depth != B->depth || bf16_engine_mode(*A, *B, nullptr) != 1 || (reinterpret_cast<uintptr_t>(C) & 15) != 0 || ldc % 8 != 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    HalfExtras ex;
+    ex.row_add = bias; ex.row_add_n = static_cast<int>(bias_n);
+    return launch_gemm_bf16(1, C, KF_BF16, ldc, 0, *A, *B, 1, 1.0f, 0.0f, as_stream(stream), 0, false, &ex);
+}
+
+int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gtv, const void* Atv, int64_t ld_at, int dtype, int64_t b, int64_t R,
                     int64_t O, int64_t Ip, float scale, void* stream) {
-    if (!Lambda || !Gtv || !Atv || b < 0 || R <= 0 || O <= 0 || Ip <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!Lambda || !Gtv || !Atv || b < 0 || R <= 0 || O <= 0 || Ip <= 0 || ld_at < Ip) return KF_ERR_INVALID_ARGUMENT;
+    if (dtype != KF_BF16 && ld_at != Ip) return KF_ERR_INVALID_ARGUMENT;
     if (dtype != KF_F32 && dtype != KF_BF16) return KF_ERR_UNSUPPORTED_DTYPE;
     if (b == 0) return KF_OK;
     hipStream_t st = as_stream(stream);
     if (dtype == KF_BF16) {
         // bf16 rotated factors: TN tiles on the bf16 MFMA engine, squared + summed over samples in registers
-        if (R == 1 || O % 8 != 0 || Ip % 8 != 0 || ((reinterpret_cast<uintptr_t>(Gtv) | reinterpret_cast<uintptr_t>(Atv)) & 15) != 0)
+        // rows of At are ld_at wide (I' zero-padded to a multiple of 8 by the rotation that produced them)
+        if (R == 1 || O % 8 != 0 || ld_at % 8 != 0 || ((reinterpret_cast<uintptr_t>(Gtv) | reinterpret_cast<uintptr_t>(Atv)) & 15) != 0)
             return KF_ERR_INVALID_ARGUMENT;
-        static bool configured = false;
-        if (!configured) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    HSMEM_BYTES) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-            configured = true;
-        }
+        if (configure_kernels() != KF_OK) return KF_ERR_LAUNCH_FAILED;
         HalfLambdaArgs la;
         HalfGemmArgs& h = la.g;
         h.C = Lambda; h.c_dtype = KF_F32; h.ldc = ld_lambda; h.c_batch_stride = 0;
         h.A.p = reinterpret_cast<const uint16_t*>(Gtv); h.A.batch_stride = R * O; h.A.ld = O; h.A.kt_stride = 64;
         h.A.rows = static_cast<int>(O); h.A.depth = static_cast<int>(R);
-        h.B.p = reinterpret_cast<const uint16_t*>(Atv); h.B.batch_stride = R * Ip; h.B.ld = Ip; h.B.kt_stride = 64;
-        h.B.rows = static_cast<int>(Ip); h.B.depth = static_cast<int>(R);
+        h.B.p = reinterpret_cast<const uint16_t*>(Atv); h.B.batch_stride = R * ld_at; h.B.ld = ld_at; h.B.kt_stride = 64;
+        h.B.rows = static_cast<int>(ld_at); h.B.depth = static_cast<int>(R);
         h.M = static_cast<int>(O); h.N = static_cast<int>(Ip); h.K = static_cast<int>(R);
         h.ksplit = 1; h.kchunk = static_cast<int>(cdiv(R, HBK) * HBK); h.alpha = 1.0f; h.beta = 0.0f; h.atomic = 1;
         h.tiles_m = static_cast<int>(cdiv(O, 128)); h.tiles_n = static_cast<int>(cdiv(Ip, 128)); h.chunks = 1;
         h.symmetric = 0; h.c_tile_stride = 0;
+        h.row_add = nullptr; h.row_add_n = 0; h.mul = nullptr; h.ld_mul = 0; h.mul_n = 0;
         const int64_t tiles = static_cast<int64_t>(h.tiles_m) * h.tiles_n;
         int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, tiles)));
         la.zchunk = static_cast<int>(cdiv(b, zsplit));
@@ -973,58 +996,76 @@ int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambd
 }
 
 int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip) {
-    // Gt, At, T and (for low-precision outputs) the fp32 staging copy of the rotated gradient
-    return static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ip + 2 * q * O * Ip);
+    // Gt, At, T and (for low-precision outputs) the fp32 staging copy of the rotated gradient; I' rounded up to the
+    // padded width the bf16 path may use
+    const int64_t Ipp = (Ip + 7) / 8 * 8;
+    return static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ipp + 2 * q * O * Ipp) + 1024;
 }
 
-int kf_precondition(void* Pout, int out_dtype, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O,
+int kf_precondition(void* Pout, int out_dtype, int64_t ldp, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O,
                     int64_t I, int append_ones, const float* Qg, const float* Qa, const float* inv_lambda, float scale,
-                    const void* Qa_bf16, const void* QgT_bf16, const void* QaT_bf16, void* workspace, int64_t workspace_bytes,
-                    void* stream) {
+                    const void* Qa_bf16, const void* QgT_bf16, const void* QaT_bf16, int64_t ldq, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
     if (!Pout || !G || !A || !Qg || !Qa || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
     if (!float_dtype(in_dtype) || (out_dtype != KF_F32 && out_dtype != KF_BF16)) return KF_ERR_UNSUPPORTED_DTYPE;
     const int64_t Ip = I + (append_ones ? 1 : 0);
+    if (ldp < Ip) return KF_ERR_INVALID_ARGUMENT;
     if (!workspace || workspace_bytes < kf_precondition_workspace_bytes(q, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (q == 0) return KF_OK;
     hipStream_t st = as_stream(stream);
+    // precondition_dtype = bf16 (reference low-precision preset): every O(q ..) contraction runs on the bf16 MFMA engine
+    // from bf16 copies of the eigenvectors (fp32 accumulation).  The augmented axis is carried at width ldq = I' rounded
+    // up to a multiple of 8 -- the copies Qa_bf16 / QaT_bf16 are [ldq, ldq] with zero padding, P has row stride ldp ==
+    // ldq and zero padding columns -- so layers with an odd I' (every Linear with bias on sequences: BERT, GPT-2) stay
+    // on the bf16 engine; the bias column "[A, 1] Qa = A Qa[:I] + Qa[I]" is a row added in the epilogue.
+    const bool low = Qa_bf16 && QgT_bf16 && QaT_bf16 && out_dtype == KF_BF16 && in_dtype == KF_BF16 && R > 1 && O % 8 == 0 && I % 8 == 0 &&
+                     I >= HBK && O >= HBK && ldq % 8 == 0 && ldq >= Ip && ldp == ldq &&
+                     ((reinterpret_cast<uintptr_t>(Qa_bf16) | reinterpret_cast<uintptr_t>(QgT_bf16) | reinterpret_cast<uintptr_t>(QaT_bf16) |
+                       reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Pout)) & 15) == 0;
+    int rc;
+    if (low) {
+        const int64_t W = ldq;
+        uint16_t* Gt16 = reinterpret_cast<uint16_t*>(workspace);   // [q R, O]
+        uint16_t* At16 = Gt16 + ((q * R * O + 127) & ~127LL);        // [q R, W]
+        uint16_t* rot16 = At16 + ((q * R * W + 127) & ~127LL);       // [q, O, W]
+        uint16_t* T16 = rot16 + ((q * O * W + 127) & ~127LL);        // [q, O, W]
+        // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']                (NT: B[n, k] = QgT[n, k])
+        rc = launch_gemm_bf16(1, Gt16, KF_BF16, O, 0, make_view(G, KF_BF16, 0, O, 1, q * R, O), make_view(QgT_bf16, KF_BF16, 0, O, 1, O, O), 1,
+                              1.0f, 0.0f, st, 0);
+        if (rc != KF_OK) return rc;
+        // At[(q r), i'] = sum_i A[(q r), i] Qa[i, i'] (+ Qa[I, i'])  (NT over the I real columns; pad columns come out zero)
+        HalfExtras bias;
+        if (append_ones) { bias.row_add = Qa + I * Ip; bias.row_add_n = static_cast<int>(Ip); }
+        rc = launch_gemm_bf16(1, At16, KF_BF16, W, 0, make_view(A, KF_BF16, 0, I, 1, q * R, I), make_view(QaT_bf16, KF_BF16, 0, W, 1, W, I), 1,
+                              1.0f, 0.0f, st, 0, false, &bias);
+        if (rc != KF_OK) return rc;
+        // rot[q][o, i] = (sum_r Gt[q, r, o] At[q, r, i]) * inv_lambda[o, i]   (TN, batched over q; zero in the pad columns)
+        HalfExtras lam;
+        lam.mul = inv_lambda; lam.ld_mul = Ip; lam.mul_n = static_cast<int>(Ip);
+        rc = launch_gemm_bf16(2, rot16, KF_BF16, W, O * W, make_view(Gt16, KF_BF16, R * O, 1, O, O, R), make_view(At16, KF_BF16, R * W, 1, W, W, R), q,
+                              1.0f, 0.0f, st, 0, false, &lam);
+        if (rc != KF_OK) return rc;
+        // T[(q o), j] = sum_i rot[(q o), i] Qa[j, i]                 (NT)
+        rc = launch_gemm_bf16(1, T16, KF_BF16, W, 0, make_view(rot16, KF_BF16, 0, W, 1, q * O, W), make_view(Qa_bf16, KF_BF16, 0, W, 1, W, W), 1,
+                              1.0f, 0.0f, st, 0);
+        if (rc != KF_OK) return rc;
+        // P[q][m, n] = scale * sum_o QgT[o, m] T[q][o, n]            (TN, batched over q)
+        return launch_gemm_bf16(2, Pout, KF_BF16, ldp, O * ldp, make_view(QgT_bf16, KF_BF16, 0, 1, O, O, O), make_view(T16, KF_BF16, O * W, 1, W, W, O), q,
+                                scale, 0.0f, st, 0);
+    }
+    if (ldp != Ip) return KF_ERR_INVALID_ARGUMENT;  // the fp32 path writes compact rows
     float* Gt = reinterpret_cast<float*>(workspace);
     float* At = Gt + q * R * O;
     float* T = At + q * R * Ip;
     // fp32 staging of the rotated gradient: the caller's buffer when it is fp32, else workspace
     float* P = out_dtype == KF_F32 ? reinterpret_cast<float*>(Pout) : T + q * O * Ip;
-    // precondition_dtype = bf16 (reference low-precision preset): the two O(q O I' (O + I')) back-rotations run on
-    // the bf16 MFMA engine from bf16 copies of the eigenvectors; the cheap forward rotation stays fp32.
-    const bool low = Qa_bf16 && QgT_bf16 && out_dtype == KF_BF16 && O % 8 == 0 && Ip % 8 == 0 && Ip >= HBK && O >= 8 &&
-                     ((reinterpret_cast<uintptr_t>(Qa_bf16) | reinterpret_cast<uintptr_t>(QgT_bf16)) & 15) == 0;
-    int rc;
     // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']
     rc = launch_gemm(Gt, O, 0, make_view(G, in_dtype, 0, O, 1, q * R, O), make_view(Qg, KF_F32, 0, 1, O, O, O), 1, 1.0f, 0.0f, nullptr, 0, st);
     if (rc != KF_OK) return rc;
     // At[(q r), i'] = sum_i [A,1][(q r), i] Qa[i, i']
-    if (low && QaT_bf16 && in_dtype == KF_BF16 && !append_ones && R > 1 &&
-        ((reinterpret_cast<uintptr_t>(QaT_bf16) | reinterpret_cast<uintptr_t>(A)) & 15) == 0) {
-        // 2 q R I'^2 flops -- for a convolution the largest term of the whole preconditioner: NT on the bf16 engine
-        rc = launch_gemm(At, Ip, 0, make_view(A, KF_BF16, 0, I, 1, q * R, I), make_view(QaT_bf16, KF_BF16, 0, Ip, 1, Ip, Ip), 1, 1.0f,
-                         0.0f, nullptr, 0, st, KF_F32);
-    } else {
-        rc = launch_gemm(At, Ip, 0, make_view(A, in_dtype, 0, I, 1, q * R, I, 0, append_ones ? 1 : 0),
-                         make_view(Qa, KF_F32, 0, 1, Ip, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
-    }
+    rc = launch_gemm(At, Ip, 0, make_view(A, in_dtype, 0, I, 1, q * R, I, 0, append_ones ? 1 : 0),
+                     make_view(Qa, KF_F32, 0, 1, Ip, Ip, Ip), 1, 1.0f, 0.0f, nullptr, 0, st);
     if (rc != KF_OK) return rc;
-    if (low) {
-        uint16_t* rot16 = reinterpret_cast<uint16_t*>(T);            // [q, O, I'] bf16
-        uint16_t* T16 = rot16 + q * O * Ip;                          // [q, O, I'] bf16
-        rc = launch_gemm(rot16, Ip, O * Ip, make_view(Gt, KF_F32, R * O, 1, O, O, R), make_view(At, KF_F32, R * Ip, 1, Ip, Ip, R), q, 1.0f,
-                         0.0f, inv_lambda, Ip, st, KF_BF16);
-        if (rc != KF_OK) return rc;
-        // T16[(q o), j] = sum_i rot16[(q o), i] Qa[j, i]            (NT, both K-contiguous)
-        rc = launch_gemm(T16, Ip, 0, make_view(rot16, KF_BF16, 0, Ip, 1, q * O, Ip), make_view(Qa_bf16, KF_BF16, 0, Ip, 1, Ip, Ip), 1, 1.0f,
-                         0.0f, nullptr, 0, st, KF_BF16);
-        if (rc != KF_OK) return rc;
-        // P[q][m, n] = scale * sum_o QgT[o, m] T16[q][o, n]         (TN, both K-strided, batched over q)
-        return launch_gemm(Pout, Ip, O * Ip, make_view(QgT_bf16, KF_BF16, 0, 1, O, O, O), make_view(T16, KF_BF16, O * Ip, 1, Ip, Ip, O), q,
-                           scale, 0.0f, nullptr, 0, st, KF_BF16);
-    }
     // rot[q][o,i] = (sum_r Gt[q,r,o] At[q,r,i]) * inv_lambda[o,i]   (stored in the caller's P buffer)
     rc = launch_gemm(P, Ip, O * Ip, make_view(Gt, KF_F32, R * O, 1, O, O, R), make_view(At, KF_F32, R * Ip, 1, Ip, Ip, R), q, 1.0f, 0.0f, inv_lambda, Ip, st);
     if (rc != KF_OK) return rc;

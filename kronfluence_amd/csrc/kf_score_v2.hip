@@ -1,0 +1,495 @@
+// kf_score_v2.hip -- second-generation bf16 score path (gfx950): LDS-DMA staged MFMA kernels.
+//
+// The R > 1 pairwise score of one layer and one train batch is two contractions (reference
+// module/conv2d.py:199-209, module/linear.py:112-122, module/tracker/pairwise_score.py:41-45):
+//
+//   psg[n][o, i]  = sum_r G[n, r, o] A'[n, r, i]                  per-sample gradient, K = R (64 .. 1024)
+//   scores[q, n] += scale * sum_{o,i} P[q, o, i] psg[n, o, i]     one GEMM over D = O I' (1e5 .. 2.4e6)
+//
+// Both kernels here stage their operand tiles with global_load_lds_dwordx4 (16 bytes per lane straight
+// into LDS: no staging VGPRs, no ds_write pass), so both operands must be K-CONTIGUOUS:
+//
+//   * score GEMM: P and psg are k-tile-major, [D/64][rows][64] -- one k-step of a 256-row tile is one
+//     contiguous 32 KB block;
+//   * per-sample gradient: G is consumed as [n][o][r] -- exactly the NCHW layout autograd hands a
+//     convolution's output gradient over -- and A' as [n][i][r].  For convolutions the rows of A' are never
+//     materialised (IMPLICIT im2col): row i = (ky, kx, c) of sample n is a strided walk over a zero-padded
+//     copy of the layer input, and because the LDS-DMA takes a per-lane source address, every 16-byte chunk
+//     (8 consecutive output columns of one output row) is fetched directly from that copy.  For Linear
+//     layers on sequences a small transposition kernel produces [n][o][t] / [n][i'][t] (and appends the
+//     ones row of the bias and the zero rows that pad I' to a multiple of 8).
+//
+// LDS image of an operand tile: [rows][64 k] bf16 with 128-byte rows and NO padding (the DMA writes lane-
+// linear); the 16-byte chunk c of row r lives at chunk position c ^ ((r >> 1) & 7), applied to the SOURCE
+// address of the DMA and to the ds_read_b128 fragment address alike, which makes the fragment reads
+// (lane l: row l & 31, k-octet l >> 5) bank-conflict free (cdna_hip_programming.md T2, rule 21).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+#include <mutex>
+
+#include "../../include/kronfluence_hip.h"
+#include "kf_engine.h"
+
+using namespace kf;
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+inline int launch_status() { return hipGetLastError() == hipSuccess ? KF_OK : KF_ERR_LAUNCH_FAILED; }
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    // 16 bytes per lane: global (per-lane address) -> LDS at lds_wave_base + lane * 16 (wave-uniform base in M0)
+    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
+                                         reinterpret_cast<uintptr_t>(src)),
+                                     reinterpret_cast<__attribute__((address_space(3))) void*>(
+                                         static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_wave_base))),
+                                     16, 0, 0);
+}
+
+__device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }
+
+// ------------------------------------------------------------------------------------------------
+// Score GEMM: C[m, n] += alpha * sum_k A[m, k] B[n, k], A and B k-tile-major bf16.
+// 512 threads = 8 wave64 as 2 (m) x 4 (n); 256 x 256 tile, each wave 128 x 64 = 4 x 2 accumulators of
+// v_mfma_f32_32x32x16_bf16; k-step 64; two LDS stages of 64 KB (A 32 KB + B 32 KB).
+// ------------------------------------------------------------------------------------------------
+struct ScoreV2Args {
+    float* C; int64_t ldc;
+    const uint16_t* A; const uint16_t* B;
+    int M, N, KT;                          // KT = K / 64
+    int tiles_m, tiles_n, ksplit, kchunk;  // kchunk in k-tiles
+    float alpha;
+};
+
+constexpr int SV2_THREADS = 512;
+constexpr int SV2_OPERAND_BYTES = 256 * 128;
+constexpr int SV2_STAGE_BYTES = 2 * SV2_OPERAND_BYTES;
+constexpr int SV2_SMEM = 2 * SV2_STAGE_BYTES;
+
+__global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    // XCD-aware block -> work mapping (workgroup L runs on XCD L % 8; speed only): the tiles of one k-chunk are
+    // consecutive items of one XCD, so their shared A / B panels are fetched from HBM once per XCD.
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.ksplit) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int chunk = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int m0 = (tile / a.tiles_n) * 256, n0 = (tile % a.tiles_n) * 256;
+    const int kt_begin = chunk * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
+
+    // DMA assignment: a wave instruction fills 8 rows x 128 B; wave w owns row groups 4 w .. 4 w + 3 of each operand
+    int off_a[4], off_b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+        const int chunk_src = (lane & 7) ^ lds_swz(row);
+        off_a[t] = min(m0 + row, a.M - 1) * 64 + chunk_src * 8;
+        off_b[t] = min(n0 + row, a.N - 1) * 64 + chunk_src * 8;
+    }
+    const int64_t a_kt = static_cast<int64_t>(a.M) * 64, b_kt = static_cast<int64_t>(a.N) * 64;
+    auto stage = [&](int buf, int kt) {
+        const uint16_t* ap = a.A + kt * a_kt;
+        const uint16_t* bp = a.B + kt * b_kt;
+        unsigned char* base = sm + buf * SV2_STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(ap + off_a[t], base + t * 1024);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(bp + off_b[t], base + SV2_OPERAND_BYTES + t * 1024);
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+
+    if (kt_begin < kt_end) {
+        const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+        stage(0, kt_begin);
+        __builtin_amdgcn_s_waitcnt(0);  // vmcnt(0) expcnt(0) lgkmcnt(0)
+        __syncthreads();
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
+            const unsigned char* sa = sm + buf * SV2_STAGE_BYTES + (wm * 128 + lr) * 128;
+            const unsigned char* sb = sm + buf * SV2_STAGE_BYTES + SV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((kk * 2 + hi) ^ sw) * 16;
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 128 + co);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[i][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 64 + jn * 32 + (lane & 31);
+                if (m < a.M && n < a.N) atomicAdd(a.C + static_cast<int64_t>(m) * a.ldc + n, a.alpha * acc[i][jn][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-sample gradient: out[n][m, i] = sum_k A[n][m, k] B[n][i, k], bf16, written k-tile-major over d = m * N + i.
+// 256 threads = 4 wave64 (2 x 2), 128 x 128 tile, k-step 64, two LDS stages of 32 KB -> two workgroups per CU.
+// B rows are plain ([n][i][k]) or implicit-im2col rows of a zero-padded, column-phase-split copy of the input.
+// ------------------------------------------------------------------------------------------------
+struct PsgV2Args {
+    uint16_t* out; int64_t out_tile_stride;     // element (n, d) at (d >> 6) * out_tile_stride + n * 64 + (d & 63)
+    const uint16_t* A; int64_t a_sample_stride; // [batch][M][K]
+    const uint16_t* B; int64_t b_sample_stride; // plain: [batch][N][K]; conv: [phase][batch][C][Hp][Wq]
+    int M, N, K;                                // K % 64 == 0
+    int batch, tiles_m, tiles_n;
+    // implicit im2col (conv != 0): row i = shift * C + c, shift = ky * k2 + kx;  k = oy * O2 + ox (O2 % 8 == 0);
+    // element = Xs[(kx * d2) % s2][n][c][s1 * oy + ky * d1][ox + (kx * d2) / s2]
+    int conv, C, k2, O2, s1, d1, s2, d2, Wq, plane /* Hp * Wq */;
+    int64_t phase_stride;                       // batch * C * plane
+};
+
+constexpr int PV2_OPERAND_BYTES = 128 * 128;
+constexpr int PV2_STAGE_BYTES = 2 * PV2_OPERAND_BYTES;
+constexpr int PV2_SMEM = 2 * PV2_STAGE_BYTES;
+
+__global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;  // the tiles of one sample run back to back on one XCD
+    if (j >= per_xcd || item >= items) return;
+    const int z = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
+
+    // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is chunk_src
+    const uint16_t* src_a[4];
+    const uint16_t* src_b[4];
+    int oct[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+        oct[t] = (lane & 7) ^ lds_swz(row);
+        const int m = min(m0 + row, a.M - 1);
+        src_a[t] = a.A + static_cast<int64_t>(z) * a.a_sample_stride + static_cast<int64_t>(m) * a.K + oct[t] * 8;
+        const int i = min(n0 + row, a.N - 1);
+        if (a.conv) {
+            const int shift = i / a.C, c = i - shift * a.C;
+            const int ky = shift / a.k2, kx = shift - ky * a.k2;
+            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
+            src_b[t] = a.B + phase * a.phase_stride + static_cast<int64_t>(z) * a.b_sample_stride +
+                       static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
+        } else {
+            src_b[t] = a.B + static_cast<int64_t>(z) * a.b_sample_stride + static_cast<int64_t>(i) * a.K + oct[t] * 8;
+        }
+    }
+    auto stage = [&](int buf, int k0) {
+        unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(src_a[t] + k0, base + t * 1024);
+        if (a.conv) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int p0 = k0 + oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2;
+                glds16(src_b[t] + oy * a.s1 * a.Wq + ox, base + PV2_OPERAND_BYTES + t * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) glds16(src_b[t] + k0, base + PV2_OPERAND_BYTES + t * 1024);
+        }
+    };
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    {
+        const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+        stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = 0; k0 < a.K; k0 += 64) {
+            if (k0 + 64 < a.K) stage(buf ^ 1, k0 + 64);
+            const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
+            const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((kk * 2 + hi) ^ sw) * 16;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + co);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + 32 * 128 + co);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    // epilogue: bf16 through LDS (pitch 272 B), then 16 bytes per lane into the k-tile-major gradient buffer
+    constexpr int OP = 272;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = acc_row(wm, ti, r, lane), nl = acc_col(wn, tj, lane);
+                uint32_t u = __float_as_uint(acc[ti][tj][r]);
+                if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;
+                else u += 0x7fffu + ((u >> 16) & 1u);
+                *reinterpret_cast<uint16_t*>(sm + ml * OP + nl * 2) = static_cast<uint16_t>(u >> 16);
+            }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int id = tid + 256 * it, ml = id >> 4, ch = id & 15;
+        const int m = m0 + ml, n = n0 + ch * 8;
+        if (m < a.M && n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
+            const int64_t d = static_cast<int64_t>(m) * a.N + n;
+            const int64_t idx = (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
+            *reinterpret_cast<u32x4*>(a.out + idx) = *reinterpret_cast<const u32x4*>(sm + ml * OP + ch * 16);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Zero-padded, column-phase-split copy of a convolution input for the implicit im2col above:
+//   Xs[phase][n][c][y][j] = x_pad[n][c][y][s2 * j + phase],  x_pad = x with p1 / p2 zero borders,
+//   y < Hp, j < Wq.  One 16-byte store (8 columns) per thread.
+// ------------------------------------------------------------------------------------------------
+struct PadArgs {
+    uint16_t* out; const uint16_t* x;
+    int64_t planes;  // batch * C
+    int H, W, Hp, Wq, p1, p2, s2;
+};
+
+__global__ __launch_bounds__(256) void conv_pad_phases_kernel(PadArgs a) {
+    const int wq8 = a.Wq >> 3;
+    const int64_t per_phase = a.planes * a.Hp * wq8, total = per_phase * a.s2;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int phase = static_cast<int>(e / per_phase);
+        int64_t rest = e - phase * per_phase;
+        const int jv = static_cast<int>(rest % wq8);
+        rest /= wq8;
+        const int y = static_cast<int>(rest % a.Hp);
+        const int64_t plane = rest / a.Hp;
+        const int iy = y - a.p1;
+        const bool row_ok = iy >= 0 && iy < a.H;
+        const uint16_t* src = a.x + (plane * a.H + (row_ok ? iy : 0)) * a.W;
+        uint32_t w[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const int ix = a.s2 * (jv * 8 + t) + phase - a.p2;
+            const bool ok = row_ok && ix >= 0 && ix < a.W;
+            const uint32_t v = src[min(max(ix, 0), a.W - 1)];
+            w[t >> 1] |= (ok ? v : 0u) << ((t & 1) * 16);
+        }
+        reinterpret_cast<u32x4*>(a.out)[e] = u32x4{w[0], w[1], w[2], w[3]};
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// [batch][T][C] -> [batch][Cp][T] (bf16), rows C .. Cp-1: the ones row of a bias (ones != 0) then zeros.
+// 64 x 64 tiles through LDS; T % 64 == 0, C % 8 == 0.
+// ------------------------------------------------------------------------------------------------
+struct TransposeArgs {
+    uint16_t* out; const uint16_t* x;
+    int T, C, Cp, ones;
+};
+
+__global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
+    __shared__ uint16_t tile[64][72];
+    const int t0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const int64_t z = blockIdx.z;
+    const uint16_t* x = a.x + z * static_cast<int64_t>(a.T) * a.C;
+    uint16_t* out = a.out + z * static_cast<int64_t>(a.Cp) * a.T;
+    // load: 64 rows (t) x 8 chunks of 8 columns
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = threadIdx.x + 256 * it, r = id >> 3, ch = id & 7;
+        const int c = c0 + ch * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (c < a.C) v = *reinterpret_cast<const u32x4*>(x + static_cast<int64_t>(t0 + r) * a.C + c);
+        else if (a.ones && c == a.C) v[0] = 0x3f80u;  // bf16 1.0 in column C, zeros after it
+        uint16_t* d = &tile[r][ch * 8];
+        d[0] = static_cast<uint16_t>(v[0]); d[1] = static_cast<uint16_t>(v[0] >> 16);
+        d[2] = static_cast<uint16_t>(v[1]); d[3] = static_cast<uint16_t>(v[1] >> 16);
+        d[4] = static_cast<uint16_t>(v[2]); d[5] = static_cast<uint16_t>(v[2] >> 16);
+        d[6] = static_cast<uint16_t>(v[3]); d[7] = static_cast<uint16_t>(v[3] >> 16);
+    }
+    __syncthreads();
+    // store: 64 rows (c) x 8 chunks of 8 t's
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = threadIdx.x + 256 * it, r = id >> 3, ch = id & 7;
+        const int c = c0 + r;
+        if (c < a.Cp) {
+            uint32_t w[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                w[t] = static_cast<uint32_t>(tile[ch * 8 + 2 * t][r]) | (static_cast<uint32_t>(tile[ch * 8 + 2 * t + 1][r]) << 16);
+            *reinterpret_cast<u32x4*>(out + static_cast<int64_t>(c) * a.T + t0 + ch * 8) = u32x4{w[0], w[1], w[2], w[3]};
+        }
+    }
+}
+
+int configure_once() {
+    static std::once_flag flag;
+    static int status = KF_OK;
+    std::call_once(flag, [] {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                SV2_SMEM) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                PV2_SMEM) != hipSuccess)
+            status = KF_ERR_LAUNCH_FAILED;
+    });
+    return status;
+}
+
+int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t* psg, int64_t Q, int64_t b, int64_t D,
+                    float scale, hipStream_t st) {
+    ScoreV2Args s;
+    s.C = scores; s.ldc = ld; s.A = P; s.B = psg;
+    s.M = static_cast<int>(Q); s.N = static_cast<int>(b); s.KT = static_cast<int>(D / 64);
+    s.tiles_m = static_cast<int>(cdiv(Q, 256)); s.tiles_n = static_cast<int>(cdiv(b, 256));
+    const int64_t tiles = static_cast<int64_t>(s.tiles_m) * s.tiles_n;
+    // one workgroup per CU and k-chunk: ~2 rounds of work items over the 256 CUs, at least 16 k-steps per item
+    int64_t ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(512, tiles), s.KT / 16));
+    const int64_t kchunk = cdiv(s.KT, ksplit);
+    ksplit = cdiv(s.KT, kchunk);
+    s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
+    const int64_t blocks = 8 * cdiv(ksplit * tiles, 8);
+    hipLaunchKernelGGL(score_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), SV2_SMEM, st, s);
+    return launch_status();
+}
+
+int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
+    p.tiles_m = static_cast<int>(cdiv(p.M, 128)); p.tiles_n = static_cast<int>(cdiv(p.N, 128));
+    const int64_t blocks = 8 * cdiv(static_cast<int64_t>(p.batch) * p.tiles_m * p.tiles_n, 8);
+    if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(psg_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), PV2_SMEM, st, p);
+    return launch_status();
+}
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~static_cast<int64_t>(255); }
+// columns of one phase copy: the last octet of an output row starts at O2 - 8 + ((k2 - 1) d2) / s2
+inline int64_t conv_wq(int64_t O2, int k2, int d2, int s2) { return (O2 + ((k2 - 1) * d2) / s2 + 7) / 8 * 8; }
+
+}  // namespace
+
+extern "C" {
+
+int64_t kf_pairwise_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2,
+                                           int p1, int p2, int d1, int d2) {
+    const int64_t O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1, O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
+    if (O1 <= 0 || O2 <= 0) return -1;
+    const int64_t Hp = H + 2 * p1, Wq = conv_wq(O2, k2, d2, s2);
+    const int64_t copies = align256(2 * s2 * b * C * Hp * Wq + 64);
+    const int64_t psg = align256(2 * b * O * C * k1 * k2);
+    return copies + psg;
+}
+
+int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G_nchw, const void* x,
+                             int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2,
+                             int d1, int d2, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!scores || !P_tiled || !G_nchw || !x || Q < 0 || b < 0 || C <= 0 || O <= 0) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1, O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
+    if (O1 <= 0 || O2 <= 0) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t P = O1 * O2, Ip = C * k1 * k2, D = O * Ip;
+    // eligibility (the host checks the same conditions and uses the materialised-patch path otherwise)
+    if (O2 % 8 != 0 || P % 64 != 0 || C % 8 != 0 || D % 64 != 0) return KF_ERR_INVALID_ARGUMENT;
+    if (((reinterpret_cast<uintptr_t>(P_tiled) | reinterpret_cast<uintptr_t>(G_nchw) | reinterpret_cast<uintptr_t>(x)) & 15) != 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    const int64_t need = kf_pairwise_conv2d_workspace_bytes(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    if (!workspace || workspace_bytes < need) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (Q == 0 || b == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    hipStream_t st = as_stream(stream);
+    const int64_t Hp = H + 2 * p1, Wq = conv_wq(O2, k2, d2, s2);
+    uint16_t* copies = reinterpret_cast<uint16_t*>(workspace);
+    uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align256(2 * s2 * b * C * Hp * Wq + 64));
+    PadArgs pa;
+    pa.out = copies; pa.x = reinterpret_cast<const uint16_t*>(x); pa.planes = b * C;
+    pa.H = static_cast<int>(H); pa.W = static_cast<int>(W); pa.Hp = static_cast<int>(Hp); pa.Wq = static_cast<int>(Wq);
+    pa.p1 = p1; pa.p2 = p2; pa.s2 = s2;
+    const int64_t chunks = s2 * b * C * Hp * (Wq / 8);
+    hipLaunchKernelGGL(conv_pad_phases_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(chunks, 256), 1 << 20))), dim3(256), 0,
+                       st, pa);
+    PsgV2Args g;
+    g.out = psg; g.out_tile_stride = b * 64;
+    g.A = reinterpret_cast<const uint16_t*>(G_nchw); g.a_sample_stride = O * P;
+    g.B = copies; g.b_sample_stride = C * Hp * Wq;
+    g.M = static_cast<int>(O); g.N = static_cast<int>(Ip); g.K = static_cast<int>(P); g.batch = static_cast<int>(b);
+    g.conv = 1; g.C = static_cast<int>(C); g.k2 = k2; g.O2 = static_cast<int>(O2); g.s1 = s1; g.d1 = d1; g.s2 = s2; g.d2 = d2;
+    g.Wq = static_cast<int>(Wq); g.plane = static_cast<int>(Hp * Wq); g.phase_stride = b * C * Hp * Wq;
+    int rc = launch_psg_v2(g, st);
+    if (rc != KF_OK) return rc;
+    return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, D, scale, st);
+}
+
+int64_t kf_pairwise_rows_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip) {
+    return align256(2 * b * O * R) + align256(2 * b * Ip * R) + align256(2 * b * O * Ip);
+}
+
+int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G, const void* A, int64_t b,
+                           int64_t R, int64_t O, int64_t I, int64_t Ip, int append_ones, float scale, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+    if (!scores || !P_tiled || !G || !A || Q < 0 || b < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (R % 64 != 0 || O % 8 != 0 || I % 8 != 0 || Ip % 8 != 0 || Ip < I + (append_ones ? 1 : 0) || (O * Ip) % 64 != 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    if (((reinterpret_cast<uintptr_t>(P_tiled) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(A)) & 15) != 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < kf_pairwise_rows_workspace_bytes(b, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (Q == 0 || b == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    if (b > 65535) return KF_ERR_INVALID_ARGUMENT;
+    hipStream_t st = as_stream(stream);
+    uint16_t* gt = reinterpret_cast<uint16_t*>(workspace);
+    uint16_t* at = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align256(2 * b * O * R));
+    uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(at) + align256(2 * b * Ip * R));
+    TransposeArgs t;
+    t.out = gt; t.x = reinterpret_cast<const uint16_t*>(G); t.T = static_cast<int>(R); t.C = static_cast<int>(O); t.Cp = static_cast<int>(O);
+    t.ones = 0;
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(O, 64)), static_cast<unsigned>(b)),
+                       dim3(256), 0, st, t);
+    t.out = at; t.x = reinterpret_cast<const uint16_t*>(A); t.C = static_cast<int>(I); t.Cp = static_cast<int>(Ip); t.ones = append_ones ? 1 : 0;
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(Ip, 64)), static_cast<unsigned>(b)),
+                       dim3(256), 0, st, t);
+    PsgV2Args g;
+    g.out = psg; g.out_tile_stride = b * 64;
+    g.A = gt; g.a_sample_stride = O * R; g.B = at; g.b_sample_stride = Ip * R;
+    g.M = static_cast<int>(O); g.N = static_cast<int>(Ip); g.K = static_cast<int>(R); g.batch = static_cast<int>(b);
+    g.conv = 0; g.C = 1; g.k2 = 1; g.O2 = 8; g.s1 = 1; g.d1 = 1; g.s2 = 1; g.d2 = 1; g.Wq = 8; g.plane = 0; g.phase_stride = 0;
+    int rc = launch_psg_v2(g, st);
+    if (rc != KF_OK) return rc;
+    return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
+}
+
+}  // extern "C"

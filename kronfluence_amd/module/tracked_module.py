@@ -92,6 +92,8 @@ class TrackedModule(nn.Module):
         self.score_sink: Optional[Tuple[torch.Tensor, int]] = None
         # True while storage["preconditioned_gradient"] holds eigenbasis-resident queries (PreconditionTracker)
         self.queries_in_eigenbasis: bool = False
+        # > 0 while the held preconditioned query gradients carry that many trailing zero columns (bf16 engine, odd I')
+        self.query_padding: int = 0
         self.storage: Dict[str, Any] = {}
         for key in (COVARIANCE_FACTOR_NAMES + EIGENDECOMPOSITION_FACTOR_NAMES + LAMBDA_FACTOR_NAMES
                     + [AGGREGATED_GRADIENT_NAME, PRECONDITIONED_GRADIENT_NAME,

@@ -127,15 +127,22 @@ class LambdaTracker(BaseTracker):
             storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=g.device)
             storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
         storage[NUM_LAMBDA_PROCESSED].add_(b)  # samples, not tokens (factor.py:203)
+        i = a.shape[-1]
         if (module.factor_args.lambda_dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and a.dtype == torch.bfloat16
-                and r > 1 and not append_ones and o % 8 == 0 and ip % 8 == 0):
+                and r > 1 and o % 8 == 0 and i % 8 == 0 and o >= 64 and i >= 64):
             # The reference's bf16 lambda_dtype casts eigenvectors and gradients to bf16 (factor.py:191-201);
-            # here the rotations and the squared product run on the bf16 MFMA engine with fp32 accumulation.
+            # here the rotations and the squared product run on the bf16 MFMA engine with fp32 accumulation.  The
+            # augmented axis is carried at width W = I' rounded up to a multiple of 8 (zero columns), and the bias column
+            # of ones is the row Q_A[I] added in the rotation's epilogue -- an odd I' (Linear with bias on sequences:
+            # BERT, GPT-2) therefore stays on the bf16 engine without a torch.cat.
             if self._bf16_eigenvectors is None:
-                self._bf16_eigenvectors = (q_a.t().contiguous().to(torch.bfloat16), q_g.t().contiguous().to(torch.bfloat16))
-            qa_t, qg_t = self._bf16_eigenvectors
+                pad = (-ip) % 8
+                qa_t = torch.nn.functional.pad(q_a.t(), (0, pad, 0, pad)).to(torch.bfloat16).contiguous()
+                self._bf16_eigenvectors = (qa_t, q_g.t().contiguous().to(torch.bfloat16),
+                                           q_a[i].contiguous() if append_ones else None)
+            qa_t, qg_t, bias_row = self._bf16_eigenvectors
             gt = ops.rotate_bf16(g.reshape(b * r, o), qg_t)
-            at = ops.rotate_bf16(a.reshape(b * r, ip), qa_t)
+            at = ops.rotate_bf16(a.reshape(b * r, i), qa_t, bias_row)
             ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
             return
         gt = ops.matmul_nn(g.reshape(b * r, o), q_g)

@@ -64,6 +64,15 @@ class ScoreSink:
 LOW_RANK_EXPANSION_BYTES = 4 << 30
 
 
+def unpadded_queries(module, preconditioned):
+    """The held query gradients at the reference's width: strips the zero columns the bf16 preconditioner appends for an
+    odd ``I'`` (``module.query_padding``).  For every reader that is not one of the padded score kernels."""
+    pad = getattr(module, "query_padding", 0)
+    if pad and torch.is_tensor(preconditioned):
+        return preconditioned[..., :preconditioned.shape[-1] - pad].contiguous()
+    return preconditioned
+
+
 def dense_queries(preconditioned, score_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """The held query gradients as one dense ``[Q, O, I']`` tensor (expands low-rank factors)."""
     if isinstance(preconditioned, TiledQueries):
@@ -82,18 +91,25 @@ class TiledQueries:
     ONCE per train pass, in query chunks, and it REPLACES the dense ``[Q, O, I']`` block in ``module.storage``: at BERT /
     GPT-2 scale the dense block is 150-175 GB, a second (let alone a padded third) copy does not fit 288 GB."""
 
-    CHUNK = 64  # queries converted at a time (bounds the padded temporary)
+    CHUNK = 64  # queries converted at a time (bounds the padded / permuted temporary)
 
-    def __init__(self, dense: torch.Tensor, pad: int) -> None:
+    def __init__(self, dense: torch.Tensor, pad: int, conv_channels: int = 0, prepadded: int = 0) -> None:
+        """``pad``: zero columns to append; ``prepadded``: trailing zero columns ``dense`` already carries (the bf16
+        preconditioner's output for an odd ``I'``).  ``conv_channels = C > 0``: the patch axis ``(c, ky, kx)`` of a
+        convolution's gradient is re-ordered to ``(ky, kx, c)``, the order in which the implicit-im2col kernel produces
+        per-sample gradients (``kf_pairwise_score_conv2d``)."""
         q, o, ip = dense.shape
-        self.num_queries, self.rows, self.width, self.pad = q, o, ip + pad, pad
+        self.num_queries, self.rows, self.width, self.conv_channels = q, o, ip + pad, conv_channels
+        self.pad = pad + prepadded  # total zero columns relative to the reference's I'
         d = o * self.width
-        assert dense.dtype == torch.bfloat16 and d % 64 == 0
+        assert dense.dtype == torch.bfloat16 and d % 64 == 0 and not (self.pad and conv_channels)
         self.tiled = torch.empty((d // 64, q, 64), dtype=torch.bfloat16, device=dense.device)
         for start in range(0, q, self.CHUNK):
             block = dense[start:start + self.CHUNK]
             if pad:
                 block = torch.nn.functional.pad(block, (0, pad))
+            if conv_channels:
+                block = block.reshape(block.shape[0], o, conv_channels, ip // conv_channels).transpose(2, 3)
             self.tiled[:, start:start + block.shape[0]] = block.reshape(block.shape[0], d // 64, 64).transpose(0, 1)
 
     @property
@@ -101,8 +117,12 @@ class TiledQueries:
         return (self.num_queries, self.rows, self.width)
 
     def dense(self) -> torch.Tensor:
-        """Back to ``[Q, O, I']`` (rare paths only)."""
+        """Back to the reference's ``[Q, O, I']`` (rare paths only)."""
         full = self.tiled.transpose(0, 1).reshape(self.num_queries, self.rows, self.width)
+        if self.conv_channels:
+            c = self.conv_channels
+            full = full.reshape(self.num_queries, self.rows, self.width // c, c).transpose(2, 3)
+            return full.reshape(self.num_queries, self.rows, self.width).contiguous()
         return full[:, :, :self.width - self.pad].contiguous()
 
 
@@ -139,15 +159,19 @@ class PairwiseScoreTracker(BaseTracker):
         factors, several rows per sample, ``O % 8 == 0``, ``O * I'_pad % 64 == 0``), else ``None``.  The first call of a
         train pass converts the held dense block and replaces it in ``module.storage``."""
         tiled = preconditioned if isinstance(preconditioned, TiledQueries) else None
+        if tiled is not None and tiled.conv_channels:  # laid out for the implicit-im2col kernel: back to the reference's
+            preconditioned, tiled = tiled.dense(), None
         if tiled is None:
             if (not torch.is_tensor(preconditioned) or preconditioned.dtype != torch.bfloat16 or g.shape[1] == 1
                     or g.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0):
                 return None
             width = a.shape[-1] + int(ones)
-            pad = (-width) % 8 if self.PAD_PATCH_AXIS else 0
-            if preconditioned.shape[-1] != width or (width + pad) % 8 != 0 or (g.shape[-1] * (width + pad)) % 64 != 0:
+            prepadded = self.module.query_padding
+            pad = ((-width) % 8 if self.PAD_PATCH_AXIS else 0) - prepadded
+            if (pad < 0 or preconditioned.shape[-1] != width + prepadded or (width + prepadded + pad) % 8 != 0
+                    or (g.shape[-1] * (width + prepadded + pad)) % 64 != 0):
                 return None
-            tiled = TiledQueries(preconditioned, pad)
+            tiled = TiledQueries(preconditioned, pad, prepadded=prepadded)
             self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = tiled  # the dense block is released
         if tiled.pad or ones:  # materialise the ones column and the zero padding on the train side as well
             parts = [a]
@@ -157,6 +181,59 @@ class PairwiseScoreTracker(BaseTracker):
                 parts.append(a.new_zeros(a.shape[:-1] + (tiled.pad,)))
             a = torch.cat(parts, dim=-1)
         return tiled, a, False
+
+    # Second-generation bf16 score path (csrc/kf_score_v2.hip): LDS-DMA fed kernels, implicit im2col for convolutions
+    # (no patch tensor, no transposed gradient copy), in-kernel bias column / padding for Linear layers on sequences.
+    SCORE_V2 = True
+
+    def _score_v2(self, preconditioned, activation: torch.Tensor, output_gradient: torch.Tensor, scores: torch.Tensor,
+                  offset: int) -> bool:
+        """Scores this layer on the v2 kernels when its shapes and dtypes allow; ``False`` -> caller takes the v1 path."""
+        module, original = self.module, self.module.original_module
+        tiled = preconditioned if isinstance(preconditioned, TiledQueries) else None
+        if not self.SCORE_V2 or output_gradient.dtype != torch.bfloat16:
+            return False
+        if tiled is None and not (torch.is_tensor(preconditioned) and preconditioned.dtype == torch.bfloat16):
+            return False
+        if isinstance(original, nn.Conv2d) and activation.dim() == 4 and output_gradient.dim() == 4:
+            if original.groups != 1 or original.bias is not None:
+                return False
+            c, (k1, k2) = activation.shape[1], original.kernel_size
+            o, o1, o2 = output_gradient.shape[1:]
+            ip = c * k1 * k2
+            if o2 % 8 != 0 or (o1 * o2) % 64 != 0 or c % 8 != 0 or (o * ip) % 64 != 0:
+                return False
+            if tiled is None:
+                if tuple(preconditioned.shape[1:]) != (o, ip):
+                    return False
+                tiled = TiledQueries(preconditioned, 0, conv_channels=c)
+                module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = tiled  # the dense block is released
+            elif tiled.conv_channels != c or tiled.shape[1:] != (o, ip):
+                return False
+            x = activation if activation.dtype == torch.bfloat16 else activation.to(torch.bfloat16)
+            ops.pairwise_score_conv2d(scores, offset, tiled, output_gradient, x, original, scale=module.gradient_scale)
+            return True
+        if isinstance(original, nn.Linear) and activation.dim() >= 3:
+            o, i = output_gradient.shape[-1], activation.shape[-1]
+            rows = activation.numel() // (activation.shape[0] * i)
+            width = i + int(original.bias is not None)
+            padded = width + (-width) % 8
+            if rows % 64 != 0 or o % 8 != 0 or i % 8 != 0 or (o * padded) % 64 != 0 or activation.shape[0] > 65535:
+                return False
+            if tiled is None:
+                prepadded = module.query_padding
+                if tuple(preconditioned.shape[1:]) != (o, width + prepadded) or prepadded not in (0, padded - width):
+                    return False
+                tiled = TiledQueries(preconditioned, padded - width - prepadded, prepadded=prepadded)
+                module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = tiled
+            elif tiled.conv_channels or tiled.shape[1:] != (o, padded):
+                return False
+            a = activation if activation.dtype == torch.bfloat16 else activation.to(torch.bfloat16)
+            b = activation.shape[0]
+            ops.pairwise_score_rows(scores, offset, tiled, output_gradient.reshape(b, rows, o), a.reshape(b, rows, i),
+                                    original.bias is not None, scale=module.gradient_scale)
+            return True
+        return False
 
     def register_hooks(self) -> None:
         module = self.module
@@ -191,6 +268,9 @@ class PairwiseScoreTracker(BaseTracker):
                 if accumulate_into is not None and accumulate_into.shape == scores.shape:
                     scores = accumulate_into
                 storage[PAIRWISE_SCORE_MATRIX_NAME] = scores
+            if (module.per_sample_gradient_process_fnc is None and not per_token and not module.queries_in_eigenbasis
+                    and self._score_v2(preconditioned, activation, output_gradient.detach(), scores, offset)):
+                return
             if module.per_sample_gradient_process_fnc is None:
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 if per_token:  # "qio,bti,bto->qbt" (linear.py:100-111): every token is a rank-one "sample"
@@ -208,14 +288,14 @@ class PairwiseScoreTracker(BaseTracker):
                     tiled, a_in, ones_in = fast
                     ops.pairwise_score(scores, offset, tiled, g, a_in, ones_in, scale=module.gradient_scale)
                 else:
-                    for first, block in self._query_blocks(preconditioned):
+                    for first, block in self._query_blocks(unpadded_queries(module, preconditioned)):
                         rows = scores[first:first + block.shape[0]]
                         ops.pairwise_score(rows, offset, block, g, a, ones, scale=module.gradient_scale)
             else:
                 # post-processed gradient (pairwise_score.py:41-45): contract the materialised gradient
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach()).contiguous()
                 b, o, ip = psg.shape
-                for first, block in self._query_blocks(preconditioned):
+                for first, block in self._query_blocks(unpadded_queries(module, preconditioned)):
                     block = block if block.dtype == torch.float32 else ops.cast(block, torch.float32)
                     q = block.shape[0]
                     ops.gemm(scores[first:first + q, offset:offset + b], scores.shape[1], 0,
@@ -243,7 +323,7 @@ class PairwiseScoreTracker(BaseTracker):
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
-            preconditioned = dense_queries(preconditioned).contiguous()
+            preconditioned = dense_queries(unpadded_queries(module, preconditioned)).contiguous()
             if preconditioned.dtype != torch.float32:
                 preconditioned = ops.cast(preconditioned, torch.float32)
             summed = summed.to(torch.float32).contiguous()

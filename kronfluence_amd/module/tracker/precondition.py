@@ -44,16 +44,19 @@ class PreconditionTracker(BaseTracker):
 
     def _bf16_eigenvectors(self):
         """bf16 copies ``(Q_A, Q_G^T, Q_A^T)`` for ``precondition_dtype == bf16`` (the reference casts the eigenvectors to
-        that dtype in ``Ekfac.prepare``, factor/config.py:323-328); ``(None, None, None)`` otherwise."""
+        that dtype in ``Ekfac.prepare``, factor/config.py:323-328), ``Q_A`` and ``Q_A^T`` zero-padded to ``[W, W]`` with
+        ``W = I'`` rounded up to a multiple of 8 (see ``ops.precondition``); ``(None, None, None)`` otherwise."""
         args = self.module.score_args
         if args.precondition_dtype != torch.bfloat16 or args.score_dtype != torch.bfloat16:
             return None, None, None
         storage = self.module.storage
         source = storage[ACTIVATION_EIGENVECTORS_NAME]
         if self._bf16_q is None or self._bf16_q[0] is not source:
-            self._bf16_q = (source, source.to(torch.bfloat16).contiguous(),
+            pad = (-source.shape[0]) % 8
+            padded = torch.nn.functional.pad(source, (0, pad, 0, pad))
+            self._bf16_q = (source, padded.to(torch.bfloat16).contiguous(),
                             storage[GRADIENT_EIGENVECTORS_NAME].t().contiguous().to(torch.bfloat16),
-                            source.t().contiguous().to(torch.bfloat16))
+                            padded.t().contiguous().to(torch.bfloat16))
         return self._bf16_q[1], self._bf16_q[2], self._bf16_q[3]
 
     def _store(self, preconditioned: torch.Tensor) -> None:
@@ -62,6 +65,9 @@ class PreconditionTracker(BaseTracker):
         subspace iterations instead of a dense SVD)."""
         args = self.module.score_args
         rank = args.query_gradient_low_rank
+        if rank is not None and self.module.query_padding:
+            preconditioned = preconditioned[..., :preconditioned.shape[-1] - self.module.query_padding].contiguous()
+            self.module.query_padding = 0
         if rank is not None and min(preconditioned.shape[1:]) > rank:
             dense = preconditioned if preconditioned.dtype == torch.float32 else ops.cast(preconditioned, torch.float32)
             left, right = ops.low_rank_factors(dense, rank, power_iterations=4 if args.use_full_svd else 2)
@@ -99,16 +105,22 @@ class PreconditionTracker(BaseTracker):
                     ops.gemm(rotated, ip, o * ip, ops.view(gt, o, 1, o, o, 1), ops.view(at, ip, 1, ip, ip, 1), batch=q,
                              alpha=module.gradient_scale, mul=storage[LAMBDA_MATRIX_NAME])
                     module.queries_in_eigenbasis = True
+                    module.query_padding = 0
                     self._store(rotated)
                     return
                 module.queries_in_eigenbasis = False
                 qa16, qgt16, qat16 = self._bf16_eigenvectors()
-                self._store(ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
-                                             storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
-                                             scale=module.gradient_scale, out_dtype=self._out_dtype(),
-                                             q_a_bf16=qa16, q_g_t_bf16=qgt16, q_a_t_bf16=qat16))
+                out = ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
+                                       storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
+                                       scale=module.gradient_scale, out_dtype=self._out_dtype(),
+                                       q_a_bf16=qa16, q_g_t_bf16=qgt16, q_a_t_bf16=qat16)
+                # the bf16 engine hands back rows zero-padded to a multiple of 8 (odd I'); the score trackers consume that
+                # width as it is, every other reader strips it (``unpadded_queries``)
+                module.query_padding = out.shape[-1] - (a.shape[-1] + int(ones))
+                self._store(out)
             else:
                 module.queries_in_eigenbasis = False
+                module.query_padding = 0
                 psg = module.compute_per_sample_gradient(activation, output_gradient.detach())
                 out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(psg, storage)
                 if module.gradient_scale != 1.0:
@@ -131,6 +143,7 @@ class PreconditionTracker(BaseTracker):
         module = self.module
         if module.factor_args.has_shared_parameters and self.cached_per_sample_gradient is not None:
             module.queries_in_eigenbasis = False
+            module.query_padding = 0
             out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(
                 self.cached_per_sample_gradient, module.storage)
             if module.gradient_scale != 1.0:
@@ -196,6 +209,7 @@ class PreconditionTracker(BaseTracker):
         if summed is None:
             return
         self.module.queries_in_eigenbasis = False
+        self.module.query_padding = 0
         out = FactorConfig.CONFIGS[self.module.factor_args.strategy].precondition_gradient(
             summed.to(torch.float32).contiguous(), storage)
         storage[AGGREGATED_GRADIENT_NAME] = None

@@ -21,7 +21,7 @@ from torch import nn
 from kronfluence_amd import ops
 from kronfluence_amd.factor.config import FactorConfig
 from kronfluence_amd.module.tracker.base import BaseTracker
-from kronfluence_amd.module.tracker.pairwise_score import dense_queries
+from kronfluence_amd.module.tracker.pairwise_score import dense_queries, unpadded_queries
 from kronfluence_amd.utils.constants import (
     ACTIVATION_EIGENVECTORS_NAME,
     GRADIENT_EIGENVECTORS_NAME,
@@ -135,7 +135,7 @@ class SelfScoreWithMeasurementTracker(_SelfScoreBase):
             preconditioned = storage[PRECONDITIONED_GRADIENT_NAME]
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned measurement gradient.")
-            preconditioned = dense_queries(preconditioned)
+            preconditioned = dense_queries(unpadded_queries(module, preconditioned))
             if module.per_sample_gradient_process_fnc is None:
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 if module.queries_in_eigenbasis:  # see PreconditionTracker.EIGENBASIS_QUERIES

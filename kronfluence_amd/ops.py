@@ -185,18 +185,31 @@ def matmul_nn(x: torch.Tensor, w: torch.Tensor, append_ones: bool = False) -> to
     return out
 
 
-def rotate_bf16(x: torch.Tensor, q_t: torch.Tensor) -> torch.Tensor:
-    """``x @ q`` on the bf16 MFMA engine: ``x: [n, d]`` bf16, ``q_t = q^T`` contiguous bf16 ``[m, d]`` -> bf16 ``[n, m]``
-    (the eigenbasis rotation of tracker/factor.py:218-226 in the reference's bf16 lambda_dtype)."""
+def rotate_bf16(x: torch.Tensor, q_t: torch.Tensor, bias_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``x @ q (+ bias_row)`` on the bf16 MFMA engine: ``x: [n, d]`` bf16, ``q_t``: contiguous bf16 ``[m, ld]`` holding
+    ``q^T`` in its first ``d`` columns (``ld >= d``, both multiples of 8) -> bf16 ``[n, m]`` -- the eigenbasis rotation of
+    tracker/factor.py:218-226 in the reference's bf16 lambda_dtype.  ``bias_row`` (fp32, ``<= m`` entries) is added to
+    every output row: with ``q_t`` built from the first ``I`` rows of ``Q_A`` and ``bias_row = Q_A[I]`` this is
+    ``[x, 1] @ Q_A`` without materialising the ones column; zero rows of ``q_t`` give zero (padding) output columns."""
     x, q_t = _contig(x), _contig(q_t)
     n, d = x.shape
-    m = q_t.shape[0]
+    m, ld = q_t.shape
+    assert ld >= d and x.dtype == q_t.dtype == torch.bfloat16
     out = torch.empty((n, m), dtype=torch.bfloat16, device=x.device)
     nat.require_device(x, "x")
+    if bias_row is None:
+        nat.check(
+            nat.lib().kf_gemm_out(out.data_ptr(), nat.dtype_code(out.dtype), m, 0, ctypes.byref(view(x, 0, d, 1, n, d)),
+                                  ctypes.byref(view(q_t, 0, ld, 1, m, d)), 1, 1.0, nat.stream_ptr(x.device)),
+            "kf_gemm_out",
+        )
+        return out
+    bias_row = _contig(bias_row)
+    assert bias_row.dtype == torch.float32 and bias_row.numel() <= m
     nat.check(
-        nat.lib().kf_gemm_out(out.data_ptr(), nat.dtype_code(out.dtype), m, 0, ctypes.byref(view(x, 0, d, 1, n, d)),
-                              ctypes.byref(view(q_t, 0, d, 1, m, d)), 1, 1.0, nat.stream_ptr(x.device)),
-        "kf_gemm_out",
+        nat.lib().kf_gemm_bias_out(out.data_ptr(), m, ctypes.byref(view(x, 0, d, 1, n, d)), ctypes.byref(view(q_t, 0, ld, 1, m, d)),
+                                   bias_row.data_ptr(), bias_row.numel(), nat.stream_ptr(x.device)),
+        "kf_gemm_bias_out",
     )
     return out
 
@@ -316,16 +329,18 @@ def low_rank_product(left: torch.Tensor, right: torch.Tensor) -> torch.Tensor:
 
 
 def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, r: int, scale: float = 1.0) -> None:
-    """``lam += sum_b (Gt_b^T At_b)^2`` with rotated factors (kf_lambda_accum; tracker/factor.py:218-226)."""
+    """``lam += sum_b (Gt_b^T At_b)^2`` with rotated factors (kf_lambda_accum; tracker/factor.py:218-226).  ``at`` may be
+    wider than ``lam`` (bf16 rows zero-padded to a multiple of 8, see ``rotate_bf16``)."""
     nat.require_device(lam, "lam")
     assert lam.dtype == torch.float32 and gt.dtype == at.dtype and gt.dtype in (torch.float32, torch.bfloat16)
     assert gt.is_contiguous() and at.is_contiguous()
     o, ip = lam.shape
-    assert gt.numel() == b * r * o and at.numel() == b * r * ip
+    ld_at = at.shape[-1]
+    assert gt.numel() == b * r * o and at.numel() == b * r * ld_at and ld_at >= ip
     # the product of the rotated factors, squared and summed (the rotations themselves are kf_gemm calls)
     with _Timed("lambda_accum", lam.device, 2.0 * b * r * o * ip, float(b) * r * (o + ip) * gt.element_size()):
         nat.check(
-            nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), nat.dtype_code(gt.dtype), b, r, o, ip,
+            nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), ld_at, nat.dtype_code(gt.dtype), b, r, o, ip,
                                       scale, nat.stream_ptr(lam.device)),
             "kf_lambda_accum",
         )
@@ -352,8 +367,10 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
                  lam_inv: torch.Tensor, scale: float = 1.0, out_dtype: torch.dtype = torch.float32,
                  q_a_bf16: Optional[torch.Tensor] = None, q_g_t_bf16: Optional[torch.Tensor] = None,
                  q_a_t_bf16: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """EK-FAC preconditioned per-sample gradient ``[q, O, I']`` from ``g: [q,R,O]`` and ``a: [q,R,I]``
-    (tracker/precondition.py:102-123 + factor/config.py:341-353)."""
+    """EK-FAC preconditioned per-sample gradient from ``g: [q,R,O]`` and ``a: [q,R,I]`` (tracker/precondition.py:102-123 +
+    factor/config.py:341-353): ``[q, O, I']``.  With the bf16 eigenvector copies (``[W, W]``, ``W = I'`` rounded up to a
+    multiple of 8, zero-padded), bf16 factors and several rows per sample, everything runs on the bf16 MFMA engine and the
+    result is ``[q, O, W]`` -- ``W - I'`` trailing zero columns (none unless ``I'`` is odd)."""
     nat.require_device(g, "g")
     g, a = _contig(g), _contig(a)
     q, r, o = g.shape
@@ -363,14 +380,23 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     assert q_g.dtype == q_a.dtype == lam_inv.dtype == torch.float32 and g.dtype == a.dtype
     q_g, q_a, lam_inv = _contig(q_g), _contig(q_a), _contig(lam_inv)  # keep the contiguous copies alive
     assert out_dtype in (torch.float32, torch.bfloat16)
-    out = torch.empty((q, o, ip), dtype=out_dtype, device=g.device)
+    width, ldq = ip, ip
+    low = (q_a_bf16 is not None and q_g_t_bf16 is not None and q_a_t_bf16 is not None and out_dtype == torch.bfloat16
+           and g.dtype == torch.bfloat16 and r > 1 and o % 8 == 0 and i % 8 == 0 and i >= 64 and o >= 64)
+    if low:
+        ldq = q_a_bf16.shape[0]
+        assert q_a_bf16.shape == q_a_t_bf16.shape == (ldq, ldq) and ldq % 8 == 0 and ip <= ldq < ip + 8
+        width = ldq
+    else:
+        q_a_bf16 = q_g_t_bf16 = q_a_t_bf16 = None
+    out = torch.empty((q, o, width), dtype=out_dtype, device=g.device)
     ws_bytes = nat.lib().kf_precondition_workspace_bytes(q, r, o, ip)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
     nat.check(
-        nat.lib().kf_precondition(out.data_ptr(), nat.dtype_code(out_dtype), g.data_ptr(), a.data_ptr(),
+        nat.lib().kf_precondition(out.data_ptr(), nat.dtype_code(out_dtype), width, g.data_ptr(), a.data_ptr(),
                                   nat.dtype_code(g.dtype), q, r, o, i,
                                   int(append_ones), q_g.data_ptr(), q_a.data_ptr(), lam_inv.data_ptr(), scale,
-                                  _ptr(q_a_bf16), _ptr(q_g_t_bf16), _ptr(q_a_t_bf16), ws.data_ptr(), ws_bytes,
+                                  _ptr(q_a_bf16), _ptr(q_g_t_bf16), _ptr(q_a_t_bf16), ldq, ws.data_ptr(), ws_bytes,
                                   nat.stream_ptr(g.device)),
         "kf_precondition",
     )
@@ -434,6 +460,62 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p, g: torch.Tensor, a:
                                         a.data_ptr(), nat.dtype_code(g.dtype), b, r, o, i, int(append_ones), scale,
                                         ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
             "kf_pairwise_score",
+        )
+
+
+def pairwise_score_conv2d(scores: torch.Tensor, col_offset: int, p, g_nchw: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d,
+                          scale: float = 1.0) -> None:
+    """Implicit-im2col score of a Conv2d layer (kf_pairwise_score_conv2d): ``p.tiled`` is the k-tile-major bf16 P whose
+    patch axis is ordered ``(ky, kx, c)``; ``g_nchw`` the hooked output gradient ``[b, O, O1, O2]`` and ``x`` the hooked
+    input ``[b, C, H, W]``, both bf16 -- neither patches nor a transposed gradient are materialised."""
+    nat.require_device(scores, "scores")
+    nat.require_device(g_nchw, "g_nchw")
+    g_nchw, x = _contig(g_nchw), _contig(x)
+    assert g_nchw.dtype == x.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32
+    b, c, h, w = x.shape
+    o, o1, o2 = g_nchw.shape[1], g_nchw.shape[2], g_nchw.shape[3]
+    k1, k2, s1, s2, p1, p2, d1, d2 = conv_geometry(conv)
+    q, ip = p.shape[0], c * k1 * k2
+    assert p.shape == (q, o, ip) and scores.shape[0] == q and col_offset + b <= scores.shape[1]
+    geometry = (b, c, h, w, o, k1, k2, s1, s2, p1, p2, d1, d2)
+    ws_bytes = nat.lib().kf_pairwise_conv2d_workspace_bytes(*geometry)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    r = o1 * o2
+    flops = 2.0 * q * b * o * ip + 2.0 * b * r * o * ip
+    nbytes = b * (r * o + c * h * w) * 2 + q * o * ip * 2 + 2.0 * q * b * 4  # B_pair: I^raw (not the patches), G, P, scores
+    with _Timed("pairwise_score", x.device, flops, nbytes):
+        nat.check(
+            nat.lib().kf_pairwise_score_conv2d(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.tiled.data_ptr(), q,
+                                               g_nchw.data_ptr(), x.data_ptr(), *geometry, scale, ws.data_ptr(), ws_bytes,
+                                               nat.stream_ptr(x.device)),
+            "kf_pairwise_score_conv2d",
+        )
+
+
+def pairwise_score_rows(scores: torch.Tensor, col_offset: int, p, g: torch.Tensor, a: torch.Tensor, append_ones: bool,
+                        scale: float = 1.0) -> None:
+    """Score of a Linear layer on ``[b, R, .]`` activations on the LDS-DMA kernels (kf_pairwise_score_rows): ``p.tiled`` is
+    k-tile-major bf16 with the augmented axis padded to ``p.shape[2]`` (a multiple of 8); bias column and padding of the
+    train side are generated inside the call."""
+    nat.require_device(scores, "scores")
+    nat.require_device(g, "g")
+    g, a = _contig(g), _contig(a)
+    assert g.dtype == a.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32
+    b, r, o = g.shape
+    i = a.shape[2]
+    q, ipp = p.shape[0], p.shape[2]
+    assert p.shape[1] == o and scores.shape[0] == q and col_offset + b <= scores.shape[1]
+    ws_bytes = nat.lib().kf_pairwise_rows_workspace_bytes(b, r, o, ipp)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    ip = i + int(append_ones)
+    flops = 2.0 * q * b * o * ip + 2.0 * b * r * o * ip
+    nbytes = b * r * (o + i) * 2 + q * o * ip * 2 + 2.0 * q * b * 4
+    with _Timed("pairwise_score", g.device, flops, nbytes):
+        nat.check(
+            nat.lib().kf_pairwise_score_rows(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.tiled.data_ptr(), q,
+                                             g.data_ptr(), a.data_ptr(), b, r, o, i, ipp, int(append_ones), scale,
+                                             ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
+            "kf_pairwise_score_rows",
         )
 
 

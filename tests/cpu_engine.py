@@ -71,8 +71,11 @@ def gemm(c, ldc, c_batch_stride, a: View, b: View, batch=1, alpha=1.0, beta=0.0,
     out.copy_(((out.double() * beta if beta != 0.0 else 0.0) + prod).to(c.dtype))
 
 
-def rotate_bf16(x, q_t):
-    return (x.double() @ q_t.double().t()).to(torch.bfloat16)
+def rotate_bf16(x, q_t, bias_row=None):
+    out = x.double() @ q_t.double()[:, : x.shape[1]].t()
+    if bias_row is not None:
+        out[:, : bias_row.numel()] += bias_row.double()
+    return out.to(torch.bfloat16)
 
 
 def syrk_accum(cov, x, n_rows, d_in, rows_inner, outer_stride, row_stride, col_stride, mask=None, append_ones=False,
@@ -117,7 +120,8 @@ def eigh_small(g, inv_sqrt=False, floor_rel=1e-12):
 
 def lambda_accum(lam, gt, at, b, r, scale=1.0) -> None:
     o, ip = lam.shape
-    g = torch.einsum("bro,bri->boi", gt.reshape(b, r, o).double(), at.reshape(b, r, ip).double()) * scale
+    at = at.reshape(b, r, -1)[..., :ip]  # rows may carry zero padding (bf16 engine, odd I')
+    g = torch.einsum("bro,bri->boi", gt.reshape(b, r, o).double(), at.double()) * scale
     lam.add_((g * g).sum(0).to(lam.dtype))
 
 
@@ -136,6 +140,10 @@ def precondition(g, a, append_ones, q_g, q_a, lam_inv, scale=1.0, out_dtype=torc
                  q_a_t_bf16=None):
     psg = _psg(g, a, append_ones)
     out = ref.ekfac_precondition(psg, q_a.double(), q_g.double(), lam_inv.double()) * scale
+    if (q_a_bf16 is not None and q_g_t_bf16 is not None and q_a_t_bf16 is not None and out_dtype == torch.bfloat16
+            and g.dtype == torch.bfloat16 and g.shape[1] > 1 and g.shape[2] % 8 == 0 and a.shape[2] % 8 == 0
+            and a.shape[2] >= 64 and g.shape[2] >= 64):
+        out = F.pad(out, (0, q_a_bf16.shape[0] - out.shape[-1]))  # the bf16 engine's padded width (same rule as ops.precondition)
     return out.to(out_dtype).contiguous()
 
 
@@ -146,6 +154,17 @@ def pairwise_score(scores, col_offset, p, g, a, append_ones, scale=1.0) -> None:
     psg = _psg(g, a, append_ones)
     block = torch.einsum("qoi,boi->qb", p.double(), psg) * scale
     scores[:, col_offset:col_offset + psg.shape[0]] += block.to(scores.dtype)
+
+
+def pairwise_score_conv2d(scores, col_offset, p, g_nchw, x, conv, scale=1.0) -> None:
+    """Implicit-im2col entry point: ``p`` is a TiledQueries whose patch axis is ordered (ky, kx, c)."""
+    block = ref.conv_pairwise_score(p.dense().double(), x.double(), g_nchw.double(), conv) * scale
+    scores[:, col_offset:col_offset + x.shape[0]] += block.to(scores.dtype)
+
+
+def pairwise_score_rows(scores, col_offset, p, g, a, append_ones, scale=1.0) -> None:
+    block = ref.linear_pairwise_score(p.dense().double(), a.double(), g.double(), append_ones) * scale
+    scores[:, col_offset:col_offset + g.shape[0]] += block.to(scores.dtype)
 
 
 def rowwise_dot(out, x, y, weight=None, scale=1.0, accumulate=True) -> None:
@@ -169,7 +188,7 @@ def cast(src, dtype):
 
 
 LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "eigh_small", "lambda_accum", "inv_lambda", "precondition",
-          "pairwise_score", "rowwise_dot", "mul_bcast", "cast")
+          "pairwise_score", "pairwise_score_conv2d", "pairwise_score_rows", "rowwise_dot", "mul_bcast", "cast")
 
 
 class _Setter:

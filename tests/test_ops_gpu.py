@@ -289,6 +289,65 @@ def test_pairwise_score_k_tile_major_layout(ops, q, b, r, o, i):
     assert rel(scores, want) <= 4e-3 and rel(scores, plain) <= 2e-5
 
 
+# ---- second-generation score path (csrc/kf_score_v2.hip): LDS-DMA kernels, implicit im2col ----------------------
+V2_CONVS = [
+    dict(b=5, cin=16, cout=32, k=3, stride=1, padding=1, dilation=1, hw=(16, 16)),     # 3x3 "same": O2 = 16, P = 256
+    dict(b=3, cin=8, cout=16, k=5, stride=2, padding=2, dilation=1, hw=(16, 16)),      # strided 5x5: two column phases
+    dict(b=4, cin=8, cout=24, k=3, stride=1, padding=2, dilation=2, hw=(8, 16)),       # dilation 2, non-square image
+    dict(b=2, cin=128, cout=130, k=3, stride=1, padding=0, dilation=1, hw=(10, 18)),   # no padding, ragged O tile, 2 k-steps
+    dict(b=7, cin=8, cout=8, k=(1, 3), stride=1, padding=(0, 1), dilation=1, hw=(8, 8)),  # 1x3 kernel, P = 64
+]
+
+
+@pytest.mark.parametrize("c", V2_CONVS)
+@pytest.mark.parametrize("q", [3, 300])
+def test_pairwise_score_conv2d_implicit_im2col(ops, c, q):
+    """kf_pairwise_score_conv2d (no patch tensor, NCHW gradient consumed in place) against the oracle's
+    ``"qio,bti,bto->qb"`` (module/conv2d.py:199-209) on the same bf16 inputs; P is held in the reference's (c, ky, kx)
+    patch order and re-ordered by ``TiledQueries``.  Bound: the per-sample gradient is rounded to bf16 once (2^-9)."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    conv = nn.Conv2d(c["cin"], c["cout"], c["k"], stride=c["stride"], padding=c["padding"], dilation=c["dilation"], bias=False)
+    b = c["b"]
+    x = _rand(b, c["cin"], *c["hw"], dtype=torch.bfloat16)
+    out = conv(x.float())
+    g = _rand(*out.shape, dtype=torch.bfloat16, seed=1)
+    ip = c["cin"] * conv.kernel_size[0] * conv.kernel_size[1]
+    p = _rand(q, c["cout"], ip, seed=7).to(torch.bfloat16)
+    want = ref.conv_pairwise_score(p.double(), x.double(), g.double(), conv.double())
+    tiled = TiledQueries(p.to(DEV), 0, conv_channels=c["cin"])
+    assert torch.equal(tiled.dense(), p.to(DEV))  # the permutation round-trips
+    scores = torch.zeros(q, b + 3, device=DEV)
+    ops.pairwise_score_conv2d(scores, 1, tiled, g.to(DEV), x.to(DEV), conv, scale=1.0)
+    ops.pairwise_score_conv2d(scores, 1, tiled, g.to(DEV), x.to(DEV), conv, scale=0.5)  # "+=" across layers
+    assert rel(scores[:, 1:1 + b], 1.5 * want) <= 4e-3, rel(scores[:, 1:1 + b], 1.5 * want)
+    assert float(scores[:, :1].abs().max()) == 0.0 and float(scores[:, 1 + b:].abs().max()) == 0.0
+    # and identical (up to fp32 summation order) to the materialised-patch v1 path on the same data
+    v1 = torch.zeros(q, b, device=DEV)
+    patches = ops.im2col(x.to(DEV), conv, False, torch.bfloat16)
+    ops.pairwise_score(v1, 0, p.to(DEV), g.to(DEV).flatten(2).transpose(1, 2).contiguous(), patches, False)
+    assert rel(scores[:, 1:1 + b], 1.5 * v1) <= 2e-3
+
+
+@pytest.mark.parametrize("q,b,r,o,i,bias", [(5, 6, 64, 64, 128, True), (300, 9, 128, 136, 72, True), (40, 3, 512, 72, 768, False),
+                                             (7, 4, 64, 8, 8, True)])
+def test_pairwise_score_rows_v2(ops, q, b, r, o, i, bias):
+    """kf_pairwise_score_rows: Linear layer on [b, R, .] rows; the bias column of ones and the zero padding of I' to a
+    multiple of 8 are generated inside the call (no torch.cat); against ``"qio,b...i,b...o->qb"`` (linear.py:112-122)."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    width = i + int(bias)
+    pad = (-width) % 8
+    p = _rand(q, o, width, seed=7).to(torch.bfloat16)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    want = ref.linear_pairwise_score(p.double(), a.double(), g.double(), bias)
+    tiled = TiledQueries(p.to(DEV), pad)
+    assert tiled.shape == (q, o, width + pad) and torch.equal(tiled.dense(), p.to(DEV))
+    scores = torch.zeros(q, b, device=DEV)
+    ops.pairwise_score_rows(scores, 0, tiled, g.to(DEV), a.to(DEV), bias)
+    assert rel(scores, want) <= 4e-3, rel(scores, want)
+
+
 @pytest.mark.parametrize("n,d", [(300, 128), (5000, 1152), (1030, 264), (64, 16)])
 def test_syrk_bf16_symmetric_engine(ops, n, d):
     """bf16 rows, no mask / bias column: upper-triangular tile pairs on the bf16 TN engine."""
