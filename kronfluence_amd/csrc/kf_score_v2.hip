@@ -45,11 +45,8 @@ inline int launch_status() { return hipGetLastError() == hipSuccess ? KF_OK : KF
 
 __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
     // 16 bytes per lane: global (per-lane address) -> LDS at lds_wave_base + lane * 16 (wave-uniform base in M0)
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(
-                                         reinterpret_cast<uintptr_t>(src)),
-                                     reinterpret_cast<__attribute__((address_space(3))) void*>(
-                                         static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds_wave_base))),
-                                     16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
 }
 
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }

@@ -138,8 +138,10 @@ def test_per_sample_gradient(ops, b, r, o, i, bias, dtype):
 
 
 # ---- stage 2 -------------------------------------------------------------------------------------
-@pytest.mark.parametrize("d,n", [(1, 5), (2, 9), (17, 100), (64, 40), (129, 1000), (300, 150), (513, 2000), (770, 300),
-                                 (1030, 5000)])  # d >= 512: block rounds (incl. d % 4 != 0 and rank-deficient cases)
+@pytest.mark.parametrize("d,n", [(1, 5), (2, 9), (17, 100), (64, 40), (129, 1000), (255, 300), (256, 1000), (300, 150), (513, 2000),
+                                 (770, 300), (1030, 5000), (1601, 2500)])
+# d >= 256: blocked rounds on the fp64 matrix cores (pairs of 32-column blocks), incl. d % 32 != 0, an odd number of
+# blocks (bye) and rank-deficient covariances
 def test_eigh_invariants_and_values(ops, d, n):
     x = _rand(n, d).double()
     cov = (x.t() @ x).float()
@@ -406,7 +408,8 @@ def test_lambda_accum_bf16_engine(ops, b, r, o, i):
 
 @pytest.mark.parametrize("q,r,o,i", [(4, 6, 64, 128), (3, 50, 128, 72), (5, 1, 16, 64)])
 def test_precondition_bf16_back_rotation(ops, q, r, o, i):
-    """precondition_dtype = bf16: back-rotations on the bf16 engine with bf16 eigenvector copies."""
+    """bf16 output from fp32 factors: without bf16 inputs and all three bf16 eigenvector copies the arithmetic stays on
+    the fp32 engine (only the stored result is bf16)."""
     g, a = _rand(q, r, o), _rand(q, r, i, seed=1)
     q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].contiguous()
     q_a = torch.linalg.qr(_rand(i, i, seed=3).double())[0].contiguous()
@@ -431,6 +434,50 @@ def test_precondition_bf16_forward_and_back_rotation(ops, q, r, o, i):
                            q_a_bf16=qa_d.to(torch.bfloat16).contiguous(), q_g_t_bf16=qg_d.t().contiguous().to(torch.bfloat16),
                            q_a_t_bf16=qa_d.t().contiguous().to(torch.bfloat16))
     assert got.dtype == torch.bfloat16 and rel(got, want) <= 1.5e-2, rel(got, want)
+
+
+@pytest.mark.parametrize("q,r,o,i", [(3, 64, 64, 128), (2, 128, 768, 768), (2, 128, 96, 3072)])
+def test_precondition_bf16_odd_augmented_axis(ops, q, r, o, i):
+    """Linear WITH bias on sequences (I' = I + 1 odd; BERT / GPT-2 shapes): the bf16 engine carries the augmented axis at
+    W = I' rounded up to 8 -- bias column = the row Q_A[I] added in the epilogue, P comes back [q, O, W] with zero
+    padding columns -- against the fp64 oracle's (K7 + K11) on the same bf16 inputs."""
+    ip = i + 1
+    w = ip + (-ip) % 8
+    g, a = _rand(q, r, o, dtype=torch.bfloat16), _rand(q, r, i, dtype=torch.bfloat16, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].contiguous()
+    q_a = torch.linalg.qr(_rand(ip, ip, seed=3).double())[0].contiguous()
+    lam_inv = _rand(o, ip, seed=4).abs().double() + 0.1
+    want = ref.ekfac_precondition(ref.linear_per_sample_gradient(a.double(), g.double(), True), q_a, q_g, lam_inv) * 0.5
+    qa_d, qg_d = q_a.float().to(DEV), q_g.float().to(DEV)
+    padded = torch.nn.functional.pad(qa_d, (0, w - ip, 0, w - ip))
+    got = ops.precondition(g.to(DEV), a.to(DEV), True, qg_d, qa_d, lam_inv.float().to(DEV), scale=0.5, out_dtype=torch.bfloat16,
+                           q_a_bf16=padded.to(torch.bfloat16).contiguous(), q_g_t_bf16=qg_d.t().contiguous().to(torch.bfloat16),
+                           q_a_t_bf16=padded.t().contiguous().to(torch.bfloat16))
+    assert got.shape == (q, o, w) and got.dtype == torch.bfloat16
+    assert float(got[..., ip:].float().abs().max()) == 0.0  # padding columns are exact zeros
+    assert rel(got[..., :ip], want) <= 1.5e-2, rel(got[..., :ip], want)
+
+
+@pytest.mark.parametrize("b,r,o,i,bias", [(4, 64, 64, 128, True), (2, 128, 768, 768, True), (3, 128, 64, 3072, True), (3, 64, 72, 136, False)])
+def test_lambda_bf16_odd_augmented_axis(ops, b, r, o, i, bias):
+    """bf16 Lambda rotations with the bias row added in the epilogue and the augmented axis zero-padded to a multiple of 8
+    (``rotate_bf16(.., bias_row)`` + ``lambda_accum`` with wide rows) against tracker/factor.py:218-226 in fp64."""
+    ip = i + int(bias)
+    w = ip + (-ip) % 8
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0]
+    q_a = torch.linalg.qr(_rand(ip, ip, seed=3).double())[0]
+    want = torch.zeros(o, ip, dtype=torch.float64)
+    ref.lambda_update(want, ref.linear_per_sample_gradient(a.double(), g.double(), bias) * 0.5, q_a, q_g)
+    qa_t = torch.nn.functional.pad(q_a.float().t(), (0, w - ip, 0, w - ip)).to(torch.bfloat16).contiguous().to(DEV)
+    at = ops.rotate_bf16(a.reshape(b * r, i).to(DEV), qa_t, q_a[i].float().contiguous().to(DEV) if bias else None)
+    assert at.shape == (b * r, w)
+    exact = torch.cat([a.double(), a.new_ones(b, r, 1).double()], -1) @ q_a if bias else a.double() @ q_a
+    assert rel(at[:, :ip], exact.reshape(b * r, ip)) <= 6e-3 and float(at[:, ip:].float().abs().max()) == 0.0
+    gt = ops.rotate_bf16(g.reshape(b * r, o).to(DEV), q_g.float().t().contiguous().to(torch.bfloat16).to(DEV))
+    lam = torch.zeros(o, ip, device=DEV)
+    ops.lambda_accum(lam, gt, at, b, r, scale=0.5)
+    assert rel(lam, want) <= 2e-2, rel(lam, want)
 
 
 # ---- SURVEY.md 8(f) kernels: row-wise weighted dots, broadcast product, squared-operand GEMM ---------------------

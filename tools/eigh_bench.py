@@ -1,10 +1,10 @@
-"""``kf_eigh_f64`` on rank-graded covariance matrices (d = 300 ... 2304): time, sweeps, orthogonality, reconstruction,
-eigenvalues against LAPACK.  ``KF_EIGH_SCALAR=1`` forces the scalar round kernel for comparison."""
+"""``kf_eigh_f64`` on rank-graded covariance matrices (d = 300 ... 4096): time, sweeps, orthogonality, reconstruction,
+eigenvalues against LAPACK.  ``KF_EIGH_BLOCK8=1`` forces the round-1 8-column VALU kernel, ``KF_EIGH_SCALAR=1`` the scalar one, for comparison."""
 import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from kronfluence_amd import ops
 dev = "cuda:0"
-for d, n in [(300, 150), (1025, 4000), (1152, 800), (2304, 5000)]:
+for d, n in [(300, 150), (769, 4000), (1025, 4000), (1152, 800), (2304, 5000), (3073, 6000), (4096, 8000)]:
     g = torch.Generator().manual_seed(d)
     x = torch.randn(n, d, generator=g) * torch.logspace(0, -3, d)
     cov = (x.t() @ x).to(dev)
