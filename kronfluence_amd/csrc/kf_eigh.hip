@@ -282,12 +282,21 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict
             out[(wave * 16 + (lane >> 4) + 4 * r) * KP + b * 16 + (lane & 15)] = acc[b][r];
 }
 
-// One cyclic Jacobi sweep over the 64 x 64 Gram matrix of a pair: U and the pair's rotation flag.
+// Rotations of one pair from its 64 x 64 Gram matrix, held in LDS: U and the pair's "rotated" flag.
+//   cross != 0: the 32 x 32 pairs (p in block P, q in block Q), as 32 parallel rounds of 32 disjoint rotations
+//               (round t: p = i, q = 32 + (i + t) % 32) -- run for every pair of every tournament round;
+//   cross == 0: the pairs INSIDE each of the two blocks (two 32-player tournaments side by side, 31 rounds of 16 + 16
+//               rotations) -- run once per sweep on one perfect matching of the blocks.
+// Together every column pair of the matrix is visited exactly once per sweep (a cyclic Jacobi ordering by blocks).
+// The Gram matrix is rotated two-sidedly, G <- J^T G J, so the angles are exactly those of the one-sided method applied
+// to the columns.  Two barriers per round: the column pass reads G and writes a second buffer (every column belongs to
+// exactly one rotation, so all of it is rewritten), the row pass writes back.
 __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restrict__ partial, double* __restrict__ Ubuf, int* __restrict__ pair_flag,
-                                                         int gsplit, double tol, const double* __restrict__ frob2, double null_scale,
-                                                         int* rotated) {
+                                                         int gsplit, int cross, double tol, const double* __restrict__ frob2,
+                                                         double null_scale, int* rotated) {
     constexpr int LP = KP + 1;
     __shared__ double G[KP * LP];
+    __shared__ double H[KP * LP];
     __shared__ double U[KP * LP];
     __shared__ double cs[KB], sn[KB];
     __shared__ int pp[KB], qq[KB];
@@ -299,7 +308,7 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
         double s = 0.0;
         for (int g = 0; g < gsplit; ++g) s += src[static_cast<int64_t>(g) * (KP * KP) + e];
         const int r = e / KP, c = e % KP;
-        G[r * LP + c] = s;
+        H[r * LP + c] = s;
         U[r * LP + c] = r == c ? 1.0 : 0.0;
     }
     if (tid == 0) any = 0;
@@ -307,59 +316,59 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
     // symmetrise (the two triangles were accumulated in different orders)
     for (int e = tid; e < KP * KP; e += 256) {
         const int r = e / KP, c = e % KP;
-        if (r < c) { const double v = 0.5 * (G[r * LP + c] + G[c * LP + r]); G[r * LP + c] = v; G[c * LP + r] = v; }
+        G[r * LP + c] = 0.5 * (H[r * LP + c] + H[c * LP + r]);
     }
     __syncthreads();
-    constexpr int M = KP - 1;
-    for (int round = 0; round < M; ++round) {
-        if (tid < KB) {
-            int p, q;
-            if (tid == 0) { p = round % M; q = M; }
-            else { p = (round + tid) % M; q = (round - tid + M) % M; }
-            const double a = G[p * LP + p], b = G[q * LP + q], g = G[p * LP + q];
-            double c = 1.0, s = 0.0;
-            if (fabs(g) > tol * sqrt(a) * sqrt(b) && a > null2 && b > null2) {
-                const double zeta = (b - a) / (2.0 * g);
-                const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
-                c = 1.0 / sqrt(1.0 + t * t);
-                s = c * t;
-                any = 1;
-            }
-            cs[tid] = c; sn[tid] = s; pp[tid] = p; qq[tid] = q;
+    const int k = tid & 31, rg = tid >> 5;  // column pass: rotation k, rows rg + 8 j
+    const int rounds = cross ? KB : KB - 1;
+    int did = 0;
+    for (int round = 0; round < rounds; ++round) {
+        int p, q;
+        if (cross) {
+            p = k; q = KB + ((k + round) & (KB - 1));
+        } else {
+            const int kk = k & 15, base = (k >> 4) * KB, m = KB - 1;
+            if (kk == 0) { p = base + round % m; q = base + m; }
+            else { p = base + (round + kk) % m; q = base + (round - kk + m) % m; }
         }
-        __syncthreads();
-        // columns: G <- G J, U <- U J   (pair k = tid & 31, rows (tid >> 5) + 8 j)
-        {
-            const int k = tid & 31, p = pp[k], q = qq[k];
-            const double c = cs[k], s = sn[k];
-            if (s != 0.0) {
+        const double a = G[p * LP + p], b = G[q * LP + q], g = G[p * LP + q];
+        double c = 1.0, s = 0.0;
+        if (fabs(g) > tol * sqrt(a) * sqrt(b) && a > null2 && b > null2) {
+            const double zeta = (b - a) / (2.0 * g);
+            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            c = 1.0 / sqrt(1.0 + t * t);
+            s = c * t;
+            did = 1;
+        }
+        if (rg == 0) { cs[k] = c; sn[k] = s; pp[k] = p; qq[k] = q; }
+        // columns: H <- G J, U <- U J
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const int r = (tid >> 5) + 8 * j;
-                    const double gp = G[r * LP + p], gq = G[r * LP + q];
-                    G[r * LP + p] = c * gp - s * gq; G[r * LP + q] = s * gp + c * gq;
-                    const double up = U[r * LP + p], uq = U[r * LP + q];
-                    U[r * LP + p] = c * up - s * uq; U[r * LP + q] = s * up + c * uq;
-                }
+        for (int j = 0; j < 8; ++j) {
+            const int r = rg + 8 * j;
+            const double gp = G[r * LP + p], gq = G[r * LP + q];
+            H[r * LP + p] = c * gp - s * gq; H[r * LP + q] = s * gp + c * gq;
+            if (s != 0.0) {
+                const double up = U[r * LP + p], uq = U[r * LP + q];
+                U[r * LP + p] = c * up - s * uq; U[r * LP + q] = s * up + c * uq;
             }
         }
         __syncthreads();
-        // rows: G <- J^T G   (column tid & 63, pairs (tid >> 6) + 4 j)
+        // rows: G <- J^T H   (column tid & 63, rotations (tid >> 6) + 4 j)
         {
             const int col = tid & 63;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const int k = (tid >> 6) + 4 * j;
-                const double c = cs[k], s = sn[k];
-                if (s != 0.0) {
-                    const int p = pp[k], q = qq[k];
-                    const double tp = G[p * LP + col], tq = G[q * LP + col];
-                    G[p * LP + col] = c * tp - s * tq; G[q * LP + col] = s * tp + c * tq;
-                }
+                const int kr = (tid >> 6) + 4 * j;
+                const double cr = cs[kr], sr = sn[kr];
+                const int pr = pp[kr], qr = qq[kr];
+                const double tp = H[pr * LP + col], tq = H[qr * LP + col];
+                G[pr * LP + col] = cr * tp - sr * tq; G[qr * LP + col] = sr * tp + cr * tq;
             }
         }
         __syncthreads();
     }
+    if (did) any = 1;
+    __syncthreads();
     if (tid == 0) {
         pair_flag[pair] = any;
         if (any) atomicAdd(rotated, 1);
@@ -667,13 +676,15 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
         int* pair_flag = reinterpret_cast<int*>(Ubuf + static_cast<int64_t>(KP) * KP * p.pairs);
         for (; sweeps < max_sweeps; ++sweeps) {
             if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-            for (int r = 0; r < p.players - 1; ++r) {
-                hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players, r,
+            // pass -1: the column pairs inside every block (pairing of round 0); then the tournament of block pairs
+            for (int r = -1; r < p.players - 1; ++r) {
+                const int pairing = r < 0 ? 0 : r;
+                hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players, pairing,
                                    p.gsplit, p.gchunk);
-                hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, tol, frob2_dev,
-                                   null_scale, flag);
+                hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1, tol,
+                                   frob2_dev, null_scale, flag);
                 hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
-                                   p.nblocks, p.players, r, p.uchunk);
+                                   p.nblocks, p.players, pairing, p.uchunk);
             }
             int host_flag = 1;
             if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;

@@ -65,13 +65,16 @@ struct ScoreV2Args {
 };
 
 constexpr int SV2_THREADS = 512;
-constexpr int SV2_OPERAND_BYTES = 256 * 128;
-constexpr int SV2_STAGE_BYTES = 2 * SV2_OPERAND_BYTES;
-constexpr int SV2_SMEM = 2 * SV2_STAGE_BYTES;
 
+// TM x TN output tile, WMW waves along m (8 / WMW along n); every wave owns (TM / WMW) x (TN / (8 / WMW)) as MI x NI
+// accumulators of 32 x 32.  256 x 256 (2 x 4 waves of 128 x 64) is the workhorse; 256 x 128 and 128 x 256 (waves of
+// 64 x 64) cut the padding when the train batch or the query count is far from a multiple of 256.
+template <int TM, int TN, int WMW>
 __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args a) {
+    constexpr int WNW = 8 / WMW, MI = TM / WMW / 32, NI = TN / WNW / 32;
+    constexpr int A_BYTES = TM * 128, STAGE_BYTES = (TM + TN) * 128, GA = TM / 64, GB = TN / 64;  // GA / GB: DMA row groups per wave
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WNW, wn = wave % WNW;
     // XCD-aware block -> work mapping (workgroup L runs on XCD L % 8; speed only): the tiles of one k-chunk are
     // consecutive items of one XCD, so their shared A / B panels are fetched from HBM once per XCD.
     const int tiles = a.tiles_m * a.tiles_n;
@@ -80,34 +83,37 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
     const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
     if (j >= per_xcd || item >= items) return;
     const int chunk = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
-    const int m0 = (tile / a.tiles_n) * 256, n0 = (tile % a.tiles_n) * 256;
+    const int m0 = (tile / a.tiles_n) * TM, n0 = (tile % a.tiles_n) * TN;
     const int kt_begin = chunk * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
 
-    // DMA assignment: a wave instruction fills 8 rows x 128 B; wave w owns row groups 4 w .. 4 w + 3 of each operand
-    int off_a[4], off_b[4];
+    // DMA assignment: a wave instruction fills 8 rows x 128 B; wave w owns row groups GA w .. of A and GB w .. of B
+    int off_a[GA], off_b[GB];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = (wave * 4 + t) * 8 + (lane >> 3);
-        const int chunk_src = (lane & 7) ^ lds_swz(row);
-        off_a[t] = min(m0 + row, a.M - 1) * 64 + chunk_src * 8;
-        off_b[t] = min(n0 + row, a.N - 1) * 64 + chunk_src * 8;
+    for (int t = 0; t < GA; ++t) {
+        const int row = (wave * GA + t) * 8 + (lane >> 3);
+        off_a[t] = min(m0 + row, a.M - 1) * 64 + ((lane & 7) ^ lds_swz(row)) * 8;
+    }
+#pragma unroll
+    for (int t = 0; t < GB; ++t) {
+        const int row = (wave * GB + t) * 8 + (lane >> 3);
+        off_b[t] = min(n0 + row, a.N - 1) * 64 + ((lane & 7) ^ lds_swz(row)) * 8;
     }
     const int64_t a_kt = static_cast<int64_t>(a.M) * 64, b_kt = static_cast<int64_t>(a.N) * 64;
     auto stage = [&](int buf, int kt) {
         const uint16_t* ap = a.A + kt * a_kt;
         const uint16_t* bp = a.B + kt * b_kt;
-        unsigned char* base = sm + buf * SV2_STAGE_BYTES + wave * 4096;
+        unsigned char* base = sm + buf * STAGE_BYTES;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(ap + off_a[t], base + t * 1024);
+        for (int t = 0; t < GA; ++t) glds16(ap + off_a[t], base + (wave * GA + t) * 1024);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(bp + off_b[t], base + SV2_OPERAND_BYTES + t * 1024);
+        for (int t = 0; t < GB; ++t) glds16(bp + off_b[t], base + A_BYTES + (wave * GB + t) * 1024);
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < NI; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
 
@@ -119,18 +125,19 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
         int buf = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
-            const unsigned char* sa = sm + buf * SV2_STAGE_BYTES + (wm * 128 + lr) * 128;
-            const unsigned char* sb = sm + buf * SV2_STAGE_BYTES + SV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
+            const unsigned char* sa = sm + buf * STAGE_BYTES + (wm * (MI * 32) + lr) * 128;
+            const unsigned char* sb = sm + buf * STAGE_BYTES + A_BYTES + (wn * (NI * 32) + lr) * 128;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const int co = ((kk * 2 + hi) ^ sw) * 16;
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+                bf16x8 bv[NI];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
+                for (int jn = 0; jn < NI; ++jn) bv[jn] = *reinterpret_cast<const bf16x8*>(sb + jn * 32 * 128 + co);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
                     const bf16x8 av = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 128 + co);
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[i][1], 0, 0, 0);
+#pragma unroll
+                    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[jn], acc[i][jn], 0, 0, 0);
                 }
             }
             __builtin_amdgcn_s_waitcnt(0);
@@ -139,13 +146,13 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < NI; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = n0 + wn * 64 + jn * 32 + (lane & 31);
+                const int m = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * (NI * 32) + jn * 32 + (lane & 31);
                 if (m < a.M && n < a.N) atomicAdd(a.C + static_cast<int64_t>(m) * a.ldc + n, a.alpha * acc[i][jn][r]);
             }
 }
@@ -361,11 +368,12 @@ int configure_once() {
     static std::once_flag flag;
     static int status = KF_OK;
     std::call_once(flag, [] {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                SV2_SMEM) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                PV2_SMEM) != hipSuccess)
-            status = KF_ERR_LAUNCH_FAILED;
+        const bool ok =
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
+        if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
 }
@@ -375,15 +383,24 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     ScoreV2Args s;
     s.C = scores; s.ldc = ld; s.A = P; s.B = psg;
     s.M = static_cast<int>(Q); s.N = static_cast<int>(b); s.KT = static_cast<int>(D / 64);
-    s.tiles_m = static_cast<int>(cdiv(Q, 256)); s.tiles_n = static_cast<int>(cdiv(b, 256));
+    // tile shape: least padded area, the 64 x 64-per-wave shapes charged 15 % for their extra LDS traffic per flop
+    const int64_t area[3] = {cdiv(Q, 256) * 256 * cdiv(b, 256) * 256, cdiv(Q, 256) * 256 * cdiv(b, 128) * 128,
+                             cdiv(Q, 128) * 128 * cdiv(b, 256) * 256};
+    int shape = 0;
+    if (area[1] * 115 < area[shape] * 100) shape = 1;
+    if (area[2] * 115 < (shape == 0 ? area[0] * 100 : area[1] * 115)) shape = 2;
+    const int tm = shape == 2 ? 128 : 256, tn = shape == 1 ? 128 : 256;
+    s.tiles_m = static_cast<int>(cdiv(Q, tm)); s.tiles_n = static_cast<int>(cdiv(b, tn));
     const int64_t tiles = static_cast<int64_t>(s.tiles_m) * s.tiles_n;
     // one workgroup per CU and k-chunk: ~2 rounds of work items over the 256 CUs, at least 16 k-steps per item
     int64_t ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(512, tiles), s.KT / 16));
     const int64_t kchunk = cdiv(s.KT, ksplit);
     ksplit = cdiv(s.KT, kchunk);
     s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
-    const int64_t blocks = 8 * cdiv(ksplit * tiles, 8);
-    hipLaunchKernelGGL(score_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), SV2_SMEM, st, s);
+    const dim3 grid(static_cast<unsigned>(8 * cdiv(ksplit * tiles, 8)));
+    if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
+    else if (shape == 1) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 128, 4>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
+    else hipLaunchKernelGGL((score_gemm_v2_kernel<128, 256, 2>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     return launch_status();
 }
 

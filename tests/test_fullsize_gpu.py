@@ -145,3 +145,110 @@ def test_resnet9_bf16_pipeline_invariances():
     x, y = x - x.mean(), y - y.mean()
     corr = float((x @ y) / (x.norm() * y.norm()))
     assert corr >= 0.98, (corr, rel(b, a))
+
+
+def test_resnet9_full_size_pairwise_stage():
+    """BASELINE.json configs[1] at its FULL size -- 50 000 train x 1 000 query, bf16 autocast, bf16 query gradients, default
+    damping -- through the product's stage functions (the stage takes about a second on an MI355X):
+
+    * the reference's invariances: a different train batch size / query batching / accumulation gives
+      the same scores (bf16 model passes change with the batch split, so the bar is the reference's own: correlation);
+    * stage-isolated parity on a 64 x 256 sub-block against the fp64 oracle ON THE SAME HOOKED TENSORS AND FACTORS: the layer
+      inputs and output gradients of those 64 queries / 256 train samples are captured with plain torch hooks from the same
+      bf16 forward / backward, and the oracle's per-sample gradient (module/conv2d.py:164-177), EK-FAC preconditioner
+      (factor/config.py:341-353) and score einsum (conv2d.py:199-209) are evaluated on them in fp64 with the product's own
+      eigenvectors and Lambda -- everything downstream of the hooks (im2col / implicit im2col, rotations, bf16 P, score
+      GEMMs) is compared, nothing upstream can differ.  Bound 2e-2 (three bf16 roundings: P, the per-sample gradient and the
+      rotated intermediates, each 2^-9 relative)."""
+    import bench
+    import torch.nn.functional as F
+    from torch import nn
+
+    from kronfluence_amd import FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+    from oracle import ekfac_ref as ref
+
+    state = State()
+    dev = state.device
+    spec = bench.WORKLOADS["resnet9"]
+    n_train, n_query = spec["n_train"], spec["n_query"]
+    assert (n_train, n_query) == (50_000, 1000)
+    torch.manual_seed(0)
+    task = bench.make_task()
+    model = prepare_model(spec["model"](), task).to(dev)
+    train, query = bench.synth(spec, n_train, 1, dev), bench.synth(spec, n_query, 2, dev)
+    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16, per_sample_gradient_dtype=torch.bfloat16,
+                            lambda_dtype=torch.bfloat16)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 1000), fargs, cpu=False)
+    assert int(cov["num_activation_covariance_processed"]["0.0"]) == n_train * 1024
+    eig = perform_eigendecomposition(cov, model, state, fargs, cpu=False)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 1000), fargs, eig, cpu=False)
+    factors = {**eig, **lam}
+
+    def run(qb, tb, acc, damping=1e-8, q=query, t=train):
+        sargs = ScoreArguments(amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16,
+                               damping_factor=damping, query_gradient_accumulation_steps=acc)
+        return compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(q, qb), qb,
+                                                    ResidentLoader(t, tb), sargs, fargs, None)["all_modules"]
+
+    full = run(250, 1000, 4)
+    assert full.shape == (n_query, n_train) and bool(torch.isfinite(full).all())
+    other = run(200, 2000, 5)   # different train batch, query batch and accumulation: one train pass again
+    x, y = full.double().flatten(), other.double().flatten()
+    x, y = x - x.mean(), y - y.mean()
+    assert float((x @ y) / (x.norm() * y.norm())) >= 0.98
+
+    # ---- stage-isolated 64 x 256 sub-block ---------------------------------------------------------------------
+    nq, nt = 64, 256
+    sub_q, sub_t = tuple(v[:nq] for v in query), tuple(v[:nt] for v in train)
+    tracked = [m for m in model.modules() if isinstance(m, TrackedModule)]
+
+    def capture(batch):
+        held, handles = {}, []
+        for m in tracked:
+            def fwd(mod, inputs, output, name=m.name):
+                held[name] = [inputs[0].detach().double().cpu(), None]
+                output.register_hook(lambda grad, name=name: held[name].__setitem__(1, grad.detach().double().cpu()))
+            handles.append(m.original_module.register_forward_hook(fwd))
+        model.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            loss = task.compute_train_loss(batch, model, sample=False)
+        loss.backward()
+        for h in handles:
+            h.remove()
+        return held
+
+    got = {}
+    for damping in (None, 1e-8):
+        got[damping] = run(nq, nt, 1, damping=damping, q=sub_q, t=sub_t).double().cpu()
+    # the bf16 model passes on these 64 / 256 samples (same kernels the stage just ran: same batch shapes)
+    held_q, held_t = capture(sub_q), capture(sub_t)
+    want = {None: torch.zeros(nq, nt, dtype=torch.float64), 1e-8: torch.zeros(nq, nt, dtype=torch.float64)}
+    for m in tracked:
+        mod = m.original_module
+        q_a = eig["activation_eigenvectors"][m.name].double().cpu()
+        q_g = eig["gradient_eigenvectors"][m.name].double().cpu()
+        lam_m, n_lam = lam["lambda_matrix"][m.name].double().cpu(), lam["num_lambda_processed"][m.name].cpu()
+        (aq, gq), (at, gt) = held_q[m.name], held_t[m.name]
+        if isinstance(mod, nn.Conv2d):
+            psg_q = ref.conv_per_sample_gradient(aq, gq, mod)
+        else:
+            psg_q = ref.linear_per_sample_gradient(aq, gq, mod.bias is not None)
+        for damping in want:
+            p = ref.ekfac_precondition(psg_q, q_a, q_g, ref.ekfac_inverse_lambda(lam_m, n_lam, damping, torch.float64))
+            if isinstance(mod, nn.Conv2d):
+                want[damping] += ref.conv_pairwise_score(p, at, gt, mod)
+            else:
+                want[damping] += ref.linear_pairwise_score(p, at, gt, mod.bias is not None)
+    errs = {d: rel(got[d], want[d]) for d in want}
+    assert errs[None] <= 2e-2, errs
+    assert errs[1e-8] <= 5e-2, errs   # Lambda^-1 spans eight decades at the default damping: bf16 cancellation is larger
+    # the same sub-block inside the full run (other batch shapes -> other MIOpen kernels): ranking agreement
+    x, y = full[:nq, :nt].double().cpu().flatten(), want[1e-8].flatten()
+    x, y = x - x.mean(), y - y.mean()
+    assert float((x @ y) / (x.norm() * y.norm())) >= 0.97
