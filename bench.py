@@ -594,7 +594,10 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip targets.mnist_mlp / other_configs in the default run")
     ap.add_argument("--factor-reps", type=int, default=1)
+    ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
     args = ap.parse_args()
+    if args.train_batch:
+        WORKLOADS[args.workload]["train_batch"] = args.train_batch
 
     from kronfluence_amd.utils.state import State
 

@@ -16,6 +16,10 @@
 
 using namespace kf;
 
+namespace kf {
+int score_gemm_tiled(float* scores, int64_t ld, const void* P, const void* psg, int64_t Q, int64_t b, int64_t D, float scale, void* stream);
+}
+
 namespace {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1129,6 +1133,7 @@ int kf_pairwise_score(float* scores, int64_t ld_scores, const void* P, int p_dty
                          tiled ? b * 64 : 0);
     if (rc != KF_OK) return rc;
     // scores[q, n] += scale * sum_d P[q, d] psg[n, d]
+    if (tiled) return score_gemm_tiled(scores, ld_scores, P, psg, Q, b, D, scale, stream);  // 256 x 256-tile LDS-DMA kernel
     kf_view vp = make_view(P, p_dtype, 0, tiled ? 64 : D, 1, Q, D);
     kf_view vg = make_view(psg, p_dtype, 0, tiled ? 64 : D, 1, b, D);
     if (tiled) { vp.k_tile_stride = Q * 64; vg.k_tile_stride = b * 64; }

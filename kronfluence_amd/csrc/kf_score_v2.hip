@@ -176,7 +176,11 @@ struct PsgV2Args {
 
 constexpr int PV2_OPERAND_BYTES = 128 * 128;
 constexpr int PV2_STAGE_BYTES = 2 * PV2_OPERAND_BYTES;
-constexpr int PV2_SMEM = 2 * PV2_STAGE_BYTES;
+constexpr int PV2_STAGES = 4;                       // LDS ring: 4 k-steps in flight (one workgroup per CU)
+constexpr int PV2_SMEM = PV2_STAGES * PV2_STAGE_BYTES;
+
+// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding, vmcnt = imm[3:0] | imm[15:14] << 4
+#define KF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
 
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     const int z = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
     const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
 
-    // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is chunk_src
+    // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is oct[t]
     const uint16_t* src_a[4];
     const uint16_t* src_b[4];
     int oct[4];
@@ -210,7 +214,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
             src_b[t] = a.B + static_cast<int64_t>(z) * a.b_sample_stride + static_cast<int64_t>(i) * a.K + oct[t] * 8;
         }
     }
-    auto stage = [&](int buf, int k0) {
+    auto stage = [&](int buf, int k0) {  // 8 DMA instructions per thread
         unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
 #pragma unroll
         for (int t = 0; t < 4; ++t) glds16(src_a[t] + k0, base + t * 1024);
@@ -229,13 +233,23 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     f32x16 acc[2][2];
     zero_acc(acc);
     {
+        // K is short (64 .. 1024 = 1 .. 16 k-steps): up to PV2_STAGES k-steps are requested up front and the ring is
+        // refilled as stages retire, so the DMA queue never drains inside a tile.  A stage is consumed after a COUNTED
+        // vmcnt (this thread's own DMAs of that stage have landed) plus a raw s_barrier (everybody's have): a plain
+        // __syncthreads() would drain the whole queue (cdna_hip_programming.md, glds pipelining across barriers).
         const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
-        stage(0, 0);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        int buf = 0;
-        for (int k0 = 0; k0 < a.K; k0 += 64) {
-            if (k0 + 64 < a.K) stage(buf ^ 1, k0 + 64);
+        const int steps = a.K >> 6;
+        const int ahead = min(steps, PV2_STAGES);
+        for (int s0 = 0; s0 < ahead; ++s0) stage(s0, s0 * 64);
+        int issued = ahead;
+        for (int st = 0; st < steps; ++st) {
+            const int inflight = issued - st - 1;  // stages requested after this one
+            if (inflight >= 3) KF_WAIT_VMCNT(24);
+            else if (inflight == 2) KF_WAIT_VMCNT(16);
+            else if (inflight == 1) KF_WAIT_VMCNT(8);
+            else KF_WAIT_VMCNT(0);
+            __builtin_amdgcn_s_barrier();
+            const int buf = st % PV2_STAGES;
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
 #pragma unroll
@@ -250,10 +264,15 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
             }
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            buf ^= 1;
+            if (issued < steps) {  // refill the stage just consumed (uniform): every wave must be done reading it
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                stage(buf, issued * 64);
+                ++issued;
+            }
         }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();  // all fragment reads done before the epilogue reuses the LDS
     }
     // epilogue: bf16 through LDS (pitch 272 B), then 16 bytes per lane into the k-tile-major gradient buffer
     constexpr int OP = 272;
@@ -289,7 +308,8 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
 // ------------------------------------------------------------------------------------------------
 struct PadArgs {
     uint16_t* out; const uint16_t* x;
-    int64_t planes;  // batch * C
+    int64_t planes;  // batch * Cp
+    int C, Cp;       // real / padded channels (planes c >= C are zero)
     int H, W, Hp, Wq, p1, p2, s2;
 };
 
@@ -305,8 +325,10 @@ __global__ __launch_bounds__(256) void conv_pad_phases_kernel(PadArgs a) {
         const int y = static_cast<int>(rest % a.Hp);
         const int64_t plane = rest / a.Hp;
         const int iy = y - a.p1;
-        const bool row_ok = iy >= 0 && iy < a.H;
-        const uint16_t* src = a.x + (plane * a.H + (row_ok ? iy : 0)) * a.W;
+        const int64_t n = plane / a.Cp;
+        const int c = static_cast<int>(plane - n * a.Cp);
+        const bool row_ok = iy >= 0 && iy < a.H && c < a.C;
+        const uint16_t* src = a.x + ((n * a.C + (c < a.C ? c : 0)) * a.H + (row_ok ? iy : 0)) * a.W;
         uint32_t w[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -364,6 +386,21 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
     }
 }
 
+// [planes][O1][O2] -> [planes][O1p][O2p], zero filled: the output-gradient grid of a convolution rounded up so that a row is
+// a whole number of 16-byte chunks and the positions a whole number of 64-wide k-steps (padded positions carry zero
+// gradient, so they contribute nothing to the per-sample gradient whatever the input holds there).
+__global__ __launch_bounds__(256) void pad_grid_kernel(uint16_t* out, const uint16_t* g, int64_t planes, int O1, int O2, int O1p, int O2p) {
+    const int64_t total = planes * O1p * O2p;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
+         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int ox = static_cast<int>(e % O2p);
+        const int64_t rest = e / O2p;
+        const int oy = static_cast<int>(rest % O1p);
+        const int64_t plane = rest / O1p;
+        out[e] = (oy < O1 && ox < O2) ? g[(plane * O1 + oy) * O2 + ox] : static_cast<uint16_t>(0);
+    }
+}
+
 int configure_once() {
     static std::once_flag flag;
     static int status = KF_OK;
@@ -418,54 +455,94 @@ inline int64_t conv_wq(int64_t O2, int k2, int d2, int s2) { return (O2 + ((k2 -
 
 }  // namespace
 
+namespace kf {
+// used by kf_pairwise_score's k-tile-major path (kf_kernels.hip): the score GEMM of a layer whose per-sample gradients were
+// formed by the v1 (transposing) kernel
+int score_gemm_tiled(float* scores, int64_t ld, const void* P, const void* psg, int64_t Q, int64_t b, int64_t D, float scale, void* stream) {
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    return launch_score_v2(scores, ld, reinterpret_cast<const uint16_t*>(P), reinterpret_cast<const uint16_t*>(psg), Q, b, D, scale,
+                           as_stream(stream));
+}
+}  // namespace kf
+
 extern "C" {
+
+namespace {
+struct ConvPlan {
+    int64_t O1, O2, O1p, O2p, Cp, Hp, Wq, Pp, Ipp, D;
+    int64_t copies_bytes, grid_bytes, psg_bytes;
+    bool ok;
+};
+ConvPlan conv_plan(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2) {
+    ConvPlan c{};
+    c.O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1;
+    c.O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
+    c.ok = c.O1 > 0 && c.O2 > 0;
+    if (!c.ok) return c;
+    c.O2p = (c.O2 + 7) / 8 * 8;
+    c.O1p = c.O1;
+    while ((c.O1p * c.O2p) % 64 != 0) ++c.O1p;
+    c.Cp = (C + 7) / 8 * 8;
+    c.Pp = c.O1p * c.O2p;
+    c.Ipp = c.Cp * k1 * k2;
+    c.D = O * c.Ipp;
+    c.Hp = std::max<int64_t>(H + 2 * p1, s1 * (c.O1p - 1) + static_cast<int64_t>(d1) * (k1 - 1) + 1);
+    c.Wq = conv_wq(c.O2p, k2, d2, s2);
+    // padding the output grid and the channels may at most double the contraction work of the gradient kernel
+    c.ok = c.Pp <= 2 * c.O1 * c.O2 && c.Cp * c.Pp <= 3 * C * c.O1 * c.O2 && c.D % 64 == 0 && O >= 8;
+    c.copies_bytes = align256(2 * s2 * b * c.Cp * c.Hp * c.Wq + 64);
+    c.grid_bytes = (c.O1p != c.O1 || c.O2p != c.O2) ? align256(2 * b * O * c.Pp) : 0;
+    c.psg_bytes = align256(2 * b * c.D);
+    return c;
+}
+}  // namespace
 
 int64_t kf_pairwise_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2,
                                            int p1, int p2, int d1, int d2) {
-    const int64_t O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1, O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
-    if (O1 <= 0 || O2 <= 0) return -1;
-    const int64_t Hp = H + 2 * p1, Wq = conv_wq(O2, k2, d2, s2);
-    const int64_t copies = align256(2 * s2 * b * C * Hp * Wq + 64);
-    const int64_t psg = align256(2 * b * O * C * k1 * k2);
-    return copies + psg;
+    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    if (!c.ok) return -1;
+    return c.copies_bytes + c.grid_bytes + c.psg_bytes;
 }
 
 int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G_nchw, const void* x,
                              int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2,
                              int d1, int d2, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!scores || !P_tiled || !G_nchw || !x || Q < 0 || b < 0 || C <= 0 || O <= 0) return KF_ERR_INVALID_ARGUMENT;
-    const int64_t O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1, O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
-    if (O1 <= 0 || O2 <= 0) return KF_ERR_INVALID_ARGUMENT;
-    const int64_t P = O1 * O2, Ip = C * k1 * k2, D = O * Ip;
+    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
     // eligibility (the host checks the same conditions and uses the materialised-patch path otherwise)
-    if (O2 % 8 != 0 || P % 64 != 0 || C % 8 != 0 || D % 64 != 0) return KF_ERR_INVALID_ARGUMENT;
+    if (!c.ok) return KF_ERR_INVALID_ARGUMENT;
     if (((reinterpret_cast<uintptr_t>(P_tiled) | reinterpret_cast<uintptr_t>(G_nchw) | reinterpret_cast<uintptr_t>(x)) & 15) != 0)
         return KF_ERR_INVALID_ARGUMENT;
-    const int64_t need = kf_pairwise_conv2d_workspace_bytes(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
-    if (!workspace || workspace_bytes < need) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (!workspace || workspace_bytes < c.copies_bytes + c.grid_bytes + c.psg_bytes) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (Q == 0 || b == 0) return KF_OK;
     if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
     hipStream_t st = as_stream(stream);
-    const int64_t Hp = H + 2 * p1, Wq = conv_wq(O2, k2, d2, s2);
     uint16_t* copies = reinterpret_cast<uint16_t*>(workspace);
-    uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align256(2 * s2 * b * C * Hp * Wq + 64));
+    uint16_t* grid = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + c.copies_bytes);
+    uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + c.copies_bytes + c.grid_bytes);
     PadArgs pa;
-    pa.out = copies; pa.x = reinterpret_cast<const uint16_t*>(x); pa.planes = b * C;
-    pa.H = static_cast<int>(H); pa.W = static_cast<int>(W); pa.Hp = static_cast<int>(Hp); pa.Wq = static_cast<int>(Wq);
+    pa.out = copies; pa.x = reinterpret_cast<const uint16_t*>(x); pa.planes = b * c.Cp; pa.C = static_cast<int>(C); pa.Cp = static_cast<int>(c.Cp);
+    pa.H = static_cast<int>(H); pa.W = static_cast<int>(W); pa.Hp = static_cast<int>(c.Hp); pa.Wq = static_cast<int>(c.Wq);
     pa.p1 = p1; pa.p2 = p2; pa.s2 = s2;
-    const int64_t chunks = s2 * b * C * Hp * (Wq / 8);
+    const int64_t chunks = s2 * b * c.Cp * c.Hp * (c.Wq / 8);
     hipLaunchKernelGGL(conv_pad_phases_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(chunks, 256), 1 << 20))), dim3(256), 0,
                        st, pa);
+    const uint16_t* gsrc = reinterpret_cast<const uint16_t*>(G_nchw);
+    if (c.grid_bytes) {
+        hipLaunchKernelGGL(pad_grid_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(b * O * c.Pp, 256), 1 << 20))), dim3(256), 0, st,
+                           grid, gsrc, b * O, static_cast<int>(c.O1), static_cast<int>(c.O2), static_cast<int>(c.O1p), static_cast<int>(c.O2p));
+        gsrc = grid;
+    }
     PsgV2Args g;
     g.out = psg; g.out_tile_stride = b * 64;
-    g.A = reinterpret_cast<const uint16_t*>(G_nchw); g.a_sample_stride = O * P;
-    g.B = copies; g.b_sample_stride = C * Hp * Wq;
-    g.M = static_cast<int>(O); g.N = static_cast<int>(Ip); g.K = static_cast<int>(P); g.batch = static_cast<int>(b);
-    g.conv = 1; g.C = static_cast<int>(C); g.k2 = k2; g.O2 = static_cast<int>(O2); g.s1 = s1; g.d1 = d1; g.s2 = s2; g.d2 = d2;
-    g.Wq = static_cast<int>(Wq); g.plane = static_cast<int>(Hp * Wq); g.phase_stride = b * C * Hp * Wq;
+    g.A = gsrc; g.a_sample_stride = O * c.Pp;
+    g.B = copies; g.b_sample_stride = c.Cp * c.Hp * c.Wq;
+    g.M = static_cast<int>(O); g.N = static_cast<int>(c.Ipp); g.K = static_cast<int>(c.Pp); g.batch = static_cast<int>(b);
+    g.conv = 1; g.C = static_cast<int>(c.Cp); g.k2 = k2; g.O2 = static_cast<int>(c.O2p); g.s1 = s1; g.d1 = d1; g.s2 = s2; g.d2 = d2;
+    g.Wq = static_cast<int>(c.Wq); g.plane = static_cast<int>(c.Hp * c.Wq); g.phase_stride = b * c.Cp * c.Hp * c.Wq;
     int rc = launch_psg_v2(g, st);
     if (rc != KF_OK) return rc;
-    return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, D, scale, st);
+    return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, c.D, scale, st);
 }
 
 int64_t kf_pairwise_rows_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip) {

@@ -14,6 +14,35 @@ import torch
 from torch.utils.hooks import RemovableHandle
 
 
+class QueryBlocks:
+    """The preconditioned query gradients of several query batches, kept as the list of per-batch ``[q_i, O, I']`` blocks.
+    The reference grows one tensor with ``torch.cat`` per batch (``tracker/precondition.py:216-240``) -- quadratic copying,
+    2.9 TB for the 174 GB of a GPT-2-small query set; the score trackers consume the blocks as they are (the k-tile-major
+    layout is built block by block), so nothing is ever concatenated on the hot path."""
+
+    def __init__(self, blocks) -> None:
+        self.blocks = list(blocks)
+
+    def append(self, block: torch.Tensor) -> "QueryBlocks":
+        self.blocks.append(block)
+        return self
+
+    @property
+    def shape(self):
+        return (sum(b.shape[0] for b in self.blocks),) + tuple(self.blocks[0].shape[1:])
+
+    @property
+    def dtype(self):
+        return self.blocks[0].dtype
+
+    @property
+    def device(self):
+        return self.blocks[0].device
+
+    def dense(self) -> torch.Tensor:
+        return self.blocks[0] if len(self.blocks) == 1 else torch.cat(self.blocks, dim=0)
+
+
 def _remove_all(handles: List[RemovableHandle]) -> List[RemovableHandle]:
     for handle in reversed(handles):
         handle.remove()

@@ -16,7 +16,7 @@ import torch
 from torch import nn
 
 from kronfluence_amd import ops
-from kronfluence_amd.module.tracker.base import BaseTracker
+from kronfluence_amd.module.tracker.base import BaseTracker, QueryBlocks
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
     AGGREGATED_GRADIENT_NAME,
@@ -68,6 +68,8 @@ def unpadded_queries(module, preconditioned):
     """The held query gradients at the reference's width: strips the zero columns the bf16 preconditioner appends for an
     odd ``I'`` (``module.query_padding``).  For every reader that is not one of the padded score kernels."""
     pad = getattr(module, "query_padding", 0)
+    if pad and isinstance(preconditioned, QueryBlocks):
+        return QueryBlocks([b[..., :b.shape[-1] - pad].contiguous() for b in preconditioned.blocks])
     if pad and torch.is_tensor(preconditioned):
         return preconditioned[..., :preconditioned.shape[-1] - pad].contiguous()
     return preconditioned
@@ -75,8 +77,8 @@ def unpadded_queries(module, preconditioned):
 
 def dense_queries(preconditioned, score_dtype: torch.dtype = torch.float32) -> torch.Tensor:
     """The held query gradients as one dense ``[Q, O, I']`` tensor (expands low-rank factors)."""
-    if isinstance(preconditioned, TiledQueries):
-        return preconditioned.dense()
+    if isinstance(preconditioned, (TiledQueries, QueryBlocks)):
+        preconditioned = preconditioned.dense()
     if isinstance(preconditioned, list):
         dense = ops.low_rank_product(preconditioned[0], preconditioned[1])
         return ops.cast(dense, torch.bfloat16) if score_dtype == torch.bfloat16 else dense
@@ -98,19 +100,28 @@ class TiledQueries:
         preconditioner's output for an odd ``I'``).  ``conv_channels = C > 0``: the patch axis ``(c, ky, kx)`` of a
         convolution's gradient is re-ordered to ``(ky, kx, c)``, the order in which the implicit-im2col kernel produces
         per-sample gradients (``kf_pairwise_score_conv2d``)."""
-        q, o, ip = dense.shape
-        self.num_queries, self.rows, self.width, self.conv_channels = q, o, ip + pad, conv_channels
+        blocks = dense.blocks if isinstance(dense, QueryBlocks) else [dense]
+        q, o, ip = (sum(b.shape[0] for b in blocks),) + tuple(blocks[0].shape[1:])
+        self.num_queries, self.rows, self.conv_channels = q, o, conv_channels
         self.pad = pad + prepadded  # total zero columns relative to the reference's I'
+        assert dense.dtype == torch.bfloat16 and not (self.pad and conv_channels)
+        taps = ip // conv_channels if conv_channels else 0
+        self.conv_padded = conv_channels + (-conv_channels) % 8  # channels incl. the zero channels the kernel adds
+        self.width = taps * self.conv_padded if conv_channels else ip + pad
         d = o * self.width
-        assert dense.dtype == torch.bfloat16 and d % 64 == 0 and not (self.pad and conv_channels)
+        assert d % 64 == 0
         self.tiled = torch.empty((d // 64, q, 64), dtype=torch.bfloat16, device=dense.device)
-        for start in range(0, q, self.CHUNK):
-            block = dense[start:start + self.CHUNK]
-            if pad:
-                block = torch.nn.functional.pad(block, (0, pad))
-            if conv_channels:
-                block = block.reshape(block.shape[0], o, conv_channels, ip // conv_channels).transpose(2, 3)
-            self.tiled[:, start:start + block.shape[0]] = block.reshape(block.shape[0], d // 64, 64).transpose(0, 1)
+        row = 0
+        for source in blocks:
+            for start in range(0, source.shape[0], self.CHUNK):
+                block = source[start:start + self.CHUNK]
+                if pad:
+                    block = torch.nn.functional.pad(block, (0, pad))
+                if conv_channels:
+                    block = block.reshape(block.shape[0], o, conv_channels, taps).transpose(2, 3)
+                    block = torch.nn.functional.pad(block, (0, self.conv_padded - conv_channels))
+                self.tiled[:, row:row + block.shape[0]] = block.reshape(block.shape[0], d // 64, 64).transpose(0, 1)
+                row += block.shape[0]
 
     @property
     def shape(self):
@@ -120,9 +131,9 @@ class TiledQueries:
         """Back to the reference's ``[Q, O, I']`` (rare paths only)."""
         full = self.tiled.transpose(0, 1).reshape(self.num_queries, self.rows, self.width)
         if self.conv_channels:
-            c = self.conv_channels
-            full = full.reshape(self.num_queries, self.rows, self.width // c, c).transpose(2, 3)
-            return full.reshape(self.num_queries, self.rows, self.width).contiguous()
+            c, cp = self.conv_channels, self.conv_padded
+            full = full.reshape(self.num_queries, self.rows, self.width // cp, cp)[..., :c].transpose(2, 3)
+            return full.reshape(self.num_queries, self.rows, -1).contiguous()
         return full[:, :, :self.width - self.pad].contiguous()
 
 
@@ -131,6 +142,12 @@ class PairwiseScoreTracker(BaseTracker):
 
     def _query_blocks(self, preconditioned):
         """Yields ``(first_row, dense [q_c, O, I'])`` covering the held queries."""
+        if isinstance(preconditioned, QueryBlocks):
+            first = 0
+            for block in preconditioned.blocks:
+                yield first, dense_queries(block)
+                first += block.shape[0]
+            return
         if not isinstance(preconditioned, list):
             yield 0, dense_queries(preconditioned)
             return
@@ -162,7 +179,8 @@ class PairwiseScoreTracker(BaseTracker):
         if tiled is not None and tiled.conv_channels:  # laid out for the implicit-im2col kernel: back to the reference's
             preconditioned, tiled = tiled.dense(), None
         if tiled is None:
-            if (not torch.is_tensor(preconditioned) or preconditioned.dtype != torch.bfloat16 or g.shape[1] == 1
+            if (not (torch.is_tensor(preconditioned) or isinstance(preconditioned, QueryBlocks))
+                    or preconditioned.dtype != torch.bfloat16 or g.shape[1] == 1
                     or g.dtype != torch.bfloat16 or a.dtype != torch.bfloat16 or g.shape[-1] % 8 != 0):
                 return None
             width = a.shape[-1] + int(ones)
@@ -193,22 +211,21 @@ class PairwiseScoreTracker(BaseTracker):
         tiled = preconditioned if isinstance(preconditioned, TiledQueries) else None
         if not self.SCORE_V2 or output_gradient.dtype != torch.bfloat16:
             return False
-        if tiled is None and not (torch.is_tensor(preconditioned) and preconditioned.dtype == torch.bfloat16):
+        if tiled is None and not ((torch.is_tensor(preconditioned) or isinstance(preconditioned, QueryBlocks))
+                                  and preconditioned.dtype == torch.bfloat16):
             return False
         if isinstance(original, nn.Conv2d) and activation.dim() == 4 and output_gradient.dim() == 4:
-            if original.groups != 1 or original.bias is not None:
+            geometry = ops.conv2d_score_geometry(activation.shape, output_gradient.shape[1], original)
+            if geometry is None:
                 return False
-            c, (k1, k2) = activation.shape[1], original.kernel_size
-            o, o1, o2 = output_gradient.shape[1:]
+            c, o, (k1, k2) = activation.shape[1], output_gradient.shape[1], original.kernel_size
             ip = c * k1 * k2
-            if o2 % 8 != 0 or (o1 * o2) % 64 != 0 or c % 8 != 0 or (o * ip) % 64 != 0:
-                return False
             if tiled is None:
                 if tuple(preconditioned.shape[1:]) != (o, ip):
                     return False
                 tiled = TiledQueries(preconditioned, 0, conv_channels=c)
                 module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = tiled  # the dense block is released
-            elif tiled.conv_channels != c or tiled.shape[1:] != (o, ip):
+            elif tiled.conv_channels != c or tiled.shape[1:] != (o, (c + (-c) % 8) * k1 * k2):
                 return False
             x = activation if activation.dtype == torch.bfloat16 else activation.to(torch.bfloat16)
             ops.pairwise_score_conv2d(scores, offset, tiled, output_gradient, x, original, scale=module.gradient_scale)

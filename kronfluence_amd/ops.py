@@ -463,26 +463,39 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p, g: torch.Tensor, a:
         )
 
 
+def conv2d_score_geometry(x_shape, out_channels: int, conv: nn.Conv2d):
+    """``(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2)`` of the implicit-im2col score call, or ``None`` when the layer is
+    not eligible (groups, bias, or a geometry whose padding to whole 16-byte chunks / 64-wide k-steps would more than
+    double the work -- decided by the library itself: ``kf_pairwise_conv2d_workspace_bytes`` returns -1)."""
+    if conv.groups != 1 or conv.bias is not None:
+        return None
+    b, c, h, w = x_shape
+    geometry = (b, c, h, w, out_channels) + conv_geometry(conv)
+    return geometry if nat.lib().kf_pairwise_conv2d_workspace_bytes(*geometry) > 0 else None
+
+
 def pairwise_score_conv2d(scores: torch.Tensor, col_offset: int, p, g_nchw: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d,
                           scale: float = 1.0) -> None:
     """Implicit-im2col score of a Conv2d layer (kf_pairwise_score_conv2d): ``p.tiled`` is the k-tile-major bf16 P whose
-    patch axis is ordered ``(ky, kx, c)``; ``g_nchw`` the hooked output gradient ``[b, O, O1, O2]`` and ``x`` the hooked
-    input ``[b, C, H, W]``, both bf16 -- neither patches nor a transposed gradient are materialised."""
+    patch axis is ordered ``(ky, kx, c)`` with ``c`` zero-padded to a multiple of 8; ``g_nchw`` the hooked output gradient
+    ``[b, O, O1, O2]`` and ``x`` the hooked input ``[b, C, H, W]``, both bf16 -- neither patches nor a transposed gradient
+    are materialised."""
     nat.require_device(scores, "scores")
     nat.require_device(g_nchw, "g_nchw")
     g_nchw, x = _contig(g_nchw), _contig(x)
     assert g_nchw.dtype == x.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32
     b, c, h, w = x.shape
     o, o1, o2 = g_nchw.shape[1], g_nchw.shape[2], g_nchw.shape[3]
-    k1, k2, s1, s2, p1, p2, d1, d2 = conv_geometry(conv)
-    q, ip = p.shape[0], c * k1 * k2
+    geometry = conv2d_score_geometry(x.shape, o, conv)
+    assert geometry is not None, "layer not eligible for the implicit-im2col path"
+    k1, k2 = geometry[5], geometry[6]
+    q, ip = p.shape[0], (c + (-c) % 8) * k1 * k2
     assert p.shape == (q, o, ip) and scores.shape[0] == q and col_offset + b <= scores.shape[1]
-    geometry = (b, c, h, w, o, k1, k2, s1, s2, p1, p2, d1, d2)
     ws_bytes = nat.lib().kf_pairwise_conv2d_workspace_bytes(*geometry)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-    r = o1 * o2
-    flops = 2.0 * q * b * o * ip + 2.0 * b * r * o * ip
-    nbytes = b * (r * o + c * h * w) * 2 + q * o * ip * 2 + 2.0 * q * b * 4  # B_pair: I^raw (not the patches), G, P, scores
+    r, real_ip = o1 * o2, c * k1 * k2
+    flops = 2.0 * q * b * o * real_ip + 2.0 * b * r * o * real_ip
+    nbytes = b * (r * o + c * h * w) * 2 + q * o * real_ip * 2 + 2.0 * q * b * 4  # B_pair: I^raw (not the patches), G, P, scores
     with _Timed("pairwise_score", x.device, flops, nbytes):
         nat.check(
             nat.lib().kf_pairwise_score_conv2d(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.tiled.data_ptr(), q,

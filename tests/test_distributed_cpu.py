@@ -117,7 +117,9 @@ def _query_allgather(rank, world, out_dir):
     m.synchronize(num_processes=world)
     m.truncate(keep_size=n_query % (per_rank * world) or per_rank * world)
     m.accumulate_iterations()
-    torch.save(m.storage["accumulated_preconditioned_gradient"], os.path.join(out_dir, f"rank{rank}.pt"))
+    held = m.storage["accumulated_preconditioned_gradient"]  # QueryBlocks: the per-batch blocks, never concatenated
+    assert held.shape == (n_query, 2, 3) and len(held.blocks) == 1
+    torch.save(held.dense(), os.path.join(out_dir, f"rank{rank}.pt"))
 
 
 def test_query_allgather_restores_dataset_order(tmp_path):

@@ -301,6 +301,8 @@ V2_CONVS = [
     dict(b=4, cin=8, cout=24, k=3, stride=1, padding=2, dilation=2, hw=(8, 16)),       # dilation 2, non-square image
     dict(b=2, cin=128, cout=130, k=3, stride=1, padding=0, dilation=1, hw=(10, 18)),   # no padding, ragged O tile, 2 k-steps
     dict(b=7, cin=8, cout=8, k=(1, 3), stride=1, padding=(0, 1), dilation=1, hw=(8, 8)),  # 1x3 kernel, P = 64
+    dict(b=6, cin=3, cout=64, k=3, stride=1, padding=1, dilation=1, hw=(16, 16)),      # 3 channels -> padded to 8 (a first layer)
+    dict(b=5, cin=16, cout=24, k=3, stride=1, padding=0, dilation=1, hw=(8, 8)),       # 6 x 6 output grid -> padded to 8 x 8
 ]
 
 
@@ -319,6 +321,7 @@ def test_pairwise_score_conv2d_implicit_im2col(ops, c, q):
     g = _rand(*out.shape, dtype=torch.bfloat16, seed=1)
     ip = c["cin"] * conv.kernel_size[0] * conv.kernel_size[1]
     p = _rand(q, c["cout"], ip, seed=7).to(torch.bfloat16)
+    assert ops.conv2d_score_geometry(x.shape, c["cout"], conv) is not None
     want = ref.conv_pairwise_score(p.double(), x.double(), g.double(), conv.double())
     tiled = TiledQueries(p.to(DEV), 0, conv_channels=c["cin"])
     assert torch.equal(tiled.dense(), p.to(DEV))  # the permutation round-trips

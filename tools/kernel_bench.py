@@ -18,6 +18,7 @@ from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 
 DEV = "cuda:0"
 RESNET9 = [  # (cin, cout, k, stride, padding, H)
+    ("conv0 3->64 (C pad 8)", 3, 64, 3, 1, 1, 32), ("conv7 256->128 6x6 grid", 256, 128, 3, 1, 0, 8),
     ("conv1 64->128 k5 s2", 64, 128, 5, 2, 2, 32), ("conv2 128->128", 128, 128, 3, 1, 1, 16), ("conv4 128->256", 128, 256, 3, 1, 1, 16),
     ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8),
 ]
@@ -57,11 +58,14 @@ def main():
             ip = cin * k * k
             pq = torch.randn(q, cout, ip, device=DEV).bfloat16()
             flops = 2.0 * q * b * cout * ip + 2.0 * b * o * o * cout * ip
-            v1p, v2p = TiledQueries(pq, 0), TiledQueries(pq, 0, conv_channels=cin)
+            v1p = TiledQueries(pq, (-ip) % 8) if cout % 8 == 0 else pq
+            v2p = TiledQueries(pq, 0, conv_channels=cin)
             s1, s2 = torch.zeros(q, b, device=DEV), torch.zeros(q, b, device=DEV)
 
             def v1(out=s1):
                 patches = ops.im2col(x, conv, False, torch.bfloat16)
+                if ip % 8:
+                    patches = torch.nn.functional.pad(patches, (0, (-ip) % 8))
                 rows = g.flatten(2).transpose(1, 2).contiguous()
                 ops.pairwise_score(out, 0, v1p, rows, patches, False)
 
