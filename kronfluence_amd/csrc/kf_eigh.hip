@@ -333,9 +333,12 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
         }
         const double a = G[p * LP + p], b = G[q * LP + q], g = G[p * LP + q];
         double c = 1.0, s = 0.0;
-        if (fabs(g) > tol * sqrt(a) * sqrt(b) && a > null2 && b > null2) {
-            const double zeta = (b - a) / (2.0 * g);
-            const double t = copysign(1.0, zeta) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+        // |g| > tol sqrt(a b), tested without square roots; the rotation with two square roots and two divisions instead
+        // of four and three (the fp64 sqrt / div sequences are the critical path of a round):
+        //   zeta = (b - a) / 2g,  t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)) = sgn(b - a) 2g / (|b - a| + sqrt((b - a)^2 + 4 g^2))
+        if (g * g > tol * tol * a * b && a > null2 && b > null2) {
+            const double w = b - a, h = 2.0 * g;
+            const double t = copysign(1.0, w) * h / (fabs(w) + sqrt(w * w + h * h));
             c = 1.0 / sqrt(1.0 + t * t);
             s = c * t;
             did = 1;

@@ -176,11 +176,7 @@ struct PsgV2Args {
 
 constexpr int PV2_OPERAND_BYTES = 128 * 128;
 constexpr int PV2_STAGE_BYTES = 2 * PV2_OPERAND_BYTES;
-constexpr int PV2_STAGES = 4;                       // LDS ring: 4 k-steps in flight (one workgroup per CU)
-constexpr int PV2_SMEM = PV2_STAGES * PV2_STAGE_BYTES;
-
-// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding, vmcnt = imm[3:0] | imm[15:14] << 4
-#define KF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
+constexpr int PV2_SMEM = 2 * PV2_STAGE_BYTES;
 
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -193,7 +189,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     const int z = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
     const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
 
-    // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is oct[t]
+    // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is chunk_src
     const uint16_t* src_a[4];
     const uint16_t* src_b[4];
     int oct[4];
@@ -214,7 +210,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
             src_b[t] = a.B + static_cast<int64_t>(z) * a.b_sample_stride + static_cast<int64_t>(i) * a.K + oct[t] * 8;
         }
     }
-    auto stage = [&](int buf, int k0) {  // 8 DMA instructions per thread
+    auto stage = [&](int buf, int k0) {
         unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
 #pragma unroll
         for (int t = 0; t < 4; ++t) glds16(src_a[t] + k0, base + t * 1024);
@@ -233,23 +229,16 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     f32x16 acc[2][2];
     zero_acc(acc);
     {
-        // K is short (64 .. 1024 = 1 .. 16 k-steps): up to PV2_STAGES k-steps are requested up front and the ring is
-        // refilled as stages retire, so the DMA queue never drains inside a tile.  A stage is consumed after a COUNTED
-        // vmcnt (this thread's own DMAs of that stage have landed) plus a raw s_barrier (everybody's have): a plain
-        // __syncthreads() would drain the whole queue (cdna_hip_programming.md, glds pipelining across barriers).
+        // Two stages of 32 KB -> two workgroups per CU, whose load and MFMA phases interleave.  (A 4-stage ring with
+        // counted vmcnt and one workgroup per CU was measured 10-15 % SLOWER on every layer shape: with K of only 1-4
+        // k-steps the second resident workgroup hides more latency than a deeper ring does.)
         const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
-        const int steps = a.K >> 6;
-        const int ahead = min(steps, PV2_STAGES);
-        for (int s0 = 0; s0 < ahead; ++s0) stage(s0, s0 * 64);
-        int issued = ahead;
-        for (int st = 0; st < steps; ++st) {
-            const int inflight = issued - st - 1;  // stages requested after this one
-            if (inflight >= 3) KF_WAIT_VMCNT(24);
-            else if (inflight == 2) KF_WAIT_VMCNT(16);
-            else if (inflight == 1) KF_WAIT_VMCNT(8);
-            else KF_WAIT_VMCNT(0);
-            __builtin_amdgcn_s_barrier();
-            const int buf = st % PV2_STAGES;
+        stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        int buf = 0;
+        for (int k0 = 0; k0 < a.K; k0 += 64) {
+            if (k0 + 64 < a.K) stage(buf ^ 1, k0 + 64);
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
 #pragma unroll
@@ -264,15 +253,10 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
             }
-            if (issued < steps) {  // refill the stage just consumed (uniform): every wave must be done reading it
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                stage(buf, issued * 64);
-                ++issued;
-            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            buf ^= 1;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();  // all fragment reads done before the epilogue reuses the LDS
     }
     // epilogue: bf16 through LDS (pitch 272 B), then 16 bytes per lane into the k-tile-major gradient buffer
     constexpr int OP = 272;

@@ -34,7 +34,8 @@ from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
 from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
-EIGH_STREAMS = 4  # concurrent eigenproblems (HIP streams / host threads) per rank
+EIGH_STREAMS = 8  # concurrent eigenproblems (HIP streams / host threads) per rank: the in-LDS solve of a round is latency
+                  # bound on a few dozen CUs, the other problems' streaming kernels fill the rest of the chip meanwhile
 
 
 def eigendecomposition_save_path(output_dir: Path, factor_name: str) -> Path:

@@ -94,6 +94,9 @@ class TrackedModule(nn.Module):
         self.queries_in_eigenbasis: bool = False
         # > 0 while the held preconditioned query gradients carry that many trailing zero columns (bf16 engine, odd I')
         self.query_padding: int = 0
+        # how many query gradients the score stage is about to hold in this module (None: unknown) -- lets the
+        # PreconditionTracker make one allocation per layer (QueryBuffer)
+        self.query_capacity: Optional[int] = None
         self.storage: Dict[str, Any] = {}
         for key in (COVARIANCE_FACTOR_NAMES + EIGENDECOMPOSITION_FACTOR_NAMES + LAMBDA_FACTOR_NAMES
                     + [AGGREGATED_GRADIENT_NAME, PRECONDITIONED_GRADIENT_NAME,

@@ -43,6 +43,32 @@ class QueryBlocks:
         return self.blocks[0] if len(self.blocks) == 1 else torch.cat(self.blocks, dim=0)
 
 
+class QueryBuffer(QueryBlocks):
+    """``QueryBlocks`` over ONE preallocated ``[capacity, O, I']`` buffer that the query batches are copied into: the stage
+    loop knows how many queries it is going to hold (``TrackedModule.query_capacity``), so each layer makes a single
+    allocation instead of one per batch -- at BERT / GPT-2 scale (150-175 GB of query gradients, 32 batches x 48 layers)
+    the per-batch blocks fragmented the caching allocator into an out-of-memory with 100 GB "reserved but unallocated"."""
+
+    def __init__(self, first: torch.Tensor, capacity: int) -> None:
+        self.buffer = torch.empty((capacity,) + tuple(first.shape[1:]), dtype=first.dtype, device=first.device)
+        self.filled = 0
+        self.overflow = []
+        self.append(first)
+
+    def append(self, block: torch.Tensor) -> "QueryBuffer":
+        q = block.shape[0]
+        if not self.overflow and self.filled + q <= self.buffer.shape[0]:
+            self.buffer[self.filled:self.filled + q].copy_(block)
+            self.filled += q
+        else:  # more queries than announced: keep them as extra blocks
+            self.overflow.append(block.contiguous())
+        return self
+
+    @property
+    def blocks(self):
+        return [self.buffer[:self.filled]] + self.overflow
+
+
 def _remove_all(handles: List[RemovableHandle]) -> List[RemovableHandle]:
     for handle in reversed(handles):
         handle.remove()

@@ -15,7 +15,7 @@ from torch import nn
 
 from kronfluence_amd import ops
 from kronfluence_amd.factor.config import FactorConfig
-from kronfluence_amd.module.tracker.base import BaseTracker, QueryBlocks
+from kronfluence_amd.module.tracker.base import BaseTracker, QueryBlocks, QueryBuffer
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
     AGGREGATED_GRADIENT_NAME,
@@ -195,9 +195,12 @@ class PreconditionTracker(BaseTracker):
             storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
                 [t.contiguous() for t in new] if held is None
                 else [torch.cat((h, t), dim=0).contiguous() for h, t in zip(held, new)])
-        else:  # dense blocks are collected, not concatenated (see QueryBlocks)
+        elif held is None:  # dense blocks are collected, not concatenated (see QueryBlocks / QueryBuffer)
+            capacity = self.module.query_capacity
             storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
-                QueryBlocks([new.contiguous()]) if held is None else held.append(new.contiguous()))
+                QueryBuffer(new, capacity) if capacity and capacity >= new.shape[0] else QueryBlocks([new.contiguous()]))
+        else:
+            held.append(new.contiguous())
         storage[PRECONDITIONED_GRADIENT_NAME] = None
 
     @torch.no_grad()

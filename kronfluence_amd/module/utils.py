@@ -202,6 +202,12 @@ def synchronize_factors(model: nn.Module, factor_names: List[str], tracked_modul
     reduce_bucket(ints, torch.int64)
 
 
+def set_query_capacity(model: nn.Module, tracked_module_names: Optional[List[str]], capacity: Optional[int]) -> None:
+    """Announces how many preconditioned query gradients the modules are about to accumulate (``QueryBuffer``)."""
+    for m in _tracked(model, tracked_module_names):
+        m.query_capacity = capacity
+
+
 def truncate(model: nn.Module, tracked_module_names: List[str], keep_size: int) -> None:
     for m in _tracked(model, tracked_module_names):
         m.truncate(keep_size=keep_size)

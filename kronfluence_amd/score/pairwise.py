@@ -16,7 +16,8 @@ from kronfluence_amd.factor.covariance import _loss_scale
 from kronfluence_amd.module.tracked_module import ModuleMode
 from kronfluence_amd.module.utils import (
     accumulate_iterations, finalize_all_iterations, finalize_iteration, get_tracked_module_names, prepare_modules,
-    set_factors, set_gradient_scale, set_mode, synchronize_modules, truncate, update_factor_args, update_score_args,
+    set_factors, set_gradient_scale, set_mode, set_query_capacity, synchronize_modules, truncate, update_factor_args,
+    update_score_args,
 )
 from kronfluence_amd.score.dot_product import (
     compute_aggregated_dot_products_with_loader, compute_dot_products_with_loader,
@@ -75,6 +76,9 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
         set_gradient_scale(model, 1.0 / scale)
 
     held = 0
+    remaining = len(query_loader.dataset)  # queries still to be preconditioned (each rank ends up holding all of them)
+    window = score_args.query_gradient_accumulation_steps * total_query_batch_size
+    set_query_capacity(model, tracked_module_names, min(window, remaining))
     for query_index, query_batch in enumerate(query_loader):
         query_batch = send_to_device(query_batch, state.device)
         with no_sync(model, state):
@@ -103,12 +107,15 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
         del scores
         state.wait_for_everyone()
         held = 0
+        remaining -= window
+        set_query_capacity(model, tracked_module_names, min(window, max(remaining, 0)))
 
     total: SCORE_TYPE = {}
     if state.is_main_process:
         total = {key: torch.cat(parts, dim=0) for key, parts in chunks.items()}
     model.zero_grad(set_to_none=True)
     set_gradient_scale(model, 1.0)
+    set_query_capacity(model, tracked_module_names, None)
     finalize_all_iterations(model, tracked_module_names)
     set_mode(model, ModuleMode.DEFAULT, release_memory=True)
     state.wait_for_everyone()

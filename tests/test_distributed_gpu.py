@@ -1,8 +1,8 @@
-"""Two ranks (sharing the one GPU of the test box, gloo transport) run the complete sharded pipeline --
-strided factor-fit shards + bucketed all-reduce, round-robin eigendecomposition + broadcast, strided
-query shards + all-gather/interleave/truncate, contiguous train chunks + score-block gather -- and
-must reproduce the single-process factors and scores.  On the 8-GPU node the same
-code path runs over RCCL (backend "nccl")."""
+"""Two ranks run the complete sharded pipeline -- strided factor-fit shards + bucketed all-reduce (every rank keeps the
+sums in HBM: no pickled hand-off), round-robin eigendecomposition + tensor broadcasts, strided query shards +
+all-gather/interleave/truncate, contiguous train chunks + score-block gather -- and must reproduce the single-process
+factors and scores.  Once with both ranks sharing the one GPU of the test box over gloo, and -- when
+at least two GPUs are visible -- one rank per GPU over RCCL (backend "nccl"), the configuration bench.py --gpus N runs."""
 
 import os
 import socket
@@ -53,28 +53,28 @@ def _pipeline(world, rank, out_path):
     def shard(sampler_cls, n):
         return list(sampler_cls(range(n), world, rank)) if world > 1 else None
 
-    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 8, shard(DistributedEvalSampler, N_TRAIN)), fargs)
-    if world > 1:
-        box = [cov]
-        dist.broadcast_object_list(box, src=0)
-        cov = box[0]
-    eig = perform_eigendecomposition(cov, model, state, fargs)
-    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 8, shard(DistributedEvalSampler, N_TRAIN)), fargs, eig)
-    if world > 1:
-        box = [lam]
-        dist.broadcast_object_list(box, src=0)
-        lam = box[0]
+    # every rank receives the all-reduced factors, device resident (what bench.py does for N > 1)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 8, shard(DistributedEvalSampler, N_TRAIN)), fargs,
+                                                 all_ranks=True, cpu=False)
+    assert all(t.is_cuda for t in cov["activation_covariance"].values())
+    eig = perform_eigendecomposition(cov, model, state, fargs, cpu=False)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 8, shard(DistributedEvalSampler, N_TRAIN)), fargs, eig,
+                                             all_ranks=True, cpu=False)
     q_idx = list(DistributedSampler(range(N_QUERY), world, rank, shuffle=False, drop_last=False)) if world > 1 else None
     scores = compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query, 2, q_idx), 2,
                                                   ResidentLoader(train, 10, shard(DistributedSamplerWithStack, N_TRAIN)),
                                                   sargs, fargs, None)
+    cpu = lambda d: {k: {n: v.cpu() for n, v in m.items()} for k, m in d.items()}  # noqa: E731
     if rank == 0:
-        torch.save({"cov": cov, "lam": lam, "scores": scores["all_modules"]}, out_path)
+        torch.save({"cov": cpu(cov), "lam": cpu(lam), "scores": scores["all_modules"]}, out_path)
+    elif world > 1:  # the other rank holds the same sums
+        torch.save({"cov": cpu(cov), "lam": cpu(lam)}, out_path + f".rank{rank}")
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, backend="gloo"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
-                      LOCAL_RANK=str(rank), KF_DIST_BACKEND="gloo")
+                      LOCAL_RANK=str(rank if backend == "nccl" else 0), KF_DIST_BACKEND=backend,
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
 
     try:
@@ -88,14 +88,21 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
-def test_two_rank_pipeline_matches_single_process(tmp_path):
+@pytest.mark.parametrize("backend", ["gloo", "nccl"])
+def test_two_rank_pipeline_matches_single_process(tmp_path, backend):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("RCCL variant needs two visible GPUs (the 1-GPU test box runs the gloo variant)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     single, double = str(tmp_path / "w1.pt"), str(tmp_path / "w2.pt")
-    mp.spawn(_worker, args=(1, port, single), nprocs=1, join=True)
-    mp.spawn(_worker, args=(2, port + 1, double), nprocs=2, join=True)
+    mp.spawn(_worker, args=(1, port, single, backend), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, port + 1, double, backend), nprocs=2, join=True)
     one, two = torch.load(single), torch.load(double)
+    other = torch.load(double + ".rank1")
+    for name, per_module in two["cov"].items():  # rank 1 received the same all-reduced factors as rank 0
+        for module, tensor in per_module.items():
+            assert torch.equal(other["cov"][name][module], tensor), (name, module)
     assert two["scores"].shape == (N_QUERY, N_TRAIN)
     for name in ("activation_covariance", "gradient_covariance"):
         for module, want in one["cov"][name].items():

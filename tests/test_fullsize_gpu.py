@@ -158,8 +158,11 @@ def test_resnet9_full_size_pairwise_stage():
       bf16 forward / backward, and the oracle's per-sample gradient (module/conv2d.py:164-177), EK-FAC preconditioner
       (factor/config.py:341-353) and score einsum (conv2d.py:199-209) are evaluated on them in fp64 with the product's own
       eigenvectors and Lambda -- everything downstream of the hooks (im2col / implicit im2col, rotations, bf16 P, score
-      GEMMs) is compared, nothing upstream can differ.  Bound 2e-2 (three bf16 roundings: P, the per-sample gradient and the
-      rotated intermediates, each 2^-9 relative)."""
+      GEMMs) is compared, nothing upstream can differ.  The oracle is given the SAME bf16-rounded eigenvectors the bf16
+      preconditioner uses (reference: ``Ekfac.prepare`` casts them to ``precondition_dtype``, factor/config.py:323-328), so the
+      difference is the kernels' own arithmetic: bf16 storage of the five intermediate products of the preconditioner, of P
+      and of the per-sample gradients (2^-9 relative each, through contractions of 1e3 - 1e5 terms).  Bound 2e-2; with
+      exact fp32 eigenvectors in the oracle (i.e. charging the cast to the engine as well) 5e-2."""
     import bench
     import torch.nn.functional as F
     from torch import nn
@@ -214,7 +217,7 @@ def test_resnet9_full_size_pairwise_stage():
             def fwd(mod, inputs, output, name=m.name):
                 held[name] = [inputs[0].detach().double().cpu(), None]
                 output.register_hook(lambda grad, name=name: held[name].__setitem__(1, grad.detach().double().cpu()))
-            handles.append(m.original_module.register_forward_hook(fwd))
+            handles.append(m.register_forward_hook(fwd))  # the wrapper's output carries the gradient (frozen weights)
         model.zero_grad(set_to_none=True)
         with torch.autocast("cuda", dtype=torch.bfloat16):
             loss = task.compute_train_loss(batch, model, sample=False)
@@ -229,10 +232,13 @@ def test_resnet9_full_size_pairwise_stage():
     # the bf16 model passes on these 64 / 256 samples (same kernels the stage just ran: same batch shapes)
     held_q, held_t = capture(sub_q), capture(sub_t)
     want = {None: torch.zeros(nq, nt, dtype=torch.float64), 1e-8: torch.zeros(nq, nt, dtype=torch.float64)}
+    exact = torch.zeros(nq, nt, dtype=torch.float64)
     for m in tracked:
         mod = m.original_module
-        q_a = eig["activation_eigenvectors"][m.name].double().cpu()
-        q_g = eig["gradient_eigenvectors"][m.name].double().cpu()
+        q_a32 = eig["activation_eigenvectors"][m.name].double().cpu()
+        q_g32 = eig["gradient_eigenvectors"][m.name].double().cpu()
+        q_a = eig["activation_eigenvectors"][m.name].to(torch.bfloat16).double().cpu()
+        q_g = eig["gradient_eigenvectors"][m.name].to(torch.bfloat16).double().cpu()
         lam_m, n_lam = lam["lambda_matrix"][m.name].double().cpu(), lam["num_lambda_processed"][m.name].cpu()
         (aq, gq), (at, gt) = held_q[m.name], held_t[m.name]
         if isinstance(mod, nn.Conv2d):
@@ -245,9 +251,14 @@ def test_resnet9_full_size_pairwise_stage():
                 want[damping] += ref.conv_pairwise_score(p, at, gt, mod)
             else:
                 want[damping] += ref.linear_pairwise_score(p, at, gt, mod.bias is not None)
+        p = ref.ekfac_precondition(psg_q, q_a32, q_g32, ref.ekfac_inverse_lambda(lam_m, n_lam, None, torch.float64))
+        exact += (ref.conv_pairwise_score(p, at, gt, mod) if isinstance(mod, nn.Conv2d)
+                  else ref.linear_pairwise_score(p, at, gt, mod.bias is not None))
     errs = {d: rel(got[d], want[d]) for d in want}
-    assert errs[None] <= 2e-2, errs
-    assert errs[1e-8] <= 5e-2, errs   # Lambda^-1 spans eight decades at the default damping: bf16 cancellation is larger
+    errs["exact eigenvectors"] = rel(got[None], exact)
+    print("stage-isolated 64 x 256 sub-block, rel_F vs fp64 oracle:", errs)
+    assert errs[None] <= 2e-2 and errs[1e-8] <= 2e-2, errs
+    assert errs["exact eigenvectors"] <= 5e-2, errs
     # the same sub-block inside the full run (other batch shapes -> other MIOpen kernels): ranking agreement
     x, y = full[:nq, :nt].double().cpu().flatten(), want[1e-8].flatten()
     x, y = x - x.mean(), y - y.mean()

@@ -352,9 +352,9 @@ def test_shared_parameters_factors_match_reference_and_scores_match_autograd(tmp
 
 
 def test_bf16_conv_with_odd_patch_axis_is_padded_not_demoted(tmp_path):
-    """A first conv layer with 3*3*3 = 27 patch columns under bf16 autocast: the tracker zero-pads that axis to 32 on
-    both sides of the contraction so the bf16 MFMA engine applies; the scores must equal the un-padded (fp32-engine
-    fallback) evaluation of the same bf16 data."""
+    """A first conv layer with 3 input channels (3*3*3 = 27 patch columns) under bf16 autocast stays on the bf16 MFMA
+    kernels: on the implicit-im2col path its channels are zero-padded to 8 (72 patch columns), on the patch path the patch
+    axis is zero-padded to 32; both must equal the un-padded fp32-engine evaluation of the same bf16 data."""
     from torch import nn
 
     from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
@@ -373,24 +373,34 @@ def test_bf16_conv_with_odd_patch_axis_is_padded_not_demoted(tmp_path):
                              factor_args=FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16))
     kw = dict(per_device_query_batch_size=spec.query_batch, per_device_train_batch_size=spec.train_batch)
     args = ScoreArguments(damping_factor=None, amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16)
-    calls = []
-    original = PairwiseScoreTracker._fast_layout
+    v2_calls, pad_calls = [], []
+    original_v2, original_layout = PairwiseScoreTracker._score_v2, PairwiseScoreTracker._fast_layout
 
-    def spy(self, preconditioned, g, a, ones):
-        out = original(self, preconditioned, g, a, ones)
-        calls.append((a.shape[-1] + int(ones), None if out is None else out[1].shape[-1]))
+    def spy_v2(self, preconditioned, activation, output_gradient, scores, offset):
+        taken = original_v2(self, preconditioned, activation, output_gradient, scores, offset)
+        v2_calls.append((tuple(activation.shape[1:]), taken))
+        return taken
+
+    def spy_layout(self, preconditioned, g, a, ones):
+        out = original_layout(self, preconditioned, g, a, ones)
+        pad_calls.append((a.shape[-1] + int(ones), None if out is None else out[1].shape[-1]))
         return out
 
-    PairwiseScoreTracker._fast_layout = spy
+    PairwiseScoreTracker._score_v2, PairwiseScoreTracker._fast_layout = spy_v2, spy_layout
     try:
+        implicit = analyzer.compute_pairwise_scores("v2", "f", query, train, score_args=args, **kw)["all_modules"]
+        assert ((3, 8, 8), True) in v2_calls, v2_calls          # first layer: implicit im2col, channels 3 -> 8
+        PairwiseScoreTracker.SCORE_V2 = False
         padded = analyzer.compute_pairwise_scores("pad", "f", query, train, score_args=args, **kw)["all_modules"]
-        assert (27, 32) in calls, calls
+        assert (27, 32) in pad_calls, pad_calls                 # patch path: 27 -> 32 columns
         PairwiseScoreTracker.PAD_PATCH_AXIS = False
         plain = analyzer.compute_pairwise_scores("nopad", "f", query, train, score_args=args, **kw)["all_modules"]
     finally:
         PairwiseScoreTracker.PAD_PATCH_AXIS = True
-        PairwiseScoreTracker._fast_layout = original
+        PairwiseScoreTracker.SCORE_V2 = True
+        PairwiseScoreTracker._score_v2, PairwiseScoreTracker._fast_layout = original_v2, original_layout
     assert rel(padded, plain) <= 2e-3, rel(padded, plain)
+    assert rel(implicit, plain) <= 2e-3, rel(implicit, plain)
 
 
 

@@ -4,7 +4,10 @@ import sys, os, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path
 import torch
 from kronfluence_amd import ops
 dev = "cuda:0"
-for d, n in [(300, 150), (769, 4000), (1025, 4000), (1152, 800), (2304, 5000), (3073, 6000), (4096, 8000)]:
+sizes = [(300, 150), (769, 4000), (1025, 4000), (1152, 800), (2304, 5000), (3073, 6000), (4096, 8000)]
+if len(sys.argv) > 1:
+    sizes = [(d, n) for d, n in sizes if str(d) in sys.argv[1:]]
+for d, n in sizes:
     g = torch.Generator().manual_seed(d)
     x = torch.randn(n, d, generator=g) * torch.logspace(0, -3, d)
     cov = (x.t() @ x).to(dev)

@@ -1,0 +1,76 @@
+"""Summarises ``rocprofv3 --pmc`` passes of a bench command into ``profiles/r02_pmc_<workload>.json`` (read back by
+bench.py for ``roofline.traffic`` / ``roofline.mfma_util``).
+
+    python tools/pmc_summary.py <workload> <out.json> <pass_dir> [<pass_dir> ...]
+
+Every pass directory holds one ``*_counter_collection.csv`` (one row per dispatch and counter).  Counters used:
+
+  FETCH_SIZE / WRITE_SIZE   KiB moved over the L2's memory-side interface per dispatch (separate passes: FETCH_SIZE takes 3 of
+                            the 4 TCC slots).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports HALF the bytes of a wide
+                            coalesced read stream -> the read side is DOUBLED here; WRITE_SIZE is taken as reported.
+  SQ_VALU_MFMA_BUSY_CYCLES  cycles the matrix pipes were busy, summed over SIMDs (32 per v_mfma_f32_32x32x16_bf16)
+  GRBM_GUI_ACTIVE           cycles the dispatch was active   ->  mfma_util = busy / (active * 256 CUs * 4 SIMDs)
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+SCORE_KERNELS = ("score_gemm_v2_kernel", "psg_gemm_v2_kernel", "conv_pad_phases_kernel", "pad_grid_kernel", "transpose_rows_kernel",
+                 "score_r1_kernel")
+
+
+def short(name: str) -> str:
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
+    return name.split("(")[0].strip()
+
+
+def main() -> None:
+    workload, out_path, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    values = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> per-dispatch values
+    for d in dirs:
+        for path in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+            with open(path, newline="") as handle:
+                for row in csv.DictReader(handle):
+                    values[short(row["Kernel_Name"])][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    kernels = {}
+    for name, counters in sorted(values.items()):
+        entry = {"launches": max(len(v) for v in counters.values())}
+        mean = {c: sum(v) / len(v) for c, v in counters.items()}
+        if "FETCH_SIZE" in mean:
+            entry["FETCH_SIZE_KiB"] = mean["FETCH_SIZE"]
+            entry["hbm_read_bytes"] = 2.0 * mean["FETCH_SIZE"] * 1024.0  # gfx950 correction
+        if "WRITE_SIZE" in mean:
+            entry["WRITE_SIZE_KiB"] = mean["WRITE_SIZE"]
+            entry["hbm_write_bytes"] = mean["WRITE_SIZE"] * 1024.0
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACTIVE"] > 0:
+            entry["mfma_busy_cycles"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"]
+            entry["gui_active_cycles"] = mean["GRBM_GUI_ACTIVE"]
+            entry["mfma_util"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] * 256 * 4)
+        kernels[name] = entry
+    # one kf_pairwise_score* call = its pad / transpose / gradient kernels + one score GEMM (or one score_r1 launch)
+    calls = sum(e["launches"] for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel") or n.startswith("score_r1_kernel"))
+    total = sum(e["launches"] * (e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0))
+                for n, e in kernels.items() if n.startswith(SCORE_KERNELS))
+    dominant = max((e for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel")), key=lambda e: e["launches"], default=None)
+    summary = {
+        "workload": workload,
+        "source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes) on the bench "
+                  "command; FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md, HBM); summary by tools/pmc_summary.py",
+        "kf_pairwise_score_bytes_per_launch": total / calls if calls else None,
+        "kf_pairwise_score_calls_profiled": calls,
+        "mfma_util": dominant.get("mfma_util") if dominant else None,
+        "kernels": {n: e for n, e in kernels.items() if n.startswith(SCORE_KERNELS) or "gemm_bf16" in n or "syrk" in n or "lambda" in n
+                    or "im2col" in n or "eigh" in n or "jacobi" in n},
+    }
+    with open(out_path, "w", encoding="utf-8") as handle:
+        json.dump(summary, handle, indent=1)
+    print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}, indent=1))
+    for n, e in summary["kernels"].items():
+        print(f"  {n[:70]:70s} {e}")
+
+
+if __name__ == "__main__":
+    main()
