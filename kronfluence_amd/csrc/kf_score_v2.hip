@@ -99,14 +99,23 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
         off_b[t] = min(n0 + row, a.N - 1) * 64 + ((lane & 7) ^ lds_swz(row)) * 8;
     }
     const int64_t a_kt = static_cast<int64_t>(a.M) * 64, b_kt = static_cast<int64_t>(a.N) * 64;
-    auto stage = [&](int buf, int kt) {
+    // part `part` (0..3) of the DMA requests of one stage: 1/4 of this wave's row groups of A and of B.  The requests of
+    // the NEXT k-step are spread over the four MFMA groups of the current one -- issuing all of them up front keeps every
+    // wave of the CU in its (50-150 cycles per request) issue phase at the same time, with the matrix pipes idle.
+    auto stage_part = [&](int buf, int kt, int part) {
         const uint16_t* ap = a.A + kt * a_kt;
         const uint16_t* bp = a.B + kt * b_kt;
         unsigned char* base = sm + buf * STAGE_BYTES;
 #pragma unroll
-        for (int t = 0; t < GA; ++t) glds16(ap + off_a[t], base + (wave * GA + t) * 1024);
+        for (int t = 0; t < GA; ++t)
+            if (t * 4 / GA == part || (GA < 4 && t == part)) glds16(ap + off_a[t], base + (wave * GA + t) * 1024);
 #pragma unroll
-        for (int t = 0; t < GB; ++t) glds16(bp + off_b[t], base + A_BYTES + (wave * GB + t) * 1024);
+        for (int t = 0; t < GB; ++t)
+            if (t * 4 / GB == part || (GB < 4 && t == part)) glds16(bp + off_b[t], base + A_BYTES + (wave * GB + t) * 1024);
+    };
+    auto stage = [&](int buf, int kt) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) stage_part(buf, kt, part);
     };
 
     f32x16 acc[MI][NI];
@@ -124,11 +133,12 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
         __syncthreads();
         int buf = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end) stage(buf ^ 1, kt + 1);
+            const bool more = kt + 1 < kt_end;
             const unsigned char* sa = sm + buf * STAGE_BYTES + (wm * (MI * 32) + lr) * 128;
             const unsigned char* sb = sm + buf * STAGE_BYTES + A_BYTES + (wn * (NI * 32) + lr) * 128;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
+                if (more) stage_part(buf ^ 1, kt + 1, kk);
                 const int co = ((kk * 2 + hi) ^ sw) * 16;
                 bf16x8 bv[NI];
 #pragma unroll

@@ -211,55 +211,47 @@ def test_resnet9_full_size_pairwise_stage():
     sub_q, sub_t = tuple(v[:nq] for v in query), tuple(v[:nt] for v in train)
     tracked = [m for m in model.modules() if isinstance(m, TrackedModule)]
 
-    def capture(batch):
+    def run_and_capture(damping):
+        """One pairwise stage on the sub-block with capture hooks riding along: the tensors recorded are the very objects
+        the trackers consume in that pass (a second forward / backward could pick other MIOpen kernels and differ by a
+        bf16 rounding, which is the size of the effect being measured)."""
         held, handles = {}, []
         for m in tracked:
             def fwd(mod, inputs, output, name=m.name):
-                held[name] = [inputs[0].detach().double().cpu(), None]
-                output.register_hook(lambda grad, name=name: held[name].__setitem__(1, grad.detach().double().cpu()))
-            handles.append(m.register_forward_hook(fwd))  # the wrapper's output carries the gradient (frozen weights)
-        model.zero_grad(set_to_none=True)
-        with torch.autocast("cuda", dtype=torch.bfloat16):
-            loss = task.compute_train_loss(batch, model, sample=False)
-        loss.backward()
-        for h in handles:
-            h.remove()
-        return held
+                key = (name, inputs[0].shape[0])  # 64 = the query batch, 256 = the train batch
+                held[key] = [inputs[0].detach().double().cpu(), None]
+                output.register_hook(lambda grad, key=key: held[key].__setitem__(1, grad.detach().double().cpu()))
+            handles.append(m.register_forward_hook(fwd))
+        try:
+            scores = run(nq, nt, 1, damping=damping, q=sub_q, t=sub_t).double().cpu()
+        finally:
+            for h in handles:
+                h.remove()
+        return scores, held
 
-    got = {}
+    errs = {}
     for damping in (None, 1e-8):
-        got[damping] = run(nq, nt, 1, damping=damping, q=sub_q, t=sub_t).double().cpu()
-    # the bf16 model passes on these 64 / 256 samples (same kernels the stage just ran: same batch shapes)
-    held_q, held_t = capture(sub_q), capture(sub_t)
-    want = {None: torch.zeros(nq, nt, dtype=torch.float64), 1e-8: torch.zeros(nq, nt, dtype=torch.float64)}
-    exact = torch.zeros(nq, nt, dtype=torch.float64)
-    for m in tracked:
-        mod = m.original_module
-        q_a32 = eig["activation_eigenvectors"][m.name].double().cpu()
-        q_g32 = eig["gradient_eigenvectors"][m.name].double().cpu()
-        q_a = eig["activation_eigenvectors"][m.name].to(torch.bfloat16).double().cpu()
-        q_g = eig["gradient_eigenvectors"][m.name].to(torch.bfloat16).double().cpu()
-        lam_m, n_lam = lam["lambda_matrix"][m.name].double().cpu(), lam["num_lambda_processed"][m.name].cpu()
-        (aq, gq), (at, gt) = held_q[m.name], held_t[m.name]
-        if isinstance(mod, nn.Conv2d):
-            psg_q = ref.conv_per_sample_gradient(aq, gq, mod)
-        else:
-            psg_q = ref.linear_per_sample_gradient(aq, gq, mod.bias is not None)
-        for damping in want:
-            p = ref.ekfac_precondition(psg_q, q_a, q_g, ref.ekfac_inverse_lambda(lam_m, n_lam, damping, torch.float64))
-            if isinstance(mod, nn.Conv2d):
-                want[damping] += ref.conv_pairwise_score(p, at, gt, mod)
-            else:
-                want[damping] += ref.linear_pairwise_score(p, at, gt, mod.bias is not None)
-        p = ref.ekfac_precondition(psg_q, q_a32, q_g32, ref.ekfac_inverse_lambda(lam_m, n_lam, None, torch.float64))
-        exact += (ref.conv_pairwise_score(p, at, gt, mod) if isinstance(mod, nn.Conv2d)
-                  else ref.linear_pairwise_score(p, at, gt, mod.bias is not None))
-    errs = {d: rel(got[d], want[d]) for d in want}
-    errs["exact eigenvectors"] = rel(got[None], exact)
-    print("stage-isolated 64 x 256 sub-block, rel_F vs fp64 oracle:", errs)
-    assert errs[None] <= 2e-2 and errs[1e-8] <= 2e-2, errs
-    assert errs["exact eigenvectors"] <= 5e-2, errs
+        got, held = run_and_capture(damping)
+        want, exact = torch.zeros(nq, nt, dtype=torch.float64), torch.zeros(nq, nt, dtype=torch.float64)
+        for m in tracked:
+            mod = m.original_module
+            conv = isinstance(mod, nn.Conv2d)
+            q_a32 = eig["activation_eigenvectors"][m.name].double().cpu()
+            q_g32 = eig["gradient_eigenvectors"][m.name].double().cpu()
+            q_a = eig["activation_eigenvectors"][m.name].to(torch.bfloat16).double().cpu()
+            q_g = eig["gradient_eigenvectors"][m.name].to(torch.bfloat16).double().cpu()
+            lam_m, n_lam = lam["lambda_matrix"][m.name].double().cpu(), lam["num_lambda_processed"][m.name].cpu()
+            (aq, gq), (at, gt) = held[(m.name, nq)], held[(m.name, nt)]
+            psg_q = ref.conv_per_sample_gradient(aq, gq, mod) if conv else ref.linear_per_sample_gradient(aq, gq, mod.bias is not None)
+            lam_inv = ref.ekfac_inverse_lambda(lam_m, n_lam, damping, torch.float64)
+            for target, (va, vg) in ((want, (q_a, q_g)), (exact, (q_a32, q_g32))):
+                p = ref.ekfac_precondition(psg_q, va, vg, lam_inv)
+                target += ref.conv_pairwise_score(p, at, gt, mod) if conv else ref.linear_pairwise_score(p, at, gt, mod.bias is not None)
+        errs[damping] = (rel(got, want), rel(got, exact))
+    print("stage-isolated 64 x 256 sub-block, rel_F vs fp64 oracle (bf16-rounded / exact eigenvectors):", errs)
+    for damping, (same, charged) in errs.items():
+        assert same <= 2e-2 and charged <= 5e-2, errs
     # the same sub-block inside the full run (other batch shapes -> other MIOpen kernels): ranking agreement
-    x, y = full[:nq, :nt].double().cpu().flatten(), want[1e-8].flatten()
+    x, y = full[:nq, :nt].double().cpu().flatten(), want.flatten()
     x, y = x - x.mean(), y - y.mean()
     assert float((x @ y) / (x.norm() * y.norm())) >= 0.97

@@ -26,9 +26,9 @@ def rel(a, b):
 
 
 class SeqLayer(nn.Module):
-    def __init__(self, i: int, o: int) -> None:
+    def __init__(self, i: int, o: int, bias: bool = True) -> None:
         super().__init__()
-        self.lin = nn.Linear(i, o)
+        self.lin = nn.Linear(i, o, bias=bias)
 
     def forward(self, x):
         return self.lin(torch.tanh(x))
@@ -63,16 +63,19 @@ def chunks(data, size):
     return [tuple(t[k:k + size] for t in data) for k in range(0, data[0].shape[0], size)]
 
 
-SHAPES = [  # (O, I, T, n_train): rows = n_train * T real tokens exceed I' so the activation covariance has full rank
-    pytest.param(768, 768, 128, 16, id="bert-768x769"),
-    pytest.param(3072, 768, 128, 16, id="bert-3072x769"),
-    pytest.param(768, 3072, 128, 48, id="bert-768x3073"),
-    pytest.param(2304, 768, 512, 4, id="gpt2-2304x769-T512"),
+SHAPES = [  # (O, I, T, n_train, bias): rows = n_train * T real tokens exceed I' so the activation covariance has full rank
+    pytest.param(768, 768, 128, 16, True, id="bert-768x769"),
+    pytest.param(3072, 768, 128, 16, True, id="bert-3072x769"),
+    pytest.param(768, 3072, 128, 48, True, id="bert-768x3073"),
+    pytest.param(2304, 768, 512, 4, True, id="gpt2-2304x769-T512"),
+    # Llama-3-8B MLP projections (14336 x 4096 / 4096 x 14336, no bias, T = 512) at 1/8 width: the C5 parity slice
+    pytest.param(1792, 512, 512, 3, False, id="llama-up-1/8-width"),
+    pytest.param(512, 1792, 512, 5, False, id="llama-down-1/8-width"),
 ]
 
 
-@pytest.mark.parametrize("o,i,t,n_train", SHAPES)
-def test_layer_shape_stages_match_oracle(o, i, t, n_train):
+@pytest.mark.parametrize("o,i,t,n_train,bias", SHAPES)
+def test_layer_shape_stages_match_oracle(o, i, t, n_train, bias):
     from kronfluence_amd import FactorArguments, ScoreArguments, Task, prepare_model
     from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
     from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader
@@ -91,7 +94,7 @@ def test_layer_shape_stages_match_oracle(o, i, t, n_train):
             return batch[1]
 
     torch.manual_seed(0)
-    raw, twin = SeqLayer(i, o), SeqLayer(i, o)
+    raw, twin = SeqLayer(i, o, bias), SeqLayer(i, o, bias)
     twin.load_state_dict(raw.state_dict())
     n_query, fb, tb = 3, max(1, n_train // 2), max(1, n_train // 2)
     train, query = make_data(n_train, t, i, o, 1), make_data(n_query, t, i, o, 2)
@@ -116,7 +119,7 @@ def test_layer_shape_stages_match_oracle(o, i, t, n_train):
         assert rel(cov[name]["lin"], ocov[name]["lin"]) <= 2e-5, (name, rel(cov[name]["lin"], ocov[name]["lin"]))
     assert int(cov["num_activation_covariance_processed"]["lin"]) == tokens == int(ocov["num_activation_covariance_processed"]["lin"])
     assert int(cov["num_gradient_covariance_processed"]["lin"]) == tokens
-    assert cov["activation_covariance"]["lin"].shape == (i + 1, i + 1)
+    assert cov["activation_covariance"]["lin"].shape == (i + int(bias), i + int(bias))
 
     eig32 = {k: {n: v.float() for n, v in d.items()} for k, d in oeig.items()}
     _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train_d, fb), fargs, eig32)
