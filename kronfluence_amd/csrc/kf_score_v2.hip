@@ -191,12 +191,22 @@ constexpr int PV2_SMEM = 2 * PV2_STAGE_BYTES;
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    // Work order (per XCD a contiguous range of items): blocks of PSG_ZB consecutive samples; inside a block tile-major,
+    // sample-minor.  The workgroups running together on an XCD then cover a few samples x all their tiles -- the samples'
+    // inputs (G, the padded input copy: ~0.2 MB each) stay in that XCD's L2 across their tiles -- and the PSG_ZB samples of
+    // one tile write ADJACENT 128-byte pieces of the k-tile-major gradient buffer (element (n, d) sits at
+    // (d / 64) * b * 64 + n * 64 + d % 64), i.e. 1 KB runs instead of isolated lines 128 KB apart.
+    constexpr int PSG_ZB = 8;
     const int tiles = a.tiles_m * a.tiles_n;
-    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
+    const int64_t zblocks = (a.batch + PSG_ZB - 1) / PSG_ZB;
+    const int64_t items = zblocks * PSG_ZB * tiles, per_xcd = (items + 7) / 8;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;  // the tiles of one sample run back to back on one XCD
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
     if (j >= per_xcd || item >= items) return;
-    const int z = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int64_t zb = item / (static_cast<int64_t>(tiles) * PSG_ZB);
+    const int rem = static_cast<int>(item - zb * tiles * PSG_ZB);
+    const int tile = rem / PSG_ZB, z = static_cast<int>(zb) * PSG_ZB + rem % PSG_ZB;
+    if (z >= a.batch) return;
     const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
 
     // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is chunk_src
@@ -437,7 +447,7 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
 
 int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
     p.tiles_m = static_cast<int>(cdiv(p.M, 128)); p.tiles_n = static_cast<int>(cdiv(p.N, 128));
-    const int64_t blocks = 8 * cdiv(static_cast<int64_t>(p.batch) * p.tiles_m * p.tiles_n, 8);
+    const int64_t blocks = 8 * cdiv(cdiv(p.batch, 8) * 8 * p.tiles_m * p.tiles_n, 8);  // PSG_ZB = 8 samples per block
     if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
     hipLaunchKernelGGL(psg_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), PV2_SMEM, st, p);
     return launch_status();

@@ -1,13 +1,14 @@
 """GPU parity at the REAL layer shapes of the BERT-base and GPT-2-small configs (C3, C4):
 one tracked ``nn.Linear`` with bias on ``[b, T, d]`` activations -- (O, I') = (768, 769), (3072, 769), (768, 3073) at
 T = 128 with random-length padding masks (reference mask semantics: ``kronfluence/module/linear.py:30-54``), and
-(2304, 769) at T = 512 -- against the CPU oracle run in fp64 on the same seeded inputs.
+(2304, 769) at T = 512, plus the Llama-3-8B MLP projections at 1/8 width (no bias, T = 512) -- against the CPU oracle run in
+fp64 on the same seeded inputs.
 
 Every stage is compared on its own, so an error cannot hide behind (or be blamed on) an earlier stage:
   covariance   product stage vs oracle                                   rel_F <= 2e-5, counters exact
   Lambda       product stage fed the ORACLE's eigenvectors vs oracle     rel_F <= 2e-4 (fp32) / 5e-2 (bf16 lambda_dtype)
   scores       product stage fed the ORACLE's eigenvectors and Lambda    rel_F <= 1e-4 (fp32, heuristic damping)
-               (query preconditioning + train pass)                      rel_F <= 2e-2 (bf16 gradients / bf16 P)
+               (query preconditioning + train pass)                      rel_F <= 4e-2 (bf16 autocast model, bf16 gradients / P / scores)
 """
 
 import pytest
@@ -143,4 +144,6 @@ def test_layer_shape_stages_match_oracle(o, i, t, n_train, bias):
                            precondition_dtype=torch.bfloat16)
     got16 = compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query_d, n_query), n_query,
                                                  ResidentLoader(train_d, tb), sargs, low, None)["all_modules"]
-    assert rel(got16, want) <= 2e-2, rel(got16, want)
+    # bf16 end to end: autocast forward / backward (the hooked tensors themselves are bf16 roundings of the oracle's), bf16
+    # preconditioner intermediates, bf16 P and per-sample gradients, scores returned in bf16 (score_dtype, as the reference)
+    assert rel(got16, want) <= 4e-2, rel(got16, want)

@@ -8,8 +8,10 @@ Every pass directory holds one ``*_counter_collection.csv`` (one row per dispatc
   FETCH_SIZE / WRITE_SIZE   KiB moved over the L2's memory-side interface per dispatch (separate passes: FETCH_SIZE takes 3 of
                             the 4 TCC slots).  MI355X_MICROARCH.md (HBM): on gfx950 FETCH_SIZE reports HALF the bytes of a wide
                             coalesced read stream -> the read side is DOUBLED here; WRITE_SIZE is taken as reported.
-  SQ_VALU_MFMA_BUSY_CYCLES  cycles the matrix pipes were busy, summed over SIMDs (32 per v_mfma_f32_32x32x16_bf16)
-  GRBM_GUI_ACTIVE           cycles the dispatch was active   ->  mfma_util = busy / (active * 256 CUs * 4 SIMDs)
+  SQ_VALU_MFMA_BUSY_CYCLES  cycles the matrix pipes were busy, summed over the 1024 SIMDs (32 per v_mfma_f32_32x32x16_bf16:
+                            the count equals 32 x the kernel's MFMA instructions, checked against the algorithmic flops)
+  GRBM_GUI_ACTIVE           active cycles of the dispatch, SUMMED OVER THE 8 XCDs (each XCD has its own GRBM; the sum is 8x the
+                            kernel-trace duration times the clock)  ->  mfma_util = busy / (active / 8 * 1024 SIMDs)
 """
 import csv
 import glob
@@ -48,7 +50,7 @@ def main() -> None:
         if "SQ_VALU_MFMA_BUSY_CYCLES" in mean and "GRBM_GUI_ACTIVE" in mean and mean["GRBM_GUI_ACTIVE"] > 0:
             entry["mfma_busy_cycles"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"]
             entry["gui_active_cycles"] = mean["GRBM_GUI_ACTIVE"]
-            entry["mfma_util"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] * 256 * 4)
+            entry["mfma_util"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         kernels[name] = entry
     # one kf_pairwise_score* call = its pad / transpose / gradient kernels + one score GEMM (or one score_r1 launch)
     calls = sum(e["launches"] for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel") or n.startswith("score_r1_kernel"))
