@@ -147,8 +147,10 @@ int kf_gemm_bias_out(void* C, int64_t ldc, const kf_view* A, const kf_view* B, c
  * convention), both fp64; the host casts back to the covariance dtype (eigen.py:214-219).
  * cov is fp32 or fp64 [d,d]; count is a host value.  workspace: device, at least
  * kf_eigh_workspace_bytes(d) bytes.  max_sweeps <= 0 selects the default (100).
- * One-sided (Hestenes) Jacobi with a round-robin pair schedule; this call synchronises `stream`
- * once per sweep to read the convergence flag.
+ * One-sided (Hestenes) Jacobi.  d >= 256: pairs of 32-column blocks on the fp64 matrix cores (Gram matrix, in-LDS
+ * cyclic sweep, rotation applied with v_mfma_f64_16x16x4_f64); convergence -- a sweep without a rotation -- is decided
+ * on the device and the kernels of sweeps enqueued past it return at once; the call enqueues sweeps in batches (8, then
+ * 4) and synchronises `stream` once per batch to read three ints back.  d < 256: scalar rounds, one read-back per sweep.
  */
 int64_t kf_eigh_workspace_bytes(int64_t d);
 int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double* evals, double* evecs,

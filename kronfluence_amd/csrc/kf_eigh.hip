@@ -240,8 +240,10 @@ __device__ __forceinline__ int64_t pair_row(int r, int P, int Q, int nblocks, in
 
 // partial[pair][split][64][64] = sum over this split's i-range of Wp[a][i] Wp[b][i]
 __global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict__ Wt, double* __restrict__ partial, int64_t d,
-                                                        int nblocks, int players, int round, int gsplit, int64_t chunk) {
+                                                        int nblocks, int players, int round, int gsplit, int64_t chunk,
+                                                        const int* __restrict__ done) {
     __shared__ double tile[KP * GPITCH];
+    if (*done) return;  // converged in an earlier sweep of this batch of launches (device-side convergence flag)
     const int pair = blockIdx.x, split = blockIdx.y;
     int P, Q;
     pair_of_round(pair, round, players, P, Q);
@@ -293,8 +295,9 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict
 // exactly one rotation, so all of it is rewritten), the row pass writes back.
 __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restrict__ partial, double* __restrict__ Ubuf, int* __restrict__ pair_flag,
                                                          int gsplit, int cross, double tol, const double* __restrict__ frob2,
-                                                         double null_scale, int* rotated) {
+                                                         double null_scale, int* rotated, const int* __restrict__ done) {
     constexpr int LP = KP + 1;
+    if (*done) return;
     __shared__ double G[KP * LP];
     __shared__ double H[KP * LP];
     __shared__ double U[KP * LP];
@@ -385,8 +388,9 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
 // rows of the pair: new[j][i] = sum_c U[c][j] old[c][i], for W^T and V^T, over this workgroup's i-range
 __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ Wt, double* __restrict__ Vt, const double* __restrict__ Ubuf,
                                                           const int* __restrict__ pair_flag, int64_t d, int nblocks, int players, int round,
-                                                          int64_t chunk) {
+                                                          int64_t chunk, const int* __restrict__ done) {
     extern __shared__ double lds[];
+    if (*done) return;
     double* Ul = lds;                 // [64 c][UPITCH]  (j contiguous)
     double* Tl = lds + KP * UPITCH;   // [64 c][UPITCH]  (i contiguous)
     const int pair = blockIdx.x;
@@ -439,6 +443,14 @@ __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ W
             }
         }
     }
+}
+
+// End of a sweep, on the device: a sweep without a rotation is convergence.  state = {rotated, done, sweeps}.
+__global__ void eigh_sweep_end_kernel(int* state) {
+    if (state[1]) return;
+    state[2] += 1;
+    if (state[0] == 0) state[1] = 1;
+    state[0] = 0;
 }
 
 // out[0] += ||W||_F^2 over this block's slice (out zeroed by the caller)
@@ -677,24 +689,33 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
         double* partial = frob2_dev + 8;
         double* Ubuf = partial + static_cast<int64_t>(KP) * KP * p.pairs * p.gsplit;
         int* pair_flag = reinterpret_cast<int*>(Ubuf + static_cast<int64_t>(KP) * KP * p.pairs);
-        for (; sweeps < max_sweeps; ++sweeps) {
-            if (hipMemsetAsync(flag, 0, sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-            // pass -1: the column pairs inside every block (pairing of round 0); then the tournament of block pairs
-            for (int r = -1; r < p.players - 1; ++r) {
-                const int pairing = r < 0 ? 0 : r;
-                hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players, pairing,
-                                   p.gsplit, p.gchunk);
-                hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1, tol,
-                                   frob2_dev, null_scale, flag);
-                hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
-                                   p.nblocks, p.players, pairing, p.uchunk);
+        // Convergence is decided ON THE DEVICE (eigh_sweep_end_kernel); the host enqueues sweeps in batches and reads the
+        // state back once per batch -- the kernels of sweeps enqueued past convergence exit at their first instruction.
+        int* state = flag;  // {rotated, done, sweeps}: three of the 16 spare ints behind `rank`
+        if (hipMemsetAsync(state, 0, 3 * sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        const int* done = state + 1;
+        int enqueued = 0, host_state[3] = {0, 0, 0};
+        while (enqueued < max_sweeps && !host_state[1]) {
+            const int batch = enqueued < 8 ? 8 : 4;  // nothing converges in under 8 sweeps at these sizes
+            for (int b = 0; b < batch && enqueued < max_sweeps; ++b, ++enqueued) {
+                // pass -1: the column pairs inside every block (pairing of round 0); then the tournament of block pairs
+                for (int r = -1; r < p.players - 1; ++r) {
+                    const int pairing = r < 0 ? 0 : r;
+                    hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players,
+                                       pairing, p.gsplit, p.gchunk, done);
+                    hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1,
+                                       tol, frob2_dev, null_scale, state, done);
+                    hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
+                                       p.nblocks, p.players, pairing, p.uchunk, done);
+                }
+                hipLaunchKernelGGL(eigh_sweep_end_kernel, dim3(1), dim3(1), 0, st, state);
             }
-            int host_flag = 1;
-            if (hipMemcpyAsync(&host_flag, flag, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            if (hipMemcpyAsync(host_state, state, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
             if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-            if (verbose) fprintf(stderr, "[kf_eigh] d=%lld blocked sweep %d: %d pairs rotated\n", static_cast<long long>(d), sweeps, host_flag);
-            if (host_flag == 0) { status = KF_OK; ++sweeps; break; }
+            if (verbose) fprintf(stderr, "[kf_eigh] d=%lld blocked: %d sweeps run, done=%d\n", static_cast<long long>(d), host_state[2], host_state[1]);
         }
+        sweeps = host_state[2];
+        if (host_state[1]) status = KF_OK;
     } else if (d > 1) {
         double frob2 = 0.0;
         if (hipMemcpyAsync(&frob2, frob2_dev, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
