@@ -546,8 +546,9 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     if rank == 0:
         peak = PEAK_BF16_MFMA_TFLOPS if low else PEAK_FP32_MFMA_TFLOPS
         roofline = _event_summary(score_events.get("pairwise_score", []), peak,
-                                  "kf_pairwise_score: score_r1_kernel<..> (one row per sample) | per-sample-gradient "
-                                  "GEMM gemm_bf16_kernel<..,TAG_PSG> + score GEMM gemm_bf16_kernel<false,TAG_SCORE>", elapsed)
+                                  "kf_pairwise_score*: score_r1_kernel (one row per sample) | conv_pad_phases_kernel / "
+                                  "transpose_rows_kernel + psg_gemm_v2_kernel (per-sample gradients) + "
+                                  "score_gemm_v2_kernel<TM,TN,W> (score GEMM; the dominant kernel)", elapsed)
         traffic = _pmc_traffic(name)
         if roofline is not None and traffic is not None:
             roofline["traffic"] = traffic.get("kf_pairwise_score_bytes_per_launch")
@@ -595,9 +596,14 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip targets.mnist_mlp / other_configs in the default run")
     ap.add_argument("--factor-reps", type=int, default=1)
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
+    ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
+                    "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
+                    "907 -> 862 ms; nothing of the EK-FAC path is affected)")
     args = ap.parse_args()
     if args.train_batch:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
+    if not args.no_miopen_find:
+        torch.backends.cudnn.benchmark = True
 
     from kronfluence_amd.utils.state import State
 

@@ -82,6 +82,29 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
                   void* stream);
 
 /*
+ * Activation covariances on the LDS-DMA engine (ABI 8; bf16 inputs, exact products, fp32 accumulation, both triangles).
+ *
+ * kf_syrk_rows_bf16: C[d,d] += alpha * X'^T X' for the hooked input X [b, T, d_in] (bf16 contiguous) of a Linear layer on
+ * sequences -- the same mathematics as kf_syrk_accum (module/linear.py:30-46 + tracker/factor.py:58) with the rows first
+ * transposed to [b, d', T] in the workspace, where the 0/1 attention mask (KF_I64 / KF_I32 / KF_U8, nullable, [b*T]) zeroes
+ * masked rows including their bias one (linear.py:39-43) and the ones row of the bias column is generated.  Needs T % 64 == 0,
+ * d_in % 8 == 0, b <= 65535; the row counter is the caller's business.
+ *
+ * kf_conv2d_cov_accum: C[I',I'] += alpha * sum_{n,p} patches[n,p,:]^T patches[n,p,:] with IMPLICIT im2col (replaces
+ * module/conv2d.py:15-64 + :106-128 + tracker/factor.py:58: no [b, P, I'] patch tensor): x [b, C, H, W] bf16 contiguous; C is
+ * indexed in the reference's patch order (c, ky, kx).  Needs groups == 1, no bias, O2 % 8 == 0 and O1*O2 % 64 == 0
+ * (kf_conv2d_cov_workspace_bytes returns -1 otherwise: use kf_im2col + kf_syrk_accum).
+ */
+int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int append_ones);
+int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T, int64_t d_in, const void* mask, int mask_dtype,
+                      int append_ones, float alpha, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t kf_conv2d_cov_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2, int p1,
+                                      int p2, int d1, int d2);
+int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2,
+                        int s1, int s2, int p1, int p2, int d1, int d2, float alpha, void* workspace, int64_t workspace_bytes,
+                        void* stream);
+
+/*
  * out[b, P, I'] = unfold(group_mean(x))  (+ ones column), I' = C/groups*k1*k2 + append_ones,
  * P = O1*O2.  Replaces module/conv2d.py:15-64 (extract_patches: rearrange, reduce "mean",
  * F.unfold, transpose) and :120-127 (ones column).  x is NCHW contiguous.

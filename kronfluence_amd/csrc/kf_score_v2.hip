@@ -352,7 +352,14 @@ __global__ __launch_bounds__(256) void conv_pad_phases_kernel(PadArgs a) {
 struct TransposeArgs {
     uint16_t* out; const uint16_t* x;
     int T, C, Cp, ones;
+    const void* mask; int mask_dtype;  // nullable [batch * T] 0/1 mask (KF_I64 / KF_I32 / KF_U8): masked rows (incl. their one) -> 0
 };
+
+__device__ __forceinline__ bool mask_on(const void* mask, int dtype, int64_t idx) {
+    if (dtype == I64) return reinterpret_cast<const int64_t*>(mask)[idx] != 0;
+    if (dtype == I32) return reinterpret_cast<const int32_t*>(mask)[idx] != 0;
+    return reinterpret_cast<const uint8_t*>(mask)[idx] != 0;
+}
 
 __global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
     __shared__ uint16_t tile[64][72];
@@ -366,7 +373,9 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
         const int id = threadIdx.x + 256 * it, r = id >> 3, ch = id & 7;
         const int c = c0 + ch * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
-        if (c < a.C) v = *reinterpret_cast<const u32x4*>(x + static_cast<int64_t>(t0 + r) * a.C + c);
+        const bool keep = !a.mask || mask_on(a.mask, a.mask_dtype, z * a.T + t0 + r);
+        if (!keep) { /* masked token: whole row zero (module/linear.py:39-43 multiplies the ones column too) */ }
+        else if (c < a.C) v = *reinterpret_cast<const u32x4*>(x + static_cast<int64_t>(t0 + r) * a.C + c);
         else if (a.ones && c == a.C) v[0] = 0x3f80u;  // bf16 1.0 in column C, zeros after it
         uint16_t* d = &tile[r][ch * 8];
         d[0] = static_cast<uint16_t>(v[0]); d[1] = static_cast<uint16_t>(v[0] >> 16);
@@ -405,6 +414,117 @@ __global__ __launch_bounds__(256) void pad_grid_kernel(uint16_t* out, const uint
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Activation covariance on the LDS-DMA engine: C[i, j] += alpha * sum_{n, k} X[n][i, k] X[n][j, k] over K-contiguous rows
+// X[n] = A'[n]^T -- the transposed (masked, bias-augmented) activations of a Linear layer on sequences, or the IMPLICIT
+// im2col rows of a convolution (same addressing as the gradient kernel above: no patch tensor; kf_conv2d_cov_accum of
+// SURVEY.md section 8b).  128 x 128 upper-triangular tile pairs, the contraction runs over (sample, k-step) without a
+// break in the DMA double buffering; split over sample ranges, fp32 atomics (both triangles).
+// ------------------------------------------------------------------------------------------------
+struct CovV2Args {
+    float* out; int64_t ldc; float alpha;
+    const uint16_t* X; int64_t sample_stride;
+    int N, K, batch, tiles, zchunk, d_out;
+    // conv addressing as PsgV2Args; rows are (shift, c) with c < Cp, covariance index c * taps + shift for c < C_real
+    int conv, Cp, C_real, taps, k2, O2, s1, d1, s2, d2, Wq, plane;
+    int64_t phase_stride;
+};
+
+__global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    int t = blockIdx.x, ti = 0;
+    while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
+    const int tj = ti + t;
+    const int m0 = ti * 128, n0 = tj * 128;
+    const int z_begin = blockIdx.y * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
+    if (z_begin >= z_end) return;
+
+    const uint16_t* src_a[4];
+    const uint16_t* src_b[4];
+    int oct[4];
+    auto row_source = [&](int i) -> const uint16_t* {
+        if (a.conv) {
+            const int shift = i / a.Cp, c = i - shift * a.Cp;
+            const int ky = shift / a.k2, kx = shift - ky * a.k2;
+            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
+            return a.X + phase * a.phase_stride + static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
+        }
+        return a.X + static_cast<int64_t>(i) * a.K;
+    };
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = (wave * 4 + g) * 8 + (lane >> 3);
+        oct[g] = (lane & 7) ^ lds_swz(row);
+        src_a[g] = row_source(min(m0 + row, a.N - 1));
+        src_b[g] = row_source(min(n0 + row, a.N - 1));
+    }
+    const int ksteps = a.K >> 6;
+    auto stage = [&](int buf, int step) {  // step = (z - z_begin) * ksteps + kstep
+        const int z = z_begin + step / ksteps, k0 = (step % ksteps) * 64;
+        const int64_t zoff = static_cast<int64_t>(z) * a.sample_stride;
+        unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int koff = k0 + oct[g] * 8;
+            if (a.conv) { const int oy = koff / a.O2, ox = koff - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
+            glds16(src_a[g] + zoff + koff, base + g * 1024);
+            glds16(src_b[g] + zoff + koff, base + PV2_OPERAND_BYTES + g * 1024);
+        }
+    };
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    {
+        const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+        const int steps = (z_end - z_begin) * ksteps;
+        stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        int buf = 0;
+        for (int step = 0; step < steps; ++step) {
+            if (step + 1 < steps) stage(buf ^ 1, step + 1);
+            const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
+            const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((kk * 2 + hi) ^ sw) * 16;
+                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + co);
+                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + 32 * 128 + co);
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    auto out_index = [&](int i) -> int {  // row of the kernel's operand -> row of the covariance matrix, -1 = padding
+        if (i >= a.N) return -1;
+        if (a.conv) {
+            const int shift = i / a.Cp, c = i - shift * a.Cp;
+            return c < a.C_real ? c * a.taps + shift : -1;
+        }
+        return i < a.d_out ? i : -1;
+    };
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gi = out_index(m0 + acc_row(wm, i, r, lane)), gj = out_index(n0 + acc_col(wn, jn, lane));
+                if (gi >= 0 && gj >= 0) {
+                    const float v = a.alpha * acc[i][jn][r];
+                    atomicAdd(a.out + static_cast<int64_t>(gi) * a.ldc + gj, v);
+                    if (ti != tj) atomicAdd(a.out + static_cast<int64_t>(gj) * a.ldc + gi, v);
+                }
+            }
+}
+
 int configure_once() {
     static std::once_flag flag;
     static int status = KF_OK;
@@ -413,7 +533,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
@@ -571,7 +692,7 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
     uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(at) + align256(2 * b * Ip * R));
     TransposeArgs t;
     t.out = gt; t.x = reinterpret_cast<const uint16_t*>(G); t.T = static_cast<int>(R); t.C = static_cast<int>(O); t.Cp = static_cast<int>(O);
-    t.ones = 0;
+    t.ones = 0; t.mask = nullptr; t.mask_dtype = 0;
     hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(O, 64)), static_cast<unsigned>(b)),
                        dim3(256), 0, st, t);
     t.out = at; t.x = reinterpret_cast<const uint16_t*>(A); t.C = static_cast<int>(I); t.Cp = static_cast<int>(Ip); t.ones = append_ones ? 1 : 0;
@@ -585,6 +706,78 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
     int rc = launch_psg_v2(g, st);
     if (rc != KF_OK) return rc;
     return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
+}
+
+int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int append_ones) {
+    const int64_t W = (d_in + (append_ones ? 1 : 0) + 7) / 8 * 8;
+    return align256(2 * b * W * T);
+}
+
+int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T, int64_t d_in, const void* mask, int mask_dtype,
+                      int append_ones, float alpha, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!C || !X || b < 0 || T <= 0 || d_in <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (T % 64 != 0 || d_in % 8 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || b > 65535) return KF_ERR_INVALID_ARGUMENT;
+    if (mask && mask_dtype != KF_I64 && mask_dtype != KF_I32 && mask_dtype != KF_U8) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (!workspace || workspace_bytes < kf_syrk_rows_workspace_bytes(b, T, d_in, append_ones)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (b == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    hipStream_t st = as_stream(stream);
+    const int64_t d = d_in + (append_ones ? 1 : 0), W = (d + 7) / 8 * 8;
+    uint16_t* xt = reinterpret_cast<uint16_t*>(workspace);
+    TransposeArgs t;
+    t.out = xt; t.x = reinterpret_cast<const uint16_t*>(X); t.T = static_cast<int>(T); t.C = static_cast<int>(d_in); t.Cp = static_cast<int>(W);
+    t.ones = append_ones ? 1 : 0; t.mask = mask; t.mask_dtype = mask_dtype;
+    hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(T / 64), static_cast<unsigned>(cdiv(W, 64)), static_cast<unsigned>(b)),
+                       dim3(256), 0, st, t);
+    CovV2Args c{};
+    c.out = C; c.ldc = ldc; c.alpha = alpha; c.X = xt; c.sample_stride = W * T;
+    c.N = static_cast<int>(W); c.K = static_cast<int>(T); c.batch = static_cast<int>(b); c.tiles = static_cast<int>(cdiv(W, 128));
+    c.d_out = static_cast<int>(d); c.conv = 0;
+    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2;
+    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, pairs)));
+    c.zchunk = static_cast<int>(cdiv(b, zsplit));
+    hipLaunchKernelGGL(cov_gemm_v2_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(cdiv(b, c.zchunk))), dim3(NTHREADS), PV2_SMEM, st, c);
+    return launch_status();
+}
+
+int64_t kf_conv2d_cov_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2, int p1, int p2, int d1,
+                                      int d2) {
+    const ConvPlan c = conv_plan(b, C, H, W, 64, k1, k2, s1, s2, p1, p2, d1, d2);
+    // the covariance sums over REAL output positions only: the grid must already be whole 16-byte chunks / k-steps
+    if (c.O1 <= 0 || c.O2 <= 0 || c.O1p != c.O1 || c.O2p != c.O2 || c.Cp > 2 * C + 8) return -1;
+    return c.copies_bytes;
+}
+
+int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2,
+                        int p1, int p2, int d1, int d2, float alpha, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!Cov || !x || b < 0 || C <= 0) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t need = kf_conv2d_cov_workspace_bytes(b, C, H, W, k1, k2, s1, s2, p1, p2, d1, d2);
+    if (need < 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0 || b > 65535) return KF_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < need) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (b == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    hipStream_t st = as_stream(stream);
+    const ConvPlan p = conv_plan(b, C, H, W, 64, k1, k2, s1, s2, p1, p2, d1, d2);
+    uint16_t* copies = reinterpret_cast<uint16_t*>(workspace);
+    PadArgs pa;
+    pa.out = copies; pa.x = reinterpret_cast<const uint16_t*>(x); pa.planes = b * p.Cp; pa.C = static_cast<int>(C); pa.Cp = static_cast<int>(p.Cp);
+    pa.H = static_cast<int>(H); pa.W = static_cast<int>(W); pa.Hp = static_cast<int>(p.Hp); pa.Wq = static_cast<int>(p.Wq);
+    pa.p1 = p1; pa.p2 = p2; pa.s2 = s2;
+    const int64_t chunks = s2 * b * p.Cp * p.Hp * (p.Wq / 8);
+    hipLaunchKernelGGL(conv_pad_phases_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(chunks, 256), 1 << 20))), dim3(256), 0,
+                       st, pa);
+    CovV2Args c{};
+    c.out = Cov; c.ldc = ldc; c.alpha = alpha; c.X = copies; c.sample_stride = p.Cp * p.Hp * p.Wq;
+    c.N = static_cast<int>(p.Ipp); c.K = static_cast<int>(p.Pp); c.batch = static_cast<int>(b); c.tiles = static_cast<int>(cdiv(p.Ipp, 128));
+    c.d_out = static_cast<int>(C * k1 * k2);
+    c.conv = 1; c.Cp = static_cast<int>(p.Cp); c.C_real = static_cast<int>(C); c.taps = k1 * k2; c.k2 = k2; c.O2 = static_cast<int>(p.O2p);
+    c.s1 = s1; c.d1 = d1; c.s2 = s2; c.d2 = d2; c.Wq = static_cast<int>(p.Wq); c.plane = static_cast<int>(p.Hp * p.Wq);
+    c.phase_stride = b * p.Cp * p.Hp * p.Wq;
+    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2;
+    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, pairs)));
+    c.zchunk = static_cast<int>(cdiv(b, zsplit));
+    hipLaunchKernelGGL(cov_gemm_v2_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(cdiv(b, c.zchunk))), dim3(NTHREADS), PV2_SMEM, st, c);
+    return launch_status();
 }
 
 }  // extern "C"

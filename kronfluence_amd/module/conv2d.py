@@ -60,6 +60,14 @@ class TrackedConv2d(TrackedModule, module_type=nn.Conv2d):
 
     # -- fused hot path ----------------------------------------------------------------------------
     def accumulate_activation_covariance(self, cov, count, input_activation):
+        geometry = ops.conv2d_cov_geometry(input_activation, self.original_module)
+        if geometry is not None:  # implicit im2col: no patch tensor (kf_conv2d_cov_accum)
+            d = input_activation.shape[1] * self.kernel_size[0] * self.kernel_size[1]
+            if cov is None:
+                cov = torch.zeros((d, d), dtype=torch.float32, device=input_activation.device)
+                count = torch.zeros(1, dtype=torch.int64, device=input_activation.device)
+            ops.conv2d_cov_accum(cov, count, input_activation, self.original_module, geometry)
+            return cov, count
         patches = self._patches(input_activation)
         d = patches.shape[-1]
         if cov is None:

@@ -80,6 +80,24 @@ def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tenso
     n = x.numel() // d_in
     if mask is not None and mask.numel() != n:
         mask = None  # linear.py:33 -- the mask applies only when it matches the row count
+    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[1] % 64 == 0 and d_in % 8 == 0 and 0 < x.shape[0] <= 65535
+            and d_in >= 64 and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
+        # bf16 rows of a sequence layer: LDS-DMA covariance kernel (exact bf16 products, fp32 accumulation); the mask must be
+        # 0/1 (integer / bool dtype) because it is applied as a row select
+        b, t = x.shape[0], x.shape[1]
+        mask = _contig(mask) if mask is not None else None
+        ws_bytes = nat.lib().kf_syrk_rows_workspace_bytes(b, t, d_in, int(has_bias))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+        d = d_in + int(has_bias)
+        with _Timed("syrk_accum", x.device, float(n) * d * (d + 1), float(n) * d_in * 2):
+            nat.check(
+                nat.lib().kf_syrk_rows_bf16(cov.data_ptr(), cov.shape[1], x.data_ptr(), b, t, d_in, _ptr(mask),
+                                            nat.dtype_code(mask.dtype) if mask is not None else 0, int(has_bias), 1.0,
+                                            ws.data_ptr(), ws_bytes, nat.stream_ptr(x.device)),
+                "kf_syrk_rows_bf16",
+            )
+        count.add_(mask.sum().to(torch.int64) if mask is not None else n)
+        return
     if mask is not None and mask.dtype not in (torch.float32, torch.int64, torch.uint8, torch.bool):
         # the reference multiplies by the mask whatever its dtype (``mul_``): bf16 / fp16 / int32 masks are widened
         mask = mask.to(torch.float32)
@@ -142,8 +160,41 @@ def im2col(x: torch.Tensor, conv: nn.Conv2d, append_ones: bool, out_dtype: torch
     return out
 
 
+def conv2d_cov_geometry(x: torch.Tensor, conv: nn.Conv2d):
+    """Arguments of ``kf_conv2d_cov_accum`` for this input, or ``None`` when the implicit-im2col covariance does not apply
+    (not bf16 on the GPU, groups, bias, or an output grid that is not whole 16-byte chunks / 64-wide k-steps)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4) or conv.groups != 1 or conv.bias is not None:
+        return None
+    if not 0 < x.shape[0] <= 65535:
+        return None
+    geometry = tuple(x.shape) + conv_geometry(conv)
+    return geometry if nat.lib().kf_conv2d_cov_workspace_bytes(*geometry) > 0 else None
+
+
+def conv2d_cov_accum(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d, geometry) -> None:
+    """``cov += patches^T patches`` without the patch tensor (kf_conv2d_cov_accum); ``count += b * O1 * O2``."""
+    x = _contig(x)
+    b, c, h, w, k1, k2, s1, s2, p1, p2, d1, d2 = geometry
+    o1 = (h + 2 * p1 - d1 * (k1 - 1) - 1) // s1 + 1
+    o2 = (w + 2 * p2 - d2 * (k2 - 1) - 1) // s2 + 1
+    n, d = b * o1 * o2, c * k1 * k2
+    ws_bytes = nat.lib().kf_conv2d_cov_workspace_bytes(*geometry)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    with _Timed("syrk_accum", x.device, float(n) * d * (d + 1), float(b) * c * h * w * 2):
+        nat.check(
+            nat.lib().kf_conv2d_cov_accum(cov.data_ptr(), cov.shape[1], x.data_ptr(), *geometry, 1.0, ws.data_ptr(), ws_bytes,
+                                          nat.stream_ptr(x.device)),
+            "kf_conv2d_cov_accum",
+        )
+    count.add_(n)
+
+
 def conv_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d) -> None:
     """module/conv2d.py:106-128 + tracker/factor.py:58."""
+    geometry = conv2d_cov_geometry(x, conv)
+    if geometry is not None:
+        conv2d_cov_accum(cov, count, x, conv, geometry)
+        return
     patches = im2col(x, conv, conv.bias is not None, x.dtype if x.dtype != torch.float64 else torch.float32)
     n, d = patches.shape[0] * patches.shape[1], patches.shape[2]
     syrk_accum(cov, patches, n, d, max(n, 1), 0, d, 1, None, False, 1.0, count)

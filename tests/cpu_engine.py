@@ -156,6 +156,10 @@ def pairwise_score(scores, col_offset, p, g, a, append_ones, scale=1.0) -> None:
     scores[:, col_offset:col_offset + psg.shape[0]] += block.to(scores.dtype)
 
 
+def conv2d_cov_geometry(x, conv):
+    return None  # no implicit-im2col covariance in the stand-in engine
+
+
 def conv2d_score_geometry(x_shape, out_channels, conv):
     return None  # the stand-in engine has no implicit-im2col path: the trackers take the patch path
 
@@ -192,7 +196,7 @@ def cast(src, dtype):
 
 
 LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "eigh_small", "lambda_accum", "inv_lambda", "precondition",
-          "pairwise_score", "conv2d_score_geometry", "pairwise_score_conv2d", "pairwise_score_rows", "rowwise_dot", "mul_bcast", "cast")
+          "pairwise_score", "conv2d_cov_geometry", "conv2d_score_geometry", "pairwise_score_conv2d", "pairwise_score_rows", "rowwise_dot", "mul_bcast", "cast")
 
 
 class _Setter:

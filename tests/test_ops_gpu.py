@@ -137,6 +137,51 @@ def test_per_sample_gradient(ops, b, r, o, i, bias, dtype):
     assert got.shape == want.shape and rel(got, want) <= TOL
 
 
+@pytest.mark.parametrize("b,t,d,bias", [(3, 64, 64, True), (5, 128, 768, True), (2, 64, 3072, True), (4, 192, 136, False)])
+@pytest.mark.parametrize("mask_dtype", [None, torch.int64, torch.bool])
+def test_linear_activation_cov_bf16_sequence_rows(ops, b, t, d, bias, mask_dtype):
+    """kf_syrk_rows_bf16 (LDS-DMA covariance kernel): bf16 [b, T, d] rows with a 0/1 padding mask and the bias column --
+    module/linear.py:30-46 + tracker/factor.py:58 -- against the oracle on the same bf16 values (exact products)."""
+    x = _rand(b, t, d, dtype=torch.bfloat16)
+    mask = None
+    if mask_dtype is not None:
+        lengths = torch.randint(1, t + 1, (b,), generator=torch.Generator().manual_seed(3))
+        mask = (torch.arange(t)[None] < lengths[:, None]).to(mask_dtype)
+    flat, count = ref.linear_flat_activation(x.double(), None if mask is None else mask.double(), bias)
+    want = torch.zeros(d + bias, d + bias, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    cov = torch.zeros(d + bias, d + bias, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for _ in range(2):
+        ops.linear_activation_cov(cov, cnt, x.to(DEV), None if mask is None else mask.to(DEV), bias)
+    assert rel(cov, 2 * want) <= TOL, rel(cov, 2 * want)
+    assert int(cnt) == 2 * int(count) and rel(cov, cov.t()) <= 1e-6
+
+
+@pytest.mark.parametrize("c", [
+    dict(b=5, cin=16, k=3, stride=1, padding=1, dilation=1, hw=(16, 16)),
+    dict(b=3, cin=8, k=5, stride=2, padding=2, dilation=1, hw=(16, 16)),
+    dict(b=4, cin=128, k=3, stride=1, padding=1, dilation=1, hw=(8, 8)),
+    dict(b=6, cin=24, k=(1, 3), stride=1, padding=(0, 1), dilation=1, hw=(8, 8)),
+])
+def test_conv_activation_cov_implicit_im2col(ops, c):
+    """kf_conv2d_cov_accum: patches^T patches straight from the bf16 NCHW input (no patch tensor), in the reference's
+    (c, ky, kx) patch order, against conv2d.py:106-128 + factor.py:58 in fp64 -- and equal to the materialised path."""
+    conv = nn.Conv2d(c["cin"], 8, c["k"], stride=c["stride"], padding=c["padding"], dilation=c["dilation"], bias=False)
+    x = _rand(c["b"], c["cin"], *c["hw"], dtype=torch.bfloat16)
+    flat, count = ref.conv_flat_activation(x.double(), conv)
+    d = flat.shape[1]
+    want = torch.zeros(d, d, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    assert ops.conv2d_cov_geometry(x.to(DEV), conv) is not None
+    cov = torch.zeros(d, d, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    for _ in range(2):
+        ops.conv_activation_cov(cov, cnt, x.to(DEV), conv)
+    assert rel(cov, 2 * want) <= TOL, rel(cov, 2 * want)
+    assert int(cnt) == 2 * count and rel(cov, cov.t()) <= 1e-6
+
+
 # ---- stage 2 -------------------------------------------------------------------------------------
 @pytest.mark.parametrize("d,n", [(1, 5), (2, 9), (17, 100), (64, 40), (129, 1000), (255, 300), (256, 1000), (300, 150), (513, 2000),
                                  (770, 300), (1030, 5000), (1601, 2500)])
