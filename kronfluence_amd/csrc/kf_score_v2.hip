@@ -25,6 +25,7 @@
 // (lane l: row l & 31, k-octet l >> 5) bank-conflict free (cdna_hip_programming.md T2, rule 21).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include <algorithm>
 #include <mutex>
@@ -525,6 +526,125 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
             }
 }
 
+// 256 x 256-tile variant of the covariance kernel (8 waves as 2 x 4, each 128 x 64: the geometry of the score GEMM) for
+// d >= 512: per MFMA it moves half the LDS fragment bytes of the 128 x 128 kernel and its k-steps are twice as long
+// against the same DMA latency.
+__global__ __launch_bounds__(SV2_THREADS) void cov_gemm_v2_big_kernel(CovV2Args a) {
+    constexpr int A_BYTES = 256 * 128, STAGE_BYTES = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    int t = blockIdx.x, ti = 0;
+    while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
+    const int tj = ti + t;
+    const int m0 = ti * 256, n0 = tj * 256;
+    const int z_begin = blockIdx.y * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
+    if (z_begin >= z_end) return;
+    const uint16_t* src_a[4];
+    const uint16_t* src_b[4];
+    int oct[4];
+    auto row_source = [&](int i) -> const uint16_t* {
+        if (a.conv) {
+            const int shift = i / a.Cp, c = i - shift * a.Cp;
+            const int ky = shift / a.k2, kx = shift - ky * a.k2;
+            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
+            return a.X + phase * a.phase_stride + static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
+        }
+        return a.X + static_cast<int64_t>(i) * a.K;
+    };
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row = (wave * 4 + g) * 8 + (lane >> 3);
+        oct[g] = (lane & 7) ^ lds_swz(row);
+        src_a[g] = row_source(min(m0 + row, a.N - 1));
+        src_b[g] = row_source(min(n0 + row, a.N - 1));
+    }
+    const int ksteps = a.K >> 6;
+    auto stage = [&](int buf, int step) {
+        const int z = z_begin + step / ksteps, k0 = (step % ksteps) * 64;
+        const int64_t zoff = static_cast<int64_t>(z) * a.sample_stride;
+        unsigned char* base = sm + buf * STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            int koff = k0 + oct[g] * 8;
+            if (a.conv) { const int oy = koff / a.O2, ox = koff - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
+            glds16(src_a[g] + zoff + koff, base + g * 1024);
+            glds16(src_b[g] + zoff + koff, base + A_BYTES + g * 1024);
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    {
+        const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+        const int steps = (z_end - z_begin) * ksteps;
+        stage(0, 0);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        int buf = 0;
+        for (int step = 0; step < steps; ++step) {
+            if (step + 1 < steps) stage(buf ^ 1, step + 1);
+            const unsigned char* sa = sm + buf * STAGE_BYTES + (wm * 128 + lr) * 128;
+            const unsigned char* sb = sm + buf * STAGE_BYTES + A_BYTES + (wn * 64 + lr) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                const int co = ((kk * 2 + hi) ^ sw) * 16;
+                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
+                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 128 + co);
+                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[i][0], 0, 0, 0);
+                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[i][1], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            buf ^= 1;
+        }
+    }
+    auto out_index = [&](int i) -> int {
+        if (i >= a.N) return -1;
+        if (a.conv) {
+            const int shift = i / a.Cp, c = i - shift * a.Cp;
+            return c < a.C_real ? c * a.taps + shift : -1;
+        }
+        return i < a.d_out ? i : -1;
+    };
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int gi = out_index(m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+                const int gj = out_index(n0 + wn * 64 + jn * 32 + (lane & 31));
+                if (gi >= 0 && gj >= 0) {
+                    const float v = a.alpha * acc[i][jn][r];
+                    atomicAdd(a.out + static_cast<int64_t>(gi) * a.ldc + gj, v);
+                    if (ti != tj) atomicAdd(a.out + static_cast<int64_t>(gj) * a.ldc + gi, v);
+                }
+            }
+}
+
+// tile geometry, split over sample ranges and launch of the covariance kernel
+int launch_cov_v2(CovV2Args& c, hipStream_t st) {
+    static const bool allow_big = [] { const char* e = getenv("KF_COV_TILE"); return !(e && atoi(e) == 128); }();
+    const bool big = allow_big && c.N >= 512;
+    const int tile = big ? 256 : 128;
+    c.tiles = static_cast<int>(cdiv(c.N, tile));
+    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2;
+    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(c.batch, cdiv(big ? 512 : 1024, pairs)));
+    c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
+    const dim3 grid(static_cast<unsigned>(pairs), static_cast<unsigned>(cdiv(c.batch, c.zchunk)));
+    if (big) hipLaunchKernelGGL(cov_gemm_v2_big_kernel, grid, dim3(SV2_THREADS), 2 * 512 * 128, st, c);
+    else hipLaunchKernelGGL(cov_gemm_v2_kernel, grid, dim3(NTHREADS), PV2_SMEM, st, c);
+    return launch_status();
+}
+
 int configure_once() {
     static std::once_flag flag;
     static int status = KF_OK;
@@ -534,7 +654,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
@@ -555,7 +676,8 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     s.tiles_m = static_cast<int>(cdiv(Q, tm)); s.tiles_n = static_cast<int>(cdiv(b, tn));
     const int64_t tiles = static_cast<int64_t>(s.tiles_m) * s.tiles_n;
     // one workgroup per CU and k-chunk: ~2 rounds of work items over the 256 CUs, at least 16 k-steps per item
-    int64_t ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(512, tiles), s.KT / 16));
+    static const int64_t target = [] { const char* e = getenv("KF_SCORE_ITEMS"); return e ? std::max<int64_t>(1, atoll(e)) : 512; }();
+    int64_t ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(target, tiles), s.KT / 16));
     const int64_t kchunk = cdiv(s.KT, ksplit);
     ksplit = cdiv(s.KT, kchunk);
     s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
@@ -731,13 +853,9 @@ int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T
                        dim3(256), 0, st, t);
     CovV2Args c{};
     c.out = C; c.ldc = ldc; c.alpha = alpha; c.X = xt; c.sample_stride = W * T;
-    c.N = static_cast<int>(W); c.K = static_cast<int>(T); c.batch = static_cast<int>(b); c.tiles = static_cast<int>(cdiv(W, 128));
+    c.N = static_cast<int>(W); c.K = static_cast<int>(T); c.batch = static_cast<int>(b);
     c.d_out = static_cast<int>(d); c.conv = 0;
-    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2;
-    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, pairs)));
-    c.zchunk = static_cast<int>(cdiv(b, zsplit));
-    hipLaunchKernelGGL(cov_gemm_v2_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(cdiv(b, c.zchunk))), dim3(NTHREADS), PV2_SMEM, st, c);
-    return launch_status();
+    return launch_cov_v2(c, st);
 }
 
 int64_t kf_conv2d_cov_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2, int p1, int p2, int d1,
@@ -768,16 +886,12 @@ int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64
                        st, pa);
     CovV2Args c{};
     c.out = Cov; c.ldc = ldc; c.alpha = alpha; c.X = copies; c.sample_stride = p.Cp * p.Hp * p.Wq;
-    c.N = static_cast<int>(p.Ipp); c.K = static_cast<int>(p.Pp); c.batch = static_cast<int>(b); c.tiles = static_cast<int>(cdiv(p.Ipp, 128));
+    c.N = static_cast<int>(p.Ipp); c.K = static_cast<int>(p.Pp); c.batch = static_cast<int>(b);
     c.d_out = static_cast<int>(C * k1 * k2);
     c.conv = 1; c.Cp = static_cast<int>(p.Cp); c.C_real = static_cast<int>(C); c.taps = k1 * k2; c.k2 = k2; c.O2 = static_cast<int>(p.O2p);
     c.s1 = s1; c.d1 = d1; c.s2 = s2; c.d2 = d2; c.Wq = static_cast<int>(p.Wq); c.plane = static_cast<int>(p.Hp * p.Wq);
     c.phase_stride = b * p.Cp * p.Hp * p.Wq;
-    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2;
-    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, pairs)));
-    c.zchunk = static_cast<int>(cdiv(b, zsplit));
-    hipLaunchKernelGGL(cov_gemm_v2_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(cdiv(b, c.zchunk))), dim3(NTHREADS), PV2_SMEM, st, c);
-    return launch_status();
+    return launch_cov_v2(c, st);
 }
 
 }  // extern "C"
