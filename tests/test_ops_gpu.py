@@ -401,6 +401,23 @@ def test_pairwise_score_rows_v2(ops, q, b, r, o, i, bias):
     assert rel(scores, want) <= 4e-3, rel(scores, want)
 
 
+@pytest.mark.parametrize("q,b", [(520, 700), (1000, 1000), (130, 1000), (1000, 100)])
+def test_score_gemm_long_k_loops(ops, q, b):
+    """The score GEMM at ResNet-9 scale (D = 128 x 1152, ragged tiles, all three tile shapes, split-K chunks of 100+
+    k-steps: the steady state of its LDS ring) against torch on the SAME bf16 per-sample gradients."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    r, o, i = 16, 128, 1152
+    p = _rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    psg = torch.einsum("bro,bri->boi", g.float(), a.float()).to(torch.bfloat16)  # the kernel's own rounding point
+    want = p.float().flatten(1) @ psg.float().flatten(1).t()
+    for _ in range(3):  # repeated launches: a stale-buffer race would show up as run-to-run differences
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(scores, 0, TiledQueries(p, 0), g, a, False)
+        assert rel(scores, want) <= 1e-5, rel(scores, want)
+
+
 @pytest.mark.parametrize("n,d", [(300, 128), (5000, 1152), (1030, 264), (64, 16)])
 def test_syrk_bf16_symmetric_engine(ops, n, d):
     """bf16 rows, no mask / bias column: upper-triangular tile pairs on the bf16 TN engine."""
