@@ -94,10 +94,21 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
  * module/conv2d.py:15-64 + :106-128 + tracker/factor.py:58: no [b, P, I'] patch tensor): x [b, C, H, W] bf16 contiguous; C is
  * indexed in the reference's patch order (c, ky, kx).  Needs groups == 1, no bias, O2 % 8 == 0 and O1*O2 % 64 == 0
  * (kf_conv2d_cov_workspace_bytes returns -1 otherwise: use kf_im2col + kf_syrk_accum).
+ *
+ * kf_syrk_planes_bf16: C[d,d] += alpha * sum_z X_z X_z^T for X [b, d, K] bf16 contiguous (every sample d rows of K contiguous
+ * values): the gradient covariance of a convolution straight from the NCHW output gradient, d = C_out, K = O1*O2 (replaces the
+ * "b c o1 o2 -> (b o1 o2) c" rearrange of module/conv2d.py:130-132 + the addmm_ of tracker/factor.py:93).  Needs K % 64 == 0.
+ *
+ * All three accumulate the call's contribution in a [d_pad, d_pad] fp32 staging matrix inside the workspace (coalesced
+ * atomics in the kernel's own row order) and add it to C -- permuted to the reference's index order and mirrored -- in one
+ * finalize pass.
  */
 int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int append_ones);
 int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T, int64_t d_in, const void* mask, int mask_dtype,
                       int append_ones, float alpha, void* workspace, int64_t workspace_bytes, void* stream);
+int64_t kf_syrk_planes_workspace_bytes(int64_t d);
+int kf_syrk_planes_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t d, int64_t K, float alpha, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 int64_t kf_conv2d_cov_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2, int p1,
                                       int p2, int d1, int d2);
 int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2,

@@ -49,6 +49,8 @@ SIGNATURES = {
     "kf_syrk_accum": (_i, [_p, _i64, _p, _i, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i, _i, _f, _p, _p]),
     "kf_syrk_rows_workspace_bytes": (_i64, [_i64, _i64, _i64, _i]),
     "kf_syrk_rows_bf16": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _i, _i, _f, _p, _i64, _p]),
+    "kf_syrk_planes_workspace_bytes": (_i64, [_i64]),
+    "kf_syrk_planes_bf16": (_i, [_p, _i64, _p, _i64, _i64, _i64, _f, _p, _i64, _p]),
     "kf_conv2d_cov_workspace_bytes": (_i64, [_i64] * 4 + [_i] * 8),
     "kf_conv2d_cov_accum": (_i, [_p, _i64, _p] + [_i64] * 4 + [_i] * 8 + [_f, _p, _i64, _p]),
     "kf_im2col": (_i, [_p, _i, _p, _i, _i64, _i64, _i64, _i64] + [_i] * 10 + [_p]),

@@ -168,115 +168,9 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
             }
 }
 
-// s_waitcnt vmcnt(n) only (expcnt / lgkmcnt untouched): gfx9 encoding, vmcnt = imm[3:0] | imm[15:14] << 4
-#define KF_WAIT_VMCNT(n) __builtin_amdgcn_s_waitcnt(((n) & 15) | (((n) >> 4) << 14) | (7 << 4) | (15 << 8))
-
-// Ring-pipelined score GEMM (the default): same tiles and wave geometry, but the operands are staged in HALF k-tiles
-// (32 k = 64-byte LDS rows) through a ring of NS stages, NS - 1 of them in flight.  The two-stage kernel above drains every
-// DMA request at the end of its k-step (vmcnt(0)), so the latency of the last request is exposed once per k-step (measured:
-// 43 % MFMA utilisation, ~2 us per k-step against 0.85 us of MFMA work); here a wave only waits for ITS requests of the
-// stage it is about to read (counted vmcnt) and one raw s_barrier per half k-step orders everybody else's
-// (MI355X_MICROARCH.md item 7: LDS-DMA data is visible after the issuing wave's vmcnt and a barrier the reader passed).
-// LDS image: [rows][32 k] bf16, 64-byte rows, chunk c (16 bytes, 0..3) of row r at position c ^ ((r >> 2) & 3) -- the four
-// 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...) then cover the 16 slots of the 256-byte bank row exactly once.
-template <int TM, int TN, int WMW, int NS>
-__global__ __launch_bounds__(SV2_THREADS) void score_gemm_ring_kernel(ScoreV2Args a) {
-    constexpr int WNW = 8 / WMW, MI = TM / WMW / 32, NI = TN / WNW / 32;
-    constexpr int A_BYTES = TM * 64, STAGE_BYTES = (TM + TN) * 64, GA = TM / 128, GB = TN / 128;  // DMA requests per wave
-    constexpr int PER_STAGE = GA + GB, LA = NS - 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave / WNW, wn = wave % WNW;
-    const int tiles = a.tiles_m * a.tiles_n;
-    const int64_t items = static_cast<int64_t>(a.ksplit) * tiles, per_xcd = (items + 7) / 8;
-    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
-    if (j >= per_xcd || item >= items) return;
-    const int chunk = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
-    const int m0 = (tile / a.tiles_n) * TM, n0 = (tile % a.tiles_n) * TN;
-    const int kt_begin = chunk * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
-
-    // a wave request fills 16 rows x 64 B; wave w owns row groups GA w .. of A and GB w .. of B
-    int off_a[GA], off_b[GB];
-#pragma unroll
-    for (int t = 0; t < GA; ++t) {
-        const int row = (wave * GA + t) * 16 + (lane >> 2);
-        off_a[t] = min(m0 + row, a.M - 1) * 64 + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
-    }
-#pragma unroll
-    for (int t = 0; t < GB; ++t) {
-        const int row = (wave * GB + t) * 16 + (lane >> 2);
-        off_b[t] = min(n0 + row, a.N - 1) * 64 + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
-    }
-    const int64_t a_kt = static_cast<int64_t>(a.M) * 64, b_kt = static_cast<int64_t>(a.N) * 64;
-    auto stage = [&](int buf, int half_step) {  // half_step counts 32-wide k-slabs from kt_begin
-        const int kt = kt_begin + (half_step >> 1), ko = (half_step & 1) * 32;
-        const uint16_t* ap = a.A + kt * a_kt + ko;
-        const uint16_t* bp = a.B + kt * b_kt + ko;
-        unsigned char* base = sm + buf * STAGE_BYTES;
-#pragma unroll
-        for (int t = 0; t < GA; ++t) glds16(ap + off_a[t], base + (wave * GA + t) * 1024);
-#pragma unroll
-        for (int t = 0; t < GB; ++t) glds16(bp + off_b[t], base + A_BYTES + (wave * GB + t) * 1024);
-    };
-
-    f32x16 acc[MI][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-
-    const int steps = 2 * (kt_end - kt_begin);
-    if (steps > 0) {
-        const int lr = lane & 31, sw = (lr >> 2) & 3, hi = lane >> 5;
-        int issued = 0;
-        for (; issued < LA && issued < steps; ++issued) stage(issued, issued);
-        int buf = 0, refill = LA % NS;
-        for (int st = 0; st < steps; ++st) {
-            // this wave's requests of stage st have landed when at most those of the later stages are outstanding
-            const int inflight = issued - st - 1;
-            if (inflight >= 3) KF_WAIT_VMCNT(3 * PER_STAGE);
-            else if (inflight == 2) KF_WAIT_VMCNT(2 * PER_STAGE);
-            else if (inflight == 1) KF_WAIT_VMCNT(PER_STAGE);
-            else KF_WAIT_VMCNT(0);
-            // everybody's requests of stage st have landed, and everybody is done reading stage st - 1 (its fragments were
-            // consumed by MFMAs issued before this barrier) -- whose buffer is the one refilled next
-            __builtin_amdgcn_s_barrier();
-            if (issued < steps) {
-                stage(refill, issued);
-                ++issued;
-                refill = refill + 1 == NS ? 0 : refill + 1;
-            }
-            const unsigned char* sa = sm + buf * STAGE_BYTES + (wm * (MI * 32) + lr) * 64;
-            const unsigned char* sb = sm + buf * STAGE_BYTES + A_BYTES + (wn * (NI * 32) + lr) * 64;
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                const int co = ((kk * 2 + hi) ^ sw) * 16;
-                bf16x8 bv[NI];
-#pragma unroll
-                for (int jn = 0; jn < NI; ++jn) bv[jn] = *reinterpret_cast<const bf16x8*>(sb + jn * 32 * 64 + co);
-#pragma unroll
-                for (int i = 0; i < MI; ++i) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 64 + co);
-#pragma unroll
-                    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[jn], acc[i][jn], 0, 0, 0);
-                }
-            }
-            buf = buf + 1 == NS ? 0 : buf + 1;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int jn = 0; jn < NI; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * (MI * 32) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                const int n = n0 + wn * (NI * 32) + jn * 32 + (lane & 31);
-                if (m < a.M && n < a.N) atomicAdd(a.C + static_cast<int64_t>(m) * a.ldc + n, a.alpha * acc[i][jn][r]);
-            }
-}
+// A ring-pipelined variant (half k-tiles through 4 / 5 LDS stages, counted vmcnt, one raw barrier per half step: 96 / 128 KB
+// in flight instead of 64) was measured at the SAME rate on every layer shape (profiles/README.md, round 2): the kernel is
+// not waiting for its DMA requests, so the two-stage form stays.
 
 // ------------------------------------------------------------------------------------------------
 // Per-sample gradient: out[n][m, i] = sum_k A[n][m, k] B[n][i, k], bf16, written k-tile-major over d = m * N + i.
@@ -530,14 +424,15 @@ __global__ __launch_bounds__(256) void pad_grid_kernel(uint16_t* out, const uint
 // X[n] = A'[n]^T -- the transposed (masked, bias-augmented) activations of a Linear layer on sequences, or the IMPLICIT
 // im2col rows of a convolution (same addressing as the gradient kernel above: no patch tensor; kf_conv2d_cov_accum of
 // SURVEY.md section 8b).  128 x 128 upper-triangular tile pairs, the contraction runs over (sample, k-step) without a
-// break in the DMA double buffering; split over sample ranges, fp32 atomics (both triangles).
+// break in the DMA double buffering; split over sample ranges.  The tiles land (coalesced fp32 atomics, or plain stores when
+// there is one sample range) in a staging matrix held in the kernel's own row order; cov_finalize_kernel adds it to C.
 // ------------------------------------------------------------------------------------------------
 struct CovV2Args {
-    float* out; int64_t ldc; float alpha;
+    float* stage; int np;                  // [np x np] fp32 staging matrix in OPERAND row order, np = tiles * 128, upper tile pairs
     const uint16_t* X; int64_t sample_stride;
-    int N, K, batch, tiles, zchunk, d_out;
-    // conv addressing as PsgV2Args; rows are (shift, c) with c < Cp, covariance index c * taps + shift for c < C_real
-    int conv, Cp, C_real, taps, k2, O2, s1, d1, s2, d2, Wq, plane;
+    int N, K, batch, tiles, zchunk, plain_store;
+    // conv addressing as PsgV2Args; operand rows are (shift, c) with c < Cp
+    int conv, Cp, k2, O2, s1, d1, s2, d2, Wq, plane;
     int64_t phase_stride;
 };
 
@@ -613,145 +508,57 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
             buf ^= 1;
         }
     }
-    auto out_index = [&](int i) -> int {  // row of the kernel's operand -> row of the covariance matrix, -1 = padding
-        if (i >= a.N) return -1;
-        if (a.conv) {
-            const int shift = i / a.Cp, c = i - shift * a.Cp;
-            return c < a.C_real ? c * a.taps + shift : -1;
-        }
-        return i < a.d_out ? i : -1;
-    };
+    // epilogue into the staging matrix (operand row order, no bounds: it is padded to whole tiles): lanes run along a row, so
+    // the atomics of a wave are two 128-byte segments.  Writing the covariance itself from here -- index map c * taps + shift,
+    // mirrored element -- was measured at MORE than the whole k-loop (scattered fp32 atomics: 1.54 ms vs 0.70 ms without them
+    // on the 128 -> 128 3 x 3 layer); cov_finalize_kernel does the permutation and the mirror once per call instead.
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int gi = out_index(m0 + acc_row(wm, i, r, lane)), gj = out_index(n0 + acc_col(wn, jn, lane));
-                if (gi >= 0 && gj >= 0) {
-                    const float v = a.alpha * acc[i][jn][r];
-                    atomicAdd(a.out + static_cast<int64_t>(gi) * a.ldc + gj, v);
-                    if (ti != tj) atomicAdd(a.out + static_cast<int64_t>(gj) * a.ldc + gi, v);
-                }
+                float* dst = a.stage + static_cast<int64_t>(m0 + acc_row(wm, i, r, lane)) * a.np + n0 + acc_col(wn, jn, lane);
+                if (a.plain_store) *dst = acc[i][jn][r];
+                else atomicAdd(dst, acc[i][jn][r]);
             }
 }
 
-// 256 x 256-tile variant of the covariance kernel (8 waves as 2 x 4, each 128 x 64: the geometry of the score GEMM) for
-// d >= 512: per MFMA it moves half the LDS fragment bytes of the 128 x 128 kernel and its k-steps are twice as long
-// against the same DMA latency.
-__global__ __launch_bounds__(SV2_THREADS) void cov_gemm_v2_big_kernel(CovV2Args a) {
-    constexpr int A_BYTES = 256 * 128, STAGE_BYTES = 2 * A_BYTES;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
-    int t = blockIdx.x, ti = 0;
-    while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
-    const int tj = ti + t;
-    const int m0 = ti * 256, n0 = tj * 256;
-    const int z_begin = blockIdx.y * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
-    if (z_begin >= z_end) return;
-    const uint16_t* src_a[4];
-    const uint16_t* src_b[4];
-    int oct[4];
-    auto row_source = [&](int i) -> const uint16_t* {
-        if (a.conv) {
-            const int shift = i / a.Cp, c = i - shift * a.Cp;
-            const int ky = shift / a.k2, kx = shift - ky * a.k2;
-            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
-            return a.X + phase * a.phase_stride + static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
-        }
-        return a.X + static_cast<int64_t>(i) * a.K;
-    };
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int row = (wave * 4 + g) * 8 + (lane >> 3);
-        oct[g] = (lane & 7) ^ lds_swz(row);
-        src_a[g] = row_source(min(m0 + row, a.N - 1));
-        src_b[g] = row_source(min(n0 + row, a.N - 1));
-    }
-    const int ksteps = a.K >> 6;
-    auto stage = [&](int buf, int step) {
-        const int z = z_begin + step / ksteps, k0 = (step % ksteps) * 64;
-        const int64_t zoff = static_cast<int64_t>(z) * a.sample_stride;
-        unsigned char* base = sm + buf * STAGE_BYTES + wave * 4096;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            int koff = k0 + oct[g] * 8;
-            if (a.conv) { const int oy = koff / a.O2, ox = koff - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
-            glds16(src_a[g] + zoff + koff, base + g * 1024);
-            glds16(src_b[g] + zoff + koff, base + A_BYTES + g * 1024);
-        }
-    };
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    {
-        const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
-        const int steps = (z_end - z_begin) * ksteps;
-        stage(0, 0);
-        __builtin_amdgcn_s_waitcnt(0);
-        __syncthreads();
-        int buf = 0;
-        for (int step = 0; step < steps; ++step) {
-            if (step + 1 < steps) stage(buf ^ 1, step + 1);
-            const unsigned char* sa = sm + buf * STAGE_BYTES + (wm * 128 + lr) * 128;
-            const unsigned char* sb = sm + buf * STAGE_BYTES + A_BYTES + (wn * 64 + lr) * 128;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((kk * 2 + hi) ^ sw) * 16;
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 128 + co);
-                    acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b0, acc[i][0], 0, 0, 0);
-                    acc[i][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, b1, acc[i][1], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0);
-            __syncthreads();
-            buf ^= 1;
-        }
-    }
-    auto out_index = [&](int i) -> int {
-        if (i >= a.N) return -1;
-        if (a.conv) {
-            const int shift = i / a.Cp, c = i - shift * a.Cp;
-            return c < a.C_real ? c * a.taps + shift : -1;
-        }
-        return i < a.d_out ? i : -1;
-    };
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int gi = out_index(m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
-                const int gj = out_index(n0 + wn * 64 + jn * 32 + (lane & 31));
-                if (gi >= 0 && gj >= 0) {
-                    const float v = a.alpha * acc[i][jn][r];
-                    atomicAdd(a.out + static_cast<int64_t>(gi) * a.ldc + gj, v);
-                    if (ti != tj) atomicAdd(a.out + static_cast<int64_t>(gj) * a.ldc + gi, v);
-                }
-            }
+// covariance[i][j] += alpha * stage[p(i)][p(j)] (or its transpose: only tile pairs ti <= tj are computed); p = operand row of
+// covariance index i: identity for plain rows, (i % taps) * Cp + i / taps for the (c, ky, kx) patch order of a convolution.
+struct CovFinalizeArgs {
+    float* out; int64_t ldc; const float* stage; int np, d, conv, Cp, taps; float alpha;
+};
+
+__global__ __launch_bounds__(256) void cov_finalize_kernel(CovFinalizeArgs a) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= a.d) return;
+    int pi = i, pj = j;
+    if (a.conv) { pi = (i % a.taps) * a.Cp + i / a.taps; pj = (j % a.taps) * a.Cp + j / a.taps; }
+    if ((pi >> 7) > (pj >> 7)) { const int t = pi; pi = pj; pj = t; }
+    a.out[static_cast<int64_t>(i) * a.ldc + j] += a.alpha * a.stage[static_cast<int64_t>(pi) * a.np + pj];
 }
 
-// tile geometry, split over sample ranges and launch of the covariance kernel
-int launch_cov_v2(CovV2Args& c, hipStream_t st) {
-    static const bool allow_big = [] { const char* e = getenv("KF_COV_TILE"); return !(e && atoi(e) == 128); }();
-    const bool big = allow_big && c.N >= 512;
-    const int tile = big ? 256 : 128;
-    c.tiles = static_cast<int>(cdiv(c.N, tile));
-    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2;
-    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(c.batch, cdiv(big ? 512 : 1024, pairs)));
+inline int64_t align256(int64_t x) { return (x + 255) & ~static_cast<int64_t>(255); }
+inline int64_t cov_stage_bytes(int64_t n_operand_rows) {
+    const int64_t np = cdiv(n_operand_rows, 128) * 128;
+    return align256(np * np * 4);
+}
+
+// tile geometry, split over sample ranges, launch of the covariance kernel and of its finalize pass
+int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
+    c.tiles = static_cast<int>(cdiv(c.N, 128));
+    c.np = c.tiles * 128;
+    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);
+    // ~1000 work items (two per CU, two rounds), each at least 8 k-steps long
+    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(1024, pairs), steps / 8}));
     c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
-    const dim3 grid(static_cast<unsigned>(pairs), static_cast<unsigned>(cdiv(c.batch, c.zchunk)));
-    if (big) hipLaunchKernelGGL(cov_gemm_v2_big_kernel, grid, dim3(SV2_THREADS), 2 * 512 * 128, st, c);
-    else hipLaunchKernelGGL(cov_gemm_v2_kernel, grid, dim3(NTHREADS), PV2_SMEM, st, c);
+    const int64_t zblocks = cdiv(c.batch, c.zchunk);
+    c.plain_store = zblocks == 1;
+    if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    hipLaunchKernelGGL(cov_gemm_v2_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(zblocks)), dim3(NTHREADS), PV2_SMEM, st, c);
+    f.stage = c.stage; f.np = c.np;
+    hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();
 }
 
@@ -762,14 +569,9 @@ int configure_once() {
         const bool ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_ring_kernel<256, 256, 2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * 512 * 64) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_ring_kernel<256, 256, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 512 * 64) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_ring_kernel<256, 128, 4, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 384 * 64) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_ring_kernel<128, 256, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * 384 * 64) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_big_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
@@ -797,14 +599,6 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     ksplit = cdiv(s.KT, kchunk);
     s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(ksplit * tiles, 8)));
-    static const int ring = [] { const char* e = getenv("KF_SCORE_RING"); return e ? atoi(e) : 0; }();
-    if (ring == 4 || ring == 5) {
-        if (shape == 0 && ring == 5) hipLaunchKernelGGL((score_gemm_ring_kernel<256, 256, 2, 5>), grid, dim3(SV2_THREADS), 5 * 512 * 64, st, s);
-        else if (shape == 0) hipLaunchKernelGGL((score_gemm_ring_kernel<256, 256, 2, 4>), grid, dim3(SV2_THREADS), 4 * 512 * 64, st, s);
-        else if (shape == 1) hipLaunchKernelGGL((score_gemm_ring_kernel<256, 128, 4, 5>), grid, dim3(SV2_THREADS), 5 * 384 * 64, st, s);
-        else hipLaunchKernelGGL((score_gemm_ring_kernel<128, 256, 2, 5>), grid, dim3(SV2_THREADS), 5 * 384 * 64, st, s);
-        return launch_status();
-    }
     if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
     else if (shape == 1) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 128, 4>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     else hipLaunchKernelGGL((score_gemm_v2_kernel<128, 256, 2>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
@@ -819,7 +613,6 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
     return launch_status();
 }
 
-inline int64_t align256(int64_t x) { return (x + 255) & ~static_cast<int64_t>(255); }
 // columns of one phase copy: the last octet of an output row starts at O2 - 8 + ((k2 - 1) d2) / s2
 inline int64_t conv_wq(int64_t O2, int k2, int d2, int s2) { return (O2 + ((k2 - 1) * d2) / s2 + 7) / 8 * 8; }
 
@@ -955,7 +748,7 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
 
 int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int append_ones) {
     const int64_t W = (d_in + (append_ones ? 1 : 0) + 7) / 8 * 8;
-    return align256(2 * b * W * T);
+    return align256(2 * b * W * T) + cov_stage_bytes(W);
 }
 
 int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T, int64_t d_in, const void* mask, int mask_dtype,
@@ -975,10 +768,30 @@ int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T
     hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(T / 64), static_cast<unsigned>(cdiv(W, 64)), static_cast<unsigned>(b)),
                        dim3(256), 0, st, t);
     CovV2Args c{};
-    c.out = C; c.ldc = ldc; c.alpha = alpha; c.X = xt; c.sample_stride = W * T;
-    c.N = static_cast<int>(W); c.K = static_cast<int>(T); c.batch = static_cast<int>(b);
-    c.d_out = static_cast<int>(d); c.conv = 0;
-    return launch_cov_v2(c, st);
+    c.stage = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + align256(2 * b * W * T));
+    c.X = xt; c.sample_stride = W * T;
+    c.N = static_cast<int>(W); c.K = static_cast<int>(T); c.batch = static_cast<int>(b); c.conv = 0;
+    CovFinalizeArgs f{};
+    f.out = C; f.ldc = ldc; f.d = static_cast<int>(d); f.conv = 0; f.alpha = alpha;
+    return launch_cov_v2(c, f, st);
+}
+
+int64_t kf_syrk_planes_workspace_bytes(int64_t d) { return cov_stage_bytes(d); }
+
+int kf_syrk_planes_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t d, int64_t K, float alpha, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
+    if (!C || !X || b < 0 || d <= 0 || K <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (K % 64 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || b > 65535) return KF_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < cov_stage_bytes(d)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (b == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    CovV2Args c{};
+    c.stage = reinterpret_cast<float*>(workspace);
+    c.X = reinterpret_cast<const uint16_t*>(X); c.sample_stride = d * K;
+    c.N = static_cast<int>(d); c.K = static_cast<int>(K); c.batch = static_cast<int>(b); c.conv = 0;
+    CovFinalizeArgs f{};
+    f.out = C; f.ldc = ldc; f.d = static_cast<int>(d); f.conv = 0; f.alpha = alpha;
+    return launch_cov_v2(c, f, as_stream(stream));
 }
 
 int64_t kf_conv2d_cov_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2, int p1, int p2, int d1,
@@ -986,7 +799,7 @@ int64_t kf_conv2d_cov_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W
     const ConvPlan c = conv_plan(b, C, H, W, 64, k1, k2, s1, s2, p1, p2, d1, d2);
     // the covariance sums over REAL output positions only: the grid must already be whole 16-byte chunks / k-steps
     if (c.O1 <= 0 || c.O2 <= 0 || c.O1p != c.O1 || c.O2p != c.O2 || c.Cp > 2 * C + 8) return -1;
-    return c.copies_bytes;
+    return align256(c.copies_bytes) + cov_stage_bytes(c.Ipp);
 }
 
 int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2, int s1, int s2,
@@ -1008,13 +821,15 @@ int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64
     hipLaunchKernelGGL(conv_pad_phases_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(chunks, 256), 1 << 20))), dim3(256), 0,
                        st, pa);
     CovV2Args c{};
-    c.out = Cov; c.ldc = ldc; c.alpha = alpha; c.X = copies; c.sample_stride = p.Cp * p.Hp * p.Wq;
+    c.stage = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + align256(p.copies_bytes));
+    c.X = copies; c.sample_stride = p.Cp * p.Hp * p.Wq;
     c.N = static_cast<int>(p.Ipp); c.K = static_cast<int>(p.Pp); c.batch = static_cast<int>(b);
-    c.d_out = static_cast<int>(C * k1 * k2);
-    c.conv = 1; c.Cp = static_cast<int>(p.Cp); c.C_real = static_cast<int>(C); c.taps = k1 * k2; c.k2 = k2; c.O2 = static_cast<int>(p.O2p);
+    c.conv = 1; c.Cp = static_cast<int>(p.Cp); c.k2 = k2; c.O2 = static_cast<int>(p.O2p);
     c.s1 = s1; c.d1 = d1; c.s2 = s2; c.d2 = d2; c.Wq = static_cast<int>(p.Wq); c.plane = static_cast<int>(p.Hp * p.Wq);
     c.phase_stride = b * p.Cp * p.Hp * p.Wq;
-    return launch_cov_v2(c, st);
+    CovFinalizeArgs f{};
+    f.out = Cov; f.ldc = ldc; f.d = static_cast<int>(C * k1 * k2); f.conv = 1; f.Cp = static_cast<int>(p.Cp); f.taps = k1 * k2; f.alpha = alpha;
+    return launch_cov_v2(c, f, st);
 }
 
 }  // extern "C"

@@ -72,6 +72,28 @@ def syrk_accum(cov: torch.Tensor, x: torch.Tensor, n_rows: int, d_in: int, rows_
         )
 
 
+def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor], has_bias: bool, alpha: float) -> bool:
+    """bf16 ``[b, T, d]`` rows of a sequence layer on the LDS-DMA covariance kernel (exact bf16 products, fp32 accumulation);
+    ``False`` when the shape / dtype is not eligible.  The mask must be 0/1 (integer / bool dtype): it is a row select."""
+    d_in = x.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[1] % 64 == 0 and d_in % 8 == 0 and d_in >= 64
+            and 0 < x.shape[0] <= 65535 and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
+        return False
+    b, t = x.shape[0], x.shape[1]
+    mask = _contig(mask) if mask is not None else None
+    ws_bytes = nat.lib().kf_syrk_rows_workspace_bytes(b, t, d_in, int(has_bias))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    d = d_in + int(has_bias)
+    with _Timed("syrk_accum", x.device, float(b * t) * d * (d + 1), float(b * t) * d_in * 2):
+        nat.check(
+            nat.lib().kf_syrk_rows_bf16(cov.data_ptr(), cov.shape[1], x.data_ptr(), b, t, d_in, _ptr(mask),
+                                        nat.dtype_code(mask.dtype) if mask is not None else 0, int(has_bias), alpha,
+                                        ws.data_ptr(), ws_bytes, nat.stream_ptr(x.device)),
+            "kf_syrk_rows_bf16",
+        )
+    return True
+
+
 def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor],
                           has_bias: bool) -> None:
     """Flatten + mask + ones column + ``addmm_`` of module/linear.py:30-46 and tracker/factor.py:58, fused."""
@@ -80,22 +102,7 @@ def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tenso
     n = x.numel() // d_in
     if mask is not None and mask.numel() != n:
         mask = None  # linear.py:33 -- the mask applies only when it matches the row count
-    if (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[1] % 64 == 0 and d_in % 8 == 0 and 0 < x.shape[0] <= 65535
-            and d_in >= 64 and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
-        # bf16 rows of a sequence layer: LDS-DMA covariance kernel (exact bf16 products, fp32 accumulation); the mask must be
-        # 0/1 (integer / bool dtype) because it is applied as a row select
-        b, t = x.shape[0], x.shape[1]
-        mask = _contig(mask) if mask is not None else None
-        ws_bytes = nat.lib().kf_syrk_rows_workspace_bytes(b, t, d_in, int(has_bias))
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
-        d = d_in + int(has_bias)
-        with _Timed("syrk_accum", x.device, float(n) * d * (d + 1), float(n) * d_in * 2):
-            nat.check(
-                nat.lib().kf_syrk_rows_bf16(cov.data_ptr(), cov.shape[1], x.data_ptr(), b, t, d_in, _ptr(mask),
-                                            nat.dtype_code(mask.dtype) if mask is not None else 0, int(has_bias), 1.0,
-                                            ws.data_ptr(), ws_bytes, nat.stream_ptr(x.device)),
-                "kf_syrk_rows_bf16",
-            )
+    if _syrk_rows_bf16(cov, x, mask, has_bias, 1.0):
         count.add_(mask.sum().to(torch.int64) if mask is not None else n)
         return
     if mask is not None and mask.dtype not in (torch.float32, torch.int64, torch.uint8, torch.bool):
@@ -110,7 +117,8 @@ def linear_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor,
     g = _contig(g)
     d = g.shape[-1]
     n = g.numel() // d
-    syrk_accum(cov, g, n, d, max(n, 1), 0, d, 1, None, False, alpha, None)
+    if not _syrk_rows_bf16(cov, g, None, False, alpha):
+        syrk_accum(cov, g, n, d, max(n, 1), 0, d, 1, None, False, alpha, None)
     if mask is not None and mask.numel() == n:
         count.add_(mask.sum().to(torch.int64))
     else:
@@ -205,6 +213,18 @@ def conv_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, a
     g = _contig(g)
     b, o, h, w = g.shape
     p = h * w
+    if g.is_cuda and g.dtype == torch.bfloat16 and p % 64 == 0 and 0 < b <= 65535:
+        # the NCHW gradient IS the operand layout of the covariance kernel: C_out rows of O1*O2 contiguous values per sample
+        ws_bytes = nat.lib().kf_syrk_planes_workspace_bytes(o)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+        with _Timed("syrk_accum", g.device, float(b * p) * o * (o + 1), float(b * p) * o * 2):
+            nat.check(
+                nat.lib().kf_syrk_planes_bf16(cov.data_ptr(), cov.shape[1], g.data_ptr(), b, o, p, alpha, ws.data_ptr(), ws_bytes,
+                                              nat.stream_ptr(g.device)),
+                "kf_syrk_planes_bf16",
+            )
+        count.add_(b * p)
+        return
     if g.dtype == torch.bfloat16 and o % 8 == 0 and o > 8:
         # [b,P,O] rows feed the bf16 MFMA engine (k = row index strided, columns contiguous)
         rows = g.flatten(2).transpose(1, 2).contiguous()

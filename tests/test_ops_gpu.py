@@ -442,6 +442,36 @@ def test_conv_gradient_cov_bf16(ops):
     assert rel(cov, want) <= TOL and int(cnt) == gcount
 
 
+@pytest.mark.parametrize("b,o,h,w,alpha", [(6, 64, 8, 8, 1.0), (3, 130, 16, 16, 0.25), (70, 256, 8, 16, 1.0), (2, 5, 8, 8, 4.0)])
+def test_conv_gradient_cov_bf16_nchw_planes(ops, b, o, h, w, alpha):
+    """kf_syrk_planes_bf16: O1*O2 % 64 == 0 -> the NCHW gradient is consumed in place (no "(b o1 o2) c" copy), staged in the
+    kernel's row order and added / mirrored by the finalize pass; twice, to check the "+=" and that the staging matrix is
+    re-zeroed; against module/conv2d.py:130-132 + tracker/factor.py:93 in fp64."""
+    g = _rand(b, o, h, w, dtype=torch.bfloat16)
+    gflat, gcount = ref.conv_flat_gradient(g.double())
+    want = torch.zeros(o, o, dtype=torch.float64)
+    ref.covariance_update(want, gflat)
+    cov = torch.zeros(o, o, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.conv_gradient_cov(cov, cnt, g.to(DEV), alpha)
+    ops.conv_gradient_cov(cov, cnt, g.to(DEV), alpha)
+    assert rel(cov, 2 * alpha * want) <= TOL and int(cnt) == 2 * gcount
+    assert torch.equal(cov, cov.t())  # one staged value feeds both triangles
+
+
+@pytest.mark.parametrize("b,t,d,alpha", [(5, 64, 64, 1.0), (3, 128, 776, 0.5), (2, 512, 136, 1.0)])
+def test_linear_gradient_cov_bf16_sequence_rows(ops, b, t, d, alpha):
+    """Gradient rows of a sequence layer on kf_syrk_rows_bf16 (never masked, only the counter is: linear.py:48-54)."""
+    g = _rand(b, t, d, dtype=torch.bfloat16)
+    mask = (torch.rand(b, t, generator=torch.Generator().manual_seed(3)) < 0.7).to(torch.int64)
+    want = alpha * g.double().flatten(0, 1).t() @ g.double().flatten(0, 1)
+    cov = torch.zeros(d, d, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.linear_gradient_cov(cov, cnt, g.to(DEV), mask.to(DEV), alpha)
+    assert rel(cov, want) <= TOL and int(cnt) == int(mask.sum())
+    assert torch.equal(cov, cov.t())
+
+
 @pytest.mark.parametrize("c", [dict(cin=8, cout=16, k=3, stride=1, padding=1, dilation=1, groups=1, bias=False, hw=(9, 7)),
                                dict(cin=16, cout=8, k=5, stride=2, padding=2, dilation=1, groups=1, bias=False, hw=(12, 12)),
                                dict(cin=8, cout=8, k=(3, 3), stride=1, padding=0, dilation=2, groups=1, bias=False, hw=(10, 10))])

@@ -15,7 +15,7 @@ from kronfluence_amd import ops
 
 DEV = "cuda:0"
 CONVS = [("conv1 64->128 k5 s2", 64, 128, 5, 2, 2, 32), ("conv2 128->128 16x16", 128, 128, 3, 1, 1, 16),
-         ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8), ("conv7 256->128 6x6 grid", 256, 128, 3, 1, 0, 8)]
+         ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8), ("conv 1x1 1152->128 16x16 (aligned taps)", 1152, 128, 1, 1, 0, 16), ("conv7 256->128 6x6 grid", 256, 128, 3, 1, 0, 8)]
 SEQS = [("bert 768 T128 b64", 64, 128, 768), ("bert 3072 T128 b64", 64, 128, 3072), ("gpt2 768 T512 b16", 16, 512, 768),
         ("gpt2 3072 T512 b16", 16, 512, 3072)]
 
@@ -43,11 +43,11 @@ def main():
         cov, count = torch.zeros(d, d, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
         geometry = ops.conv2d_cov_geometry(x, conv)
         if geometry is None:
-            print(f"{name:26s} not on the implicit path (materialised patches)", flush=True)
+            print(f"{name:40s} not on the implicit path (materialised patches)", flush=True)
             continue
         t = timed(lambda: ops.conv2d_cov_accum(cov, count, x, conv, geometry))
         flops = float(b * o * o) * d * (d + 1)
-        print(f"{name:26s} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s", flush=True)
+        print(f"{name:40s} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s", flush=True)
     for name, bb, t_len, d_in in SEQS:
         x = torch.randn(bb, t_len, d_in, device=DEV).bfloat16()
         mask = (torch.rand(bb, t_len, device=DEV) < 0.9).to(torch.int64)
@@ -55,7 +55,7 @@ def main():
         cov, count = torch.zeros(d, d, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
         t = timed(lambda: ops.linear_activation_cov(cov, count, x, mask, True))
         flops = float(bb * t_len) * d * (d + 1)
-        print(f"{name:26s} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s", flush=True)
+        print(f"{name:40s} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s", flush=True)
 
 
 if __name__ == "__main__":

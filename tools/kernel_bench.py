@@ -20,7 +20,7 @@ DEV = "cuda:0"
 RESNET9 = [  # (cin, cout, k, stride, padding, H)
     ("conv0 3->64 (C pad 8)", 3, 64, 3, 1, 1, 32), ("conv7 256->128 6x6 grid", 256, 128, 3, 1, 0, 8),
     ("conv1 64->128 k5 s2", 64, 128, 5, 2, 2, 32), ("conv2 128->128", 128, 128, 3, 1, 1, 16), ("conv4 128->256", 128, 256, 3, 1, 1, 16),
-    ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8),
+    ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8), ("conv 1x1 1152->128 (aligned)", 1152, 128, 1, 1, 0, 16),
 ]
 SEQ = {  # (name, O, I, T)
     "bert": [("bert 768x769", 768, 768, 128), ("bert 3072x769", 3072, 768, 128), ("bert 768x3073", 768, 3072, 128)],
