@@ -290,11 +290,13 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict
 //   cross == 0: the pairs INSIDE each of the two blocks (two 32-player tournaments side by side, 31 rounds of 16 + 16
 //               rotations) -- run once per sweep on one perfect matching of the blocks.
 // Together every column pair of the matrix is visited exactly once per sweep (a cyclic Jacobi ordering by blocks).
+// (Driving the pair's 64 x 64 subproblem further before touching the columns -- 2, 3 or 5 alternating cross / in-block passes
+// per block pair -- was measured: the sweep count stays at 20-21 for d = 3073 and the solve only gets longer.)
 // The Gram matrix is rotated two-sidedly, G <- J^T G J, so the angles are exactly those of the one-sided method applied
 // to the columns.  Two barriers per round: the column pass reads G and writes a second buffer (every column belongs to
 // exactly one rotation, so all of it is rewritten), the row pass writes back.
 __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restrict__ partial, double* __restrict__ Ubuf, int* __restrict__ pair_flag,
-                                                         int gsplit, int cross, int npass, double tol, const double* __restrict__ frob2,
+                                                         int gsplit, int cross, double tol, const double* __restrict__ frob2,
                                                          double null_scale, int* rotated, const int* __restrict__ done) {
     constexpr int LP = KP + 1;
     if (*done) return;
@@ -323,15 +325,11 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
     }
     __syncthreads();
     const int k = tid & 31, rg = tid >> 5;  // column pass: rotation k, rows rg + 8 j
-    // passes of a block pair: cross, in-block, cross, ... (npass of them; 1 = the cyclic-by-blocks ordering, every column pair
-    // once per sweep; more = the pair's 64 x 64 subproblem is driven further towards diagonal before the columns are touched)
+    const int rounds = cross ? KB : KB - 1;
     int did = 0;
-    for (int pass = 0; pass < (cross ? npass : 1); ++pass) {
-    const bool cross_pass = cross && !(pass & 1);
-    const int rounds = cross_pass ? KB : KB - 1;
     for (int round = 0; round < rounds; ++round) {
         int p, q;
-        if (cross_pass) {
+        if (cross) {
             p = k; q = KB + ((k + round) & (KB - 1));
         } else {
             const int kk = k & 15, base = (k >> 4) * KB, m = KB - 1;
@@ -376,7 +374,6 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
             }
         }
         __syncthreads();
-    }
     }
     if (did) any = 1;
     __syncthreads();
@@ -699,7 +696,6 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
         int* state = flag;  // {rotated, done, sweeps}: three of the 16 spare ints behind `rank`
         if (hipMemsetAsync(state, 0, 3 * sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
         const int* done = state + 1;
-        static const int npass = [] { const char* e = getenv("KF_EIGH_PASSES"); return e ? std::max(1, atoi(e)) : 1; }();
         int enqueued = 0, host_state[3] = {0, 0, 0};
         while (enqueued < max_sweeps && !host_state[1]) {
             const int batch = enqueued < 8 ? 8 : 4;  // nothing converges in under 8 sweeps at these sizes
@@ -710,7 +706,7 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
                     hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players,
                                        pairing, p.gsplit, p.gchunk, done);
                     hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1,
-                                       npass, tol, frob2_dev, null_scale, state, done);
+                                       tol, frob2_dev, null_scale, state, done);
                     hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
                                        p.nblocks, p.players, pairing, p.uchunk, done);
                 }

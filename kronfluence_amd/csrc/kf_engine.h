@@ -114,6 +114,30 @@ __device__ __forceinline__ int acc_row(int wm, int ti, int reg, int lane) {
 }
 __device__ __forceinline__ int acc_col(int wn, int tj, int lane) { return wn * 64 + tj * 32 + (lane & 31); }
 
+// Lower-triangle mirror of a symmetric product: the wave's 2 x 2 accumulator blocks of the (ti < tj) tile go to
+// C[n0 + n][m0 + m] TRANSPOSED THROUGH LDS, so that lanes run along the contiguous direction of C (two 128-byte segments per
+// wave instruction).  Mirroring straight from the fragment layout puts the 64 lanes of an instruction on 64 different rows:
+// scattered fp32 atomics that were measured at 2-3x the cost of the whole k-loop of a covariance tile.
+// All 256 threads call it; `lds` holds 4 x 32 x 33 floats (free after the main loop); v(i, j, r) = finished value of acc[i][j][r].
+template <typename Value, typename Store>
+__device__ __forceinline__ void mirror_through_lds(float* lds, int wm, int wn, int lane, int wave, Value value, Store store) {
+    float* mine = lds + wave * (32 * 33);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            __syncthreads();  // the region is free (main loop / previous block done)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mine[(lane & 31) * 33 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)] = value(i, j, r);
+            __syncthreads();
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) {
+                const int nl = rr * 2 + (lane >> 5), ml = lane & 31;
+                store(wn * 64 + j * 32 + nl, wm * 64 + i * 32 + ml, mine[nl * 33 + ml]);  // (n in tile, m in tile, value)
+            }
+        }
+}
+
 __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int i = 0; i < 2; ++i)

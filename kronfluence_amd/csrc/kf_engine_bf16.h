@@ -282,13 +282,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
                     float* dst = reinterpret_cast<float*>(a.C) + idx;
                     if (a.atomic) atomicAdd(dst, v);
                     else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
-                    if (mirror) {  // off-diagonal tile pair: mirror into the lower triangle
-                        float* lo = reinterpret_cast<float*>(a.C) + cz + static_cast<int64_t>(n) * a.ldc + m;
-                        if (a.atomic) atomicAdd(lo, v);
-                        else *lo = (a.beta == 0.0f) ? v : v + a.beta * *lo;
-                    }
                 }
             }
+    if (mirror)  // off-diagonal tile pair of a symmetric product (uniform per workgroup): the lower triangle, coalesced
+        mirror_through_lds(
+            reinterpret_cast<float*>(hsm), wm, wn, lane, wave,
+            [&](int ti, int tj, int r) { return bf16_epilogue(a, acc[ti][tj][r], m0 + acc_row(wm, ti, r, lane), n0 + acc_col(wn, tj, lane)); },
+            [&](int nl, int ml, float v) {
+                const int n = n0 + nl, m = m0 + ml;
+                if (m < a.M && n < a.N) {
+                    float* lo = reinterpret_cast<float*>(a.C) + cz + static_cast<int64_t>(n) * a.ldc + m;
+                    if (a.atomic) atomicAdd(lo, v);
+                    else *lo = (a.beta == 0.0f) ? v : v + a.beta * *lo;
+                }
+            });
 }
 
 // Lambda += scale2 * sum_z ( sum_k A[z][k,m] B[z][k,n] )^2 -- the EK-FAC corrected eigenvalues from bf16

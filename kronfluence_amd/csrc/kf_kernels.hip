@@ -350,11 +350,21 @@ __global__ __launch_bounds__(NTHREADS) void syrk_kernel(SyrkArgs a) {
                 if (m < d && n < d) {
                     const float v = a.alpha * acc[i][j][r];
                     float* up = a.C + static_cast<int64_t>(m) * a.ldc + n;
-                    float* lo = a.C + static_cast<int64_t>(n) * a.ldc + m;
-                    if (a.atomic) { atomicAdd(up, v); if (ti != tj) atomicAdd(lo, v); }
-                    else { *up += v; if (ti != tj) *lo += v; }
+                    if (a.atomic) atomicAdd(up, v);
+                    else *up += v;
                 }
             }
+    if (ti != tj)  // uniform per workgroup
+        mirror_through_lds(
+            smem, wm, wn, lane, wave, [&](int i, int j, int r) { return a.alpha * acc[i][j][r]; },
+            [&](int nl, int ml, float v) {
+                const int n = tj * BN + nl, m = ti * BM + ml;
+                if (m < d && n < d) {
+                    float* lo = a.C + static_cast<int64_t>(n) * a.ldc + m;
+                    if (a.atomic) atomicAdd(lo, v);
+                    else *lo += v;
+                }
+            });
 }
 
 __global__ void count_kernel(int64_t* count, const void* mask, int mask_dtype, int64_t n) {
