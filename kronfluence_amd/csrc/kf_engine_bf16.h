@@ -194,7 +194,7 @@ __device__ __forceinline__ void bf16_tile_mainloop(const HalfGemmArgs& a, const 
 #undef KF_NT_LOAD
 }
 
-template <bool TRANS>
+template <bool TRANS, bool SYM = false>  // SYM: the symmetric (SYRK) instantiation -- its mirror epilogue costs registers
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
@@ -202,7 +202,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
     // only): all output tiles of one (batch, k-chunk) slab go to the SAME XCD in consecutive order, so
     // the 8 m-tiles x 8 n-tiles that re-read the same A / B k-range hit in that XCD's 4 MB L2 instead
     // of each XCD pulling its own copy over the fabric.
-    const int tiles = a.symmetric ? a.tiles_m * (a.tiles_m + 1) / 2 : a.tiles_m * a.tiles_n;
+    const int tiles = SYM ? a.tiles_m * (a.tiles_m + 1) / 2 : a.tiles_m * a.tiles_n;
     // work items (chunk-major, tile-minor) are cut into 8 contiguous ranges, one per XCD: whole k-chunks
     // when there are many, runs of neighbouring tiles (same A rows) when there are few.
     const int64_t items = static_cast<int64_t>(a.chunks) * tiles, per_xcd = (items + 7) / 8;
@@ -212,14 +212,14 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
     const int chunk = static_cast<int>(item / tiles);
     const int tile = static_cast<int>(item % tiles);
     int tile_i = tile / a.tiles_n, tile_j = tile % a.tiles_n;
-    if (a.symmetric) {  // tile -> (tile_i <= tile_j) of the upper triangle
+    if (SYM) {  // tile -> (tile_i <= tile_j) of the upper triangle
         int t = tile;
         tile_i = 0;
         while (t >= a.tiles_m - tile_i) { t -= a.tiles_m - tile_i; ++tile_i; }
         tile_j = tile_i + t;
     }
     const int n0 = tile_j * 128, m0 = tile_i * 128;
-    const bool mirror = a.symmetric && tile_i != tile_j;
+    const bool mirror = SYM && tile_i != tile_j;
     const int z = chunk / a.ksplit, ks = chunk % a.ksplit;
     const int k_begin = ks * a.kchunk;
     const int k_end = min(a.K, k_begin + a.kchunk);
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
                     else *dst = (a.beta == 0.0f) ? v : v + a.beta * *dst;
                 }
             }
-    if (mirror)  // off-diagonal tile pair of a symmetric product (uniform per workgroup): the lower triangle, coalesced
+    if constexpr (SYM) if (mirror)  // off-diagonal tile pair (uniform per workgroup): the lower triangle, coalesced
         mirror_through_lds(
             reinterpret_cast<float*>(hsm), wm, wn, lane, wave,
             [&](int ti, int tj, int r) { return bf16_epilogue(a, acc[ti][tj][r], m0 + acc_row(wm, ti, r, lane), n0 + acc_col(wn, tj, lane)); },

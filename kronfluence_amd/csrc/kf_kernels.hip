@@ -197,6 +197,7 @@ int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batc
     if (nblocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
     const dim3 grid(static_cast<unsigned>(nblocks));
     if (mode == 1) hipLaunchKernelGGL((gemm_bf16_kernel<false>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
+    else if (symmetric) hipLaunchKernelGGL((gemm_bf16_kernel<true, true>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
     else hipLaunchKernelGGL((gemm_bf16_kernel<true>), grid, dim3(NTHREADS), HSMEM_BYTES, st, h);
     return launch_status();
 }
@@ -766,6 +767,7 @@ int configure_kernels() {
         const bool ok =
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, HSMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(im2col_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
