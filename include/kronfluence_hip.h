@@ -82,7 +82,7 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
                   void* stream);
 
 /*
- * Activation covariances on the LDS-DMA engine (ABI 8; bf16 inputs, exact products, fp32 accumulation, both triangles).
+ * Covariances on the LDS-DMA engine (ABI 8 / 9; bf16 inputs, exact products, fp32 accumulation, both triangles).
  *
  * kf_syrk_rows_bf16: C[d,d] += alpha * X'^T X' for the hooked input X [b, T, d_in] (bf16 contiguous) of a Linear layer on
  * sequences -- the same mathematics as kf_syrk_accum (module/linear.py:30-46 + tracker/factor.py:58) with the rows first
