@@ -554,6 +554,13 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             roofline["traffic"] = traffic.get("kf_pairwise_score_bytes_per_launch")
             roofline["traffic_source"] = traffic.get("source")
             roofline["mfma_util"] = traffic.get("mfma_util")
+        roofline_cov = _event_summary(fit_events.get("syrk_accum", []), peak, "covariance calls: kf_syrk_accum | kf_syrk_rows_bf16 | "
+                                      "kf_conv2d_cov_accum | kf_syrk_planes_bf16 (pad / transpose + cov_gemm_v2_kernel + cov_finalize_kernel; "
+                                      "algorithmic bytes = one read of the rows handed over)", fit_times["covariance"])
+        if roofline_cov is not None and traffic is not None and traffic.get("cov_gemm_bytes_per_launch") is not None:
+            roofline_cov["traffic"] = traffic["cov_gemm_bytes_per_launch"]
+            roofline_cov["traffic_source"] = "cov_gemm_v2_kernel alone (per launch), same PMC passes as roofline.traffic"
+            roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
         result = {
             "metric": "pairwise_influence_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -568,8 +575,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                        **({"scaled_from": {"n_train": spec.get("full_n_train"), "n_query": spec.get("full_n_query", spec["n_query"])}}
                           if n_train < spec.get("full_n_train", 0) else {})},
             "roofline": roofline,
-            "roofline_cov": _event_summary(fit_events.get("syrk_accum", []), peak, "kf_syrk_accum (activation + gradient "
-                                           "covariance SYRK; algorithmic bytes = one read of the rows handed to it)", fit_times["covariance"]),
+            "roofline_cov": roofline_cov,
             "roofline_lambda": _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_accum (factored form)",
                                               fit_times["lambda"]),
             "factor_fit": {"samples_per_sec": n_train / fit_total, "seconds": fit_times, "n_fit": n_train,

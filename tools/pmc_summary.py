@@ -64,8 +64,12 @@ def main() -> None:
         "kf_pairwise_score_bytes_per_launch": total / calls if calls else None,
         "kf_pairwise_score_calls_profiled": calls,
         "mfma_util": dominant.get("mfma_util") if dominant else None,
+        # covariance stage (present when the profiled command ran the factor fit): the GEMM kernel of the LDS-DMA covariance path
+        "cov_gemm_bytes_per_launch": (lambda e: e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0) if e else None)(
+            kernels.get("cov_gemm_v2_kernel")),
+        "cov_gemm_mfma_util": (kernels.get("cov_gemm_v2_kernel") or {}).get("mfma_util"),
         "kernels": {n: e for n, e in kernels.items() if n.startswith(SCORE_KERNELS) or "gemm_bf16" in n or "syrk" in n or "lambda" in n
-                    or "im2col" in n or "eigh" in n or "jacobi" in n},
+                    or "im2col" in n or "eigh" in n or "jacobi" in n or n.startswith("cov_")},
     }
     with open(out_path, "w", encoding="utf-8") as handle:
         json.dump(summary, handle, indent=1)
