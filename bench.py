@@ -638,7 +638,9 @@ def main() -> None:
         line["other_configs"] = {}
         for other in ("bert_base", "gpt2_small"):
             try:
-                r = run_workload(other, state, None, None, steps=1, warmup=1, factor_reps=0, cpu_baseline=False)
+                # factor_reps=1: the reported fit is the second, warm one (the first GPT-2 covariance pass alone spends ~5 s in
+                # first-touch allocations and GEMM heuristics)
+                r = run_workload(other, state, None, None, steps=1, warmup=1, factor_reps=1, cpu_baseline=False)
                 line["other_configs"][other] = {k: r[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
                                                                    "roofline_cov", "roofline_lambda", "factor_fit", "peak_hbm_gib")}
             except Exception as error:  # an extra must never take the headline down with it

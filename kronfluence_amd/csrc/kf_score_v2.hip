@@ -52,6 +52,25 @@ __device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
 
 __device__ __forceinline__ int lds_swz(int row) { return (row >> 1) & 7; }
 
+// One 64-deep k-step of a wave's 64 x 64 block (2 x 2 accumulators) from an LDS stage; sa / sb = this lane's row in the A / B
+// image.  (Requesting the fragments of k-slab kk + 1 before the MFMAs of slab kk -- asm ds_reads with counted lgkmcnt, because
+// hipcc drains lgkmcnt to 0 after every global_load_lds -- was measured on all three LDS-DMA kernels: no change; the second
+// wave of the SIMD already fills those gaps.)
+__device__ __forceinline__ void wave_kstep_64x64(f32x16 (&acc)[2][2], const unsigned char* sa, const unsigned char* sb, int hi, int sw) {
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int co = ((kk * 2 + hi) ^ sw) * 16;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + co);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + 32 * 128 + co);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // Score GEMM: C[m, n] += alpha * sum_k A[m, k] B[n, k], A and B k-tile-major bf16.
 // 512 threads = 8 wave64 as 2 (m) x 4 (n); 256 x 256 tile, each wave 128 x 64 = 4 x 2 accumulators of
@@ -266,18 +285,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
             if (k0 + 64 < a.K) stage(buf ^ 1, k0 + 64);
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((kk * 2 + hi) ^ sw) * 16;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + co);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + 32 * 128 + co);
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            wave_kstep_64x64(acc, sa, sb, hi, sw);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             buf ^= 1;
@@ -430,7 +438,7 @@ __global__ __launch_bounds__(256) void pad_grid_kernel(uint16_t* out, const uint
 struct CovV2Args {
     float* stage; int np;                  // [np x np] fp32 staging matrix in OPERAND row order, np = tiles * 128, upper tile pairs
     const uint16_t* X; int64_t sample_stride;
-    int N, K, batch, tiles, zchunk, plain_store;
+    int N, K, batch, tiles, zchunk, zblocks, plain_store;
     // conv addressing as PsgV2Args; operand rows are (shift, c) with c < Cp
     int conv, Cp, k2, O2, s1, d1, s2, d2, Wq, plane;
     int64_t phase_stride;
@@ -439,11 +447,20 @@ struct CovV2Args {
 __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    int t = blockIdx.x, ti = 0;
+    // XCD-aware work order (workgroup L runs on XCD L % 8): items are (sample range, tile pair), sample range major, cut into 8
+    // contiguous runs -- the tile pairs of a sample range share its rows, so every XCD streams its own samples through its own
+    // L2 (with pair-major blocks every XCD read every sample: 1.65 GB of L2 misses per launch against 0.1 GB of operands)
+    const int pairs = a.tiles * (a.tiles + 1) / 2;
+    const int64_t items = static_cast<int64_t>(a.zblocks) * pairs, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, jx = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + jx;
+    if (jx >= per_xcd || item >= items) return;
+    const int zb = static_cast<int>(item / pairs);
+    int t = static_cast<int>(item % pairs), ti = 0;
     while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
     const int tj = ti + t;
     const int m0 = ti * 128, n0 = tj * 128;
-    const int z_begin = blockIdx.y * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
+    const int z_begin = zb * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
     if (z_begin >= z_end) return;
 
     const uint16_t* src_a[4];
@@ -491,18 +508,7 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
             if (step + 1 < steps) stage(buf ^ 1, step + 1);
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
-                const int co = ((kk * 2 + hi) ^ sw) * 16;
-                const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + co);
-                const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + 32 * 128 + co);
-                const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
-                const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);
-            }
+            wave_kstep_64x64(acc, sa, sb, hi, sw);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             buf ^= 1;
@@ -554,9 +560,11 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(1024, pairs), steps / 8}));
     c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
     const int64_t zblocks = cdiv(c.batch, c.zchunk);
+    c.zblocks = static_cast<int>(zblocks);
     c.plain_store = zblocks == 1;
+    const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
     if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-    hipLaunchKernelGGL(cov_gemm_v2_kernel, dim3(static_cast<unsigned>(pairs), static_cast<unsigned>(zblocks)), dim3(NTHREADS), PV2_SMEM, st, c);
+    hipLaunchKernelGGL(cov_gemm_v2_kernel, grid, dim3(NTHREADS), PV2_SMEM, st, c);
     f.stage = c.stage; f.np = c.np;
     hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();

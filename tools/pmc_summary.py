@@ -29,7 +29,34 @@ def short(name: str) -> str:
     return name.split("(")[0].strip()
 
 
+def score_call_bytes(kernels: dict) -> float:
+    """HBM bytes of all kf_pairwise_score* calls.  The pad / transpose kernels also serve the covariance entry points when the
+    profiled command ran the factor fit: a score call launches exactly one psg_gemm_v2_kernel with one conv_pad_phases_kernel
+    (convolution) or two transpose_rows_kernel (sequence rows), so only that share of their launches is counted."""
+    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith("psg_gemm_v2_kernel"))
+    total = 0.0
+    for n, e in kernels.items():
+        if not n.startswith(SCORE_KERNELS):
+            continue
+        share = 1.0
+        if n.startswith("conv_pad_phases_kernel"):
+            share = min(1.0, psg / e["launches"])
+        elif n.startswith("transpose_rows_kernel"):
+            share = min(1.0, 2.0 * psg / e["launches"])
+        total += share * e["launches"] * (e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0))
+    return total
+
+
 def main() -> None:
+    if sys.argv[1] == "--recompute":  # python tools/pmc_summary.py --recompute <summary.json>: totals from the kept per-kernel means
+        with open(sys.argv[2], encoding="utf-8") as handle:
+            summary = json.load(handle)
+        calls = summary["kf_pairwise_score_calls_profiled"]
+        summary["kf_pairwise_score_bytes_per_launch"] = score_call_bytes(summary["kernels"]) / calls if calls else None
+        with open(sys.argv[2], "w", encoding="utf-8") as handle:
+            json.dump(summary, handle, indent=1)
+        print(summary["kf_pairwise_score_bytes_per_launch"])
+        return
     workload, out_path, dirs = sys.argv[1], sys.argv[2], sys.argv[3:]
     values = defaultdict(lambda: defaultdict(list))  # kernel -> counter -> per-dispatch values
     for d in dirs:
@@ -54,8 +81,7 @@ def main() -> None:
         kernels[name] = entry
     # one kf_pairwise_score* call = its pad / transpose / gradient kernels + one score GEMM (or one score_r1 launch)
     calls = sum(e["launches"] for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel") or n.startswith("score_r1_kernel"))
-    total = sum(e["launches"] * (e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0))
-                for n, e in kernels.items() if n.startswith(SCORE_KERNELS))
+    total = score_call_bytes(kernels)
     dominant = max((e for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel")), key=lambda e: e["launches"], default=None)
     summary = {
         "workload": workload,
