@@ -24,7 +24,11 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def _contig(t: torch.Tensor) -> torch.Tensor:
-    return t if t.is_contiguous() else t.contiguous()
+    """Input operand as the kernels want it: contiguous and 16-byte aligned (a contiguous VIEW into a larger tensor, e.g. a
+    slice along the batch axis of an odd-sized sample, may start anywhere; the vector loads / LDS-DMA requests may not)."""
+    if t.is_contiguous() and t.data_ptr() % 16 == 0:
+        return t
+    return t.clone(memory_format=torch.contiguous_format)
 
 
 def view(t: torch.Tensor, batch_stride: int, row_stride: int, k_stride: int, rows: int, depth: int,
@@ -77,7 +81,8 @@ def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Ten
     ``False`` when the shape / dtype is not eligible.  The mask must be 0/1 (integer / bool dtype): it is a row select."""
     d_in = x.shape[-1]
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[1] % 64 == 0 and d_in % 8 == 0 and d_in >= 64
-            and 0 < x.shape[0] <= 65535 and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
+            and 0 < x.shape[0] <= 65535 and x.data_ptr() % 16 == 0
+            and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
         return False
     b, t = x.shape[0], x.shape[1]
     mask = _contig(mask) if mask is not None else None
@@ -213,7 +218,7 @@ def conv_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, a
     g = _contig(g)
     b, o, h, w = g.shape
     p = h * w
-    if g.is_cuda and g.dtype == torch.bfloat16 and p % 64 == 0 and 0 < b <= 65535:
+    if g.is_cuda and g.dtype == torch.bfloat16 and p % 64 == 0 and 0 < b <= 65535 and g.data_ptr() % 16 == 0:
         # the NCHW gradient IS the operand layout of the covariance kernel: C_out rows of O1*O2 contiguous values per sample
         ws_bytes = nat.lib().kf_syrk_planes_workspace_bytes(o)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)

@@ -418,6 +418,36 @@ def test_score_gemm_long_k_loops(ops, q, b):
         assert rel(scores, want) <= 1e-5, rel(scores, want)
 
 
+def test_contiguous_but_misaligned_views(ops):
+    """A contiguous view that starts 2 bytes into an allocation (``data_ptr() % 16 == 2``) is legal input: ops copies it to an
+    aligned buffer instead of handing the vector loads / LDS-DMA requests an address they cannot take."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    def shifted(t):
+        flat = torch.zeros(t.numel() + 1, dtype=t.dtype, device=DEV)
+        flat[1:] = t.to(DEV).flatten()
+        view = flat[1:].view(t.shape)
+        assert view.is_contiguous() and view.data_ptr() % 16 != 0
+        return view
+
+    b, t, d, o = 3, 64, 72, 64
+    x, g = _rand(b, t, d, dtype=torch.bfloat16), _rand(b, t, o, dtype=torch.bfloat16, seed=1)
+    cov, cnt = torch.zeros(d, d, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.linear_activation_cov(cov, cnt, shifted(x), None, False)
+    assert rel(cov, x.double().flatten(0, 1).t() @ x.double().flatten(0, 1)) <= TOL
+    p = _rand(5, o, d, seed=7).to(torch.bfloat16)
+    scores = torch.zeros(5, b, device=DEV)
+    ops.pairwise_score_rows(scores, 0, TiledQueries(p.to(DEV), 0), shifted(g), shifted(x), False)
+    assert rel(scores, ref.linear_pairwise_score(p.double(), x.double(), g.double(), False)) <= 4e-3
+    gc = _rand(2, 64, 8, 8, dtype=torch.bfloat16, seed=2)
+    gflat, gcount = ref.conv_flat_gradient(gc.double())
+    want = torch.zeros(64, 64, dtype=torch.float64)
+    ref.covariance_update(want, gflat)
+    cov2, cnt2 = torch.zeros(64, 64, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.conv_gradient_cov(cov2, cnt2, shifted(gc))
+    assert rel(cov2, want) <= TOL and int(cnt2) == gcount
+
+
 @pytest.mark.parametrize("n,d", [(300, 128), (5000, 1152), (1030, 264), (64, 16)])
 def test_syrk_bf16_symmetric_engine(ops, n, d):
     """bf16 rows, no mask / bias column: upper-triangular tile pairs on the bf16 TN engine."""
