@@ -18,6 +18,8 @@ using namespace kf;
 
 namespace kf {
 int score_gemm_tiled(float* scores, int64_t ld, const void* P, const void* psg, int64_t Q, int64_t b, int64_t D, float scale, void* stream);
+int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                   float alpha, const float* row_add, int row_add_n, void* stream);
 }
 
 namespace {
@@ -164,6 +166,14 @@ int launch_gemm_bf16(int mode, void* C, int c_dtype, int64_t ldc, int64_t c_batc
                      const HalfExtras* extras = nullptr) {
     if (configure_kernels() != KF_OK) return KF_ERR_LAUNCH_FAILED;
     const int64_t M = A.rows, N = B.rows, K = A.depth;
+    // tall row-major NT product with a bf16 result (the eigenbasis rotations of Lambda / preconditioning): 256 x 256-tile
+    // LDS-DMA kernel (csrc/kf_score_v2.hip) -- 0.55-0.62 PFLOP/s on this engine at those shapes
+    if (mode == 1 && batch == 1 && c_dtype == KF_BF16 && beta == 0.0f && !symmetric && c_tile_stride == 0 && !(extras && extras->mul) &&
+        !A.k_tile_stride && !B.k_tile_stride && K % 64 == 0 && N % 8 == 0 && ldc % 8 == 0 && M < (1LL << 31) - 256 &&
+        (reinterpret_cast<uintptr_t>(C) & 15) == 0 &&
+        cdiv(M, 256) * cdiv(N, 256) >= 512 /* two rounds of one workgroup per CU */ && cdiv(N, 256) * 256 * 100 <= N * 115)
+        return rotate_gemm_v2(C, ldc, A.p, A.row_stride, B.p, B.row_stride, M, N, K, alpha, extras ? extras->row_add : nullptr,
+                              extras ? extras->row_add_n : 0, st);
     const bool batch_sum = (c_batch_stride == 0 && batch > 1 && c_tile_stride == 0);
     const int64_t tm = cdiv(M, 128), tn = cdiv(N, 128);
     const int64_t tiles = (symmetric ? tm * (tm + 1) / 2 : tm * tn) * batch, ksteps = cdiv(K, HBK);

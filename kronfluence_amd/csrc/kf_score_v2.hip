@@ -192,6 +192,113 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
 // not waiting for its DMA requests, so the two-stage form stays.
 
 // ------------------------------------------------------------------------------------------------
+// Rotation GEMM: C[m, n] = alpha * sum_k A[m, k] B[n, k] (+ row_add[n]), bf16 row-major operands (K contiguous) and a bf16
+// row-major result -- the eigenbasis rotations X Q of the Lambda stage and of the preconditioner (tracker/factor.py:218-226,
+// tracker/precondition.py:102-123), where M = samples x positions is huge and K = N = I' (or O) is a few thousand at most.
+// Same 256 x 256 tile / 8 waves / two 64 KB LDS-DMA stages as the score GEMM; no split-K (K is short), the whole result tile
+// goes bf16 through the 128 KB of LDS (XOR-swizzled 16-byte chunks) and out in 16-byte row-major stores.
+// ------------------------------------------------------------------------------------------------
+struct RotateArgs {
+    uint16_t* C; int64_t ldc;
+    const uint16_t* A; int64_t lda;
+    const uint16_t* B; int64_t ldb;
+    int M, N, KT;                 // KT = K / 64
+    int tiles_m, tiles_n;
+    float alpha;
+    const float* row_add; int row_add_n;
+};
+
+__global__ __launch_bounds__(SV2_THREADS) void rotate_gemm_v2_kernel(RotateArgs a) {
+    constexpr int MI = 4, NI = 2, A_BYTES = 256 * 128, STAGE_BYTES = 2 * A_BYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 2, wn = wave & 3;
+    // XCD-aware order: m-major, n-minor items in 8 contiguous runs -- the n-tiles of an m-tile (same A rows) run on one XCD;
+    // B (the eigenvector matrix, a few MB) is L2-resident everywhere
+    const int64_t items = static_cast<int64_t>(a.tiles_m) * a.tiles_n, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int m0 = static_cast<int>(item / a.tiles_n) * 256, n0 = static_cast<int>(item % a.tiles_n) * 256;
+
+    const uint16_t* src_a[4];
+    const uint16_t* src_b[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = (wave * 4 + t) * 8 + (lane >> 3), oct = (lane & 7) ^ lds_swz(row);
+        src_a[t] = a.A + static_cast<int64_t>(min(m0 + row, a.M - 1)) * a.lda + oct * 8;
+        src_b[t] = a.B + static_cast<int64_t>(min(n0 + row, a.N - 1)) * a.ldb + oct * 8;
+    }
+    auto stage_part = [&](int buf, int kt, int part) {  // one of the four A and one of the four B requests of this wave
+        unsigned char* base = sm + buf * STAGE_BYTES;
+        glds16(src_a[part] + kt * 64, base + (wave * 4 + part) * 1024);
+        glds16(src_b[part] + kt * 64, base + A_BYTES + (wave * 4 + part) * 1024);
+    };
+
+    f32x16 acc[MI][NI];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    {
+        const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+#pragma unroll
+        for (int part = 0; part < 4; ++part) stage_part(0, 0, part);
+        __builtin_amdgcn_s_waitcnt(0);
+        __syncthreads();
+        int buf = 0;
+        for (int kt = 0; kt < a.KT; ++kt) {
+            const bool more = kt + 1 < a.KT;
+            const unsigned char* sa = sm + buf * STAGE_BYTES + (wm * 128 + lr) * 128;
+            const unsigned char* sb = sm + buf * STAGE_BYTES + A_BYTES + (wn * 64 + lr) * 128;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                if (more) stage_part(buf ^ 1, kt + 1, kk);
+                const int co = ((kk * 2 + hi) ^ sw) * 16;
+                bf16x8 bv[NI];
+#pragma unroll
+                for (int jn = 0; jn < NI; ++jn) bv[jn] = *reinterpret_cast<const bf16x8*>(sb + jn * 32 * 128 + co);
+#pragma unroll
+                for (int i = 0; i < MI; ++i) {
+                    const bf16x8 av = *reinterpret_cast<const bf16x8*>(sa + i * 32 * 128 + co);
+#pragma unroll
+                    for (int jn = 0; jn < NI; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv[jn], acc[i][jn], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();  // also: every wave is done with the stage buffers before the epilogue reuses them
+            buf ^= 1;
+        }
+    }
+    // epilogue: element (ml, nl) of the tile as bf16 at ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + (nl & 7) * 2
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int jn = 0; jn < NI; ++jn) {
+            const int nl = wn * 64 + jn * 32 + (lane & 31), n = n0 + nl;
+            const float add = (a.row_add && n < a.row_add_n) ? a.row_add[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                uint32_t u = __float_as_uint(a.alpha * acc[i][jn][r] + add);
+                if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;
+                else u += 0x7fffu + ((u >> 16) & 1u);
+                *reinterpret_cast<uint16_t*>(sm + ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + (nl & 7) * 2) = static_cast<uint16_t>(u >> 16);
+            }
+        }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int id = tid + SV2_THREADS * it, ml = id >> 5, ch = id & 31;
+        const int m = m0 + ml, n = n0 + ch * 8;
+        if (m < a.M && n < a.N)  // N % 8 == 0: a chunk is entirely in or out
+            *reinterpret_cast<u32x4*>(a.C + static_cast<int64_t>(m) * a.ldc + n) =
+                *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ch ^ (ml & 31)) << 4));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Per-sample gradient: out[n][m, i] = sum_k A[n][m, k] B[n][i, k], bf16, written k-tile-major over d = m * N + i.
 // 256 threads = 4 wave64 (2 x 2), 128 x 128 tile, k-step 64, two LDS stages of 32 KB -> two workgroups per CU.
 // B rows are plain ([n][i][k]) or implicit-im2col rows of a zero-padded, column-phase-split copy of the input.
@@ -582,6 +689,7 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
@@ -637,6 +745,21 @@ int score_gemm_tiled(float* scores, int64_t ld, const void* P, const void* psg, 
     if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
     return launch_score_v2(scores, ld, reinterpret_cast<const uint16_t*>(P), reinterpret_cast<const uint16_t*>(psg), Q, b, D, scale,
                            as_stream(stream));
+}
+
+// used by the bf16 GEMM entry points (kf_kernels.hip) for large row-major NT products with a bf16 result: see RotateArgs
+int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                   float alpha, const float* row_add, int row_add_n, void* stream) {
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    RotateArgs r;
+    r.C = reinterpret_cast<uint16_t*>(C); r.ldc = ldc; r.A = reinterpret_cast<const uint16_t*>(A); r.lda = lda;
+    r.B = reinterpret_cast<const uint16_t*>(B); r.ldb = ldb;
+    r.M = static_cast<int>(M); r.N = static_cast<int>(N); r.KT = static_cast<int>(K / 64);
+    r.tiles_m = static_cast<int>(cdiv(M, 256)); r.tiles_n = static_cast<int>(cdiv(N, 256));
+    r.alpha = alpha; r.row_add = row_add; r.row_add_n = row_add_n;
+    const int64_t blocks = 8 * cdiv(static_cast<int64_t>(r.tiles_m) * r.tiles_n, 8);
+    hipLaunchKernelGGL(rotate_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), 2 * 512 * 128, as_stream(stream), r);
+    return launch_status();
 }
 }  // namespace kf
 

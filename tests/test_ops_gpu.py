@@ -418,6 +418,24 @@ def test_score_gemm_long_k_loops(ops, q, b):
         assert rel(scores, want) <= 1e-5, rel(scores, want)
 
 
+@pytest.mark.parametrize("n,d,m,bias", [(40000, 1152, 1152, False), (33000, 1600, 1608, True), (70001, 256, 2304, False)])
+def test_rotate_bf16_tall_products(ops, n, d, m, bias):
+    """The rotations ``X Q`` of the Lambda stage at sizes that take the 256 x 256-tile LDS-DMA kernel (>= 512 tiles): ragged last
+    row tile, result width not a multiple of 256, bias row in the epilogue, zero padding rows of ``q_t``; against torch on the
+    same bf16 inputs (one bf16 rounding of the result: 2^-9)."""
+    x = _rand(n, d, dtype=torch.bfloat16).to(DEV)
+    q_t = (_rand(m, d, seed=3) / d ** 0.5).to(torch.bfloat16).to(DEV)
+    if m > d:
+        q_t[d:] = 0  # padding rows -> zero output columns
+    row = _rand(m, seed=5).to(DEV) if bias else None
+    want = x.float() @ q_t.float().t() + (row if bias else 0.0)
+    for _ in range(2):
+        got = ops.rotate_bf16(x, q_t, row)
+        assert got.shape == (n, m) and got.dtype == torch.bfloat16
+        assert rel(got, want) <= 4e-3, rel(got, want)
+        assert rel(got[-300:], want[-300:]) <= 4e-3 and rel(got[:, -40:], want[:, -40:]) <= 4e-3  # the ragged edges
+
+
 def test_contiguous_but_misaligned_views(ops):
     """A contiguous view that starts 2 bytes into an allocation (``data_ptr() % 16 == 2``) is legal input: ops copies it to an
     aligned buffer instead of handing the vector loads / LDS-DMA requests an address they cannot take."""
