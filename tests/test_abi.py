@@ -19,8 +19,9 @@ def _declared_symbols():
 
 def test_header_declares_the_expected_entry_points():
     names = _declared_symbols()
-    for required in ("kf_syrk_accum", "kf_im2col", "kf_gemm", "kf_eigh_f64", "kf_lambda_accum", "kf_inv_lambda",
-                     "kf_precondition", "kf_pairwise_score", "kf_cast", "kf_abi_version"):
+    for required in ("kf_syrk_accum", "kf_syrk_rows_bf16", "kf_syrk_planes_bf16", "kf_conv2d_cov_accum", "kf_im2col", "kf_gemm",
+                     "kf_eigh_f64", "kf_lambda_accum", "kf_inv_lambda", "kf_precondition", "kf_pairwise_score",
+                     "kf_pairwise_score_conv2d", "kf_pairwise_score_rows", "kf_cast", "kf_abi_version"):
         assert required in names
 
 
@@ -77,3 +78,20 @@ def test_product_never_imports_the_oracle():
             if name.endswith(".py"):
                 text = open(os.path.join(base, name)).read()
                 assert "import oracle" not in text and "from oracle" not in text, os.path.join(base, name)
+
+
+def test_operands_are_made_contiguous_and_16_byte_aligned():
+    """``ops._contig`` (every input operand passes through it): strided views are compacted, and a CONTIGUOUS view that starts
+    off a 16-byte boundary is copied -- the vector loads / LDS-DMA requests of the kernels need aligned bases."""
+    from kronfluence_amd import ops
+
+    base = torch.arange(4 * 6 + 1, dtype=torch.float32)
+    aligned = base[:24].view(4, 6)
+    assert ops._contig(aligned) is aligned
+    shifted = base[1:].view(4, 6)  # contiguous, 4 bytes into the allocation
+    assert shifted.is_contiguous() and shifted.data_ptr() % 16 != 0
+    fixed = ops._contig(shifted)
+    assert fixed is not shifted and fixed.data_ptr() % 16 == 0 and torch.equal(fixed, shifted)
+    strided = aligned.t()
+    fixed = ops._contig(strided)
+    assert fixed.is_contiguous() and fixed.data_ptr() % 16 == 0 and torch.equal(fixed, strided)
