@@ -315,9 +315,39 @@ WORKLOADS = {
                       amp=torch.bfloat16, fp32_factors=True, factor_batch=256, train_batch=512, query_batch=109,
                       cpu_sample=dict(n_train=16, n_query=4, n_fit=8)),
     "gpt2_small": dict(model=gpt2_small, kind="lm", vocab=50257, tokens=512, n_train=2048, n_query=1024,
-                       full_n_train=100_000, full_n_query=2000, amp=torch.bfloat16, factor_batch=64, train_batch=128,
+                       full_n_train=100_000, full_n_query=2000, amp=torch.bfloat16, low_cov=True, factor_batch=64, train_batch=128,
                        query_batch=32, cpu_sample=dict(n_train=8, n_query=2, n_fit=4)),
 }
+
+
+def factor_arguments(spec):
+    """The FactorArguments ``bench.py`` runs a workload with (also used by tests/test_configs_gpu.py).  bf16 workloads use
+    the reference's low-precision gradients (per_sample_gradient_dtype / lambda_dtype bf16); the covariances stay fp32 (BERT:
+    "fp32 factors / bf16 grads") unless the workload says ``low_cov`` -- the reference's ``all_low_precision`` preset
+    (utils/common/factor_arguments.py:38-47): hooked tensors are cast to bf16 ahead of the covariance update, so every
+    layer (LayerNorm outputs under autocast are fp32) runs on the bf16 LDS-DMA covariance kernel; accumulation stays fp32."""
+    from kronfluence_amd import FactorArguments
+
+    amp = spec["amp"]
+    extra = {}
+    if amp == torch.bfloat16:
+        extra.update(per_sample_gradient_dtype=torch.bfloat16, lambda_dtype=torch.bfloat16)
+        if spec.get("low_cov"):
+            extra.update(activation_covariance_dtype=torch.bfloat16, gradient_covariance_dtype=torch.bfloat16)
+    return FactorArguments(use_empirical_fisher=True, amp_dtype=amp, **extra)
+
+
+def score_arguments(spec, n_query: int, world: int, per_dev_q: int):
+    """ScoreArguments of a workload: every preconditioned query gradient held resident in HBM (P: n_query x D) -> ONE
+    train pass per step."""
+    from kronfluence_amd import ScoreArguments
+
+    amp = spec["amp"]
+    low = amp == torch.bfloat16
+    accumulate = -(-n_query // (per_dev_q * world))
+    return ScoreArguments(amp_dtype=amp, query_gradient_accumulation_steps=accumulate,
+                          score_dtype=torch.bfloat16 if low else torch.float32,
+                          precondition_dtype=torch.bfloat16 if low else torch.float32)
 
 
 def workload_parts(spec, raw_model):
@@ -378,7 +408,8 @@ def _pmc_traffic(workload: str) -> Optional[dict]:
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int], steps: int, warmup: int,
                  factor_reps: int, cpu_baseline: bool, full_cpu_parity: bool = False) -> dict:
-    from kronfluence_amd import FactorArguments, ScoreArguments, ops, prepare_model
+    from kronfluence_amd import ops, prepare_model
+    from kronfluence_amd.utils import comm
     from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
     from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
     from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
@@ -397,16 +428,10 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     query = make_data(spec, n_query, 2, dev)
     amp = spec["amp"]
     low = amp == torch.bfloat16
-    # bf16 workloads use the reference's low-precision gradients (per_sample_gradient_dtype / lambda_dtype bf16); the
-    # covariances always stay fp32 (at least the reference's precision; BERT: "fp32 factors / bf16 grads")
-    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=amp, **(dict(
-        per_sample_gradient_dtype=torch.bfloat16, lambda_dtype=torch.bfloat16) if low else {}))
+    fargs = factor_arguments(spec)
     per_dev_q = max(1, min(spec["query_batch"], -(-n_query // world)))
-    # hold every preconditioned query gradient resident in HBM (P: n_query x D) -> ONE train pass per step
-    accumulate = -(-n_query // (per_dev_q * world))
-    sargs = ScoreArguments(amp_dtype=amp, query_gradient_accumulation_steps=accumulate,
-                           score_dtype=torch.bfloat16 if low else torch.float32,
-                           precondition_dtype=torch.bfloat16 if low else torch.float32)
+    sargs = score_arguments(spec, n_query, world, per_dev_q)
+    accumulate = sargs.query_gradient_accumulation_steps
     layers = tracked_shapes(model)
     D = sum(o * ip for o, ip in layers)
 
@@ -453,6 +478,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     passes = factor_reps + 1 if factor_reps > 0 else 1  # first pass = warm-up; --factor-reps 0: single cold pass
     for index in range(passes):
         ops.EVENT_LOG = {} if index == passes - 1 else None
+        comm.EXCHANGE_LOG = {} if (index == passes - 1 and world > 1) else None
         t_cov, (_, cov) = timed(lambda: fit_covariance_matrices_with_loader(model, state, task, factor_loader(), fargs,
                                                                              all_ranks=True, cpu=False))
         t_eig, eig = timed(lambda: perform_eigendecomposition(cov, model, state, fargs, cpu=False))
@@ -460,6 +486,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                                                                          all_ranks=True, cpu=False))
         fit_times = {"covariance": t_cov, "eigendecomposition": t_eig, "lambda": t_lam}
         fit_events, ops.EVENT_LOG = (ops.EVENT_LOG or {}), None
+        fit_exchanges, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
     factors = {k: {n: v.to(dev) for n, v in d.items()} for k, d in {**eig, **lam}.items()}
     eig_dims = sorted({int(v.shape[0]) for d in (cov["activation_covariance"], cov["gradient_covariance"]) for v in d.values()})
     del cov
@@ -475,6 +502,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     gc.collect()
     gc.disable()  # no cyclic-GC pause between steps either (the stage loops already pause it inside a stage)
     ops.EVENT_LOG = {}
+    comm.EXCHANGE_LOG = {} if world > 1 else None
     seg0 = torch.cuda.memory_stats().get("segment.all.allocated", 0)
     barrier()
     t0 = time.perf_counter()
@@ -493,6 +521,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     score_events, ops.EVENT_LOG = ops.EVENT_LOG, None
+    score_exchanges, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
     pairs = float(n_query) * float(n_train) * steps
     value = pairs / elapsed
     if rank == 0:
@@ -581,6 +610,10 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             "factor_fit": {"samples_per_sec": n_train / fit_total, "seconds": fit_times, "n_fit": n_train,
                            "eigen_dims": eig_dims},
             "peak_hbm_gib": round(peak_mem, 1),
+            # rank 0's collectives (RCCL over xGMI; all inside the timed regions): seconds are stream time between events
+            # around each call -- for the query all-gather only the wait still exposed after overlapping with backward
+            "exchanges": ({"backend": dist.get_backend(), "ranks": world, "factor_fit": fit_exchanges,
+                           "pairwise_timed_steps": score_exchanges} if world > 1 else None),
             "cpu_baseline": cpu,
         }
     del factors, eig, lam, model, train, query, scores
@@ -588,6 +621,24 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
     return result
+
+
+def _respawn_under_torchrun(gpus: int) -> None:
+    """``python bench.py --gpus N`` typed WITHOUT a launcher (no ``WORLD_SIZE``): re-execute this very command line as
+    N ranks of one node under ``torch.distributed.run`` (one process per GPU, RCCL) and relay its output -- rank 0 of the
+    child job prints the JSON line."""
+    import socket
+    import subprocess
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as probe:
+        probe.bind(("127.0.0.1", 0))
+        port = probe.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC for RCCL / cross-process tensors on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // gpus)))
+    command = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(command, env=env))
 
 
 def main() -> None:
@@ -606,6 +657,8 @@ def main() -> None:
                     "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
                     "907 -> 862 ms; nothing of the EK-FAC path is affected)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        _respawn_under_torchrun(args.gpus)
     if args.train_batch:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
     if not args.no_miopen_find:
@@ -618,13 +671,13 @@ def main() -> None:
     state = State()
     world, rank = state.num_processes, state.process_index
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run for N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     line = run_workload(args.workload, state, args.n_train, args.n_query, args.steps, args.warmup, args.factor_reps,
                         cpu_baseline=not args.no_cpu_baseline)
-    extras = (world == 1 and args.workload == "resnet9" and args.n_train is None and args.n_query is None
-              and not args.no_extras and os.environ.get("KF_BENCH_EXTRAS", "1") != "0")
-    if extras:
+    default_run = (args.workload == "resnet9" and args.n_train is None and args.n_query is None and not args.no_extras
+                   and os.environ.get("KF_BENCH_EXTRAS", "1") != "0")
+    if default_run and world == 1:
         # north-star target: >= 10x reference-CPU pairs/s on MNIST-MLP at 1 GPU with scores within 1e-4 -- the CPU oracle
         # runs the FULL 100 x 1000 workload on the same factors, so the score error is part of the same line
         m = run_workload("mnist_mlp", state, None, None, steps=10, warmup=2, factor_reps=1, cpu_baseline=True)
@@ -635,20 +688,27 @@ def main() -> None:
             "scores_rel_F_vs_cpu_oracle": m["cpu_baseline"].get("gpu_vs_cpu_scores_rel_F"), "damping": 1e-8,
             "target_rel": 1e-4, "roofline": m["roofline"], "factor_fit": m["factor_fit"],
         }}
-        line["other_configs"] = {}
-        for other in ("bert_base", "gpt2_small"):
+    if default_run:
+        # N = 1: BERT-base and GPT-2-small at bounded sizes.  N > 1: GPT-2-small only -- the config the north-star scaling
+        # target (>= 6x strong scaling 1 -> 8) is stated on -- sharded like the headline, same fixed size at every N.
+        others = ("bert_base", "gpt2_small") if world == 1 else ("gpt2_small",)
+        extras: Dict[str, dict] = {}
+        for other in others:
             try:
                 # factor_reps=1: the reported fit is the second, warm one (the first GPT-2 covariance pass alone spends ~5 s in
                 # first-touch allocations and GEMM heuristics)
                 r = run_workload(other, state, None, None, steps=1, warmup=1, factor_reps=1, cpu_baseline=False)
-                line["other_configs"][other] = {k: r[k] for k in ("value", "unit", "ms_per_step", "config", "roofline",
-                                                                   "roofline_cov", "roofline_lambda", "factor_fit", "peak_hbm_gib")}
+                if rank == 0:
+                    extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline",
+                                                      "roofline_cov", "roofline_lambda", "factor_fit", "exchanges", "peak_hbm_gib")}
             except Exception as error:  # an extra must never take the headline down with it
-                line["other_configs"][other] = {"error": f"{type(error).__name__}: {error}"[:300]}
+                extras[other] = {"error": f"{type(error).__name__}: {error}"[:300]}
                 gc.collect()
                 torch.cuda.empty_cache()
+        if rank == 0:
+            line["other_configs"] = extras
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

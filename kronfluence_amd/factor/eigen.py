@@ -24,6 +24,7 @@ from kronfluence_amd.module.utils import (
     synchronize_factors, update_factor_args,
 )
 from kronfluence_amd.task import Task
+from kronfluence_amd.utils.comm import exchange
 from kronfluence_amd.utils.constants import (
     ACTIVATION_COVARIANCE_MATRIX_NAME, ACTIVATION_EIGENVALUES_NAME, ACTIVATION_EIGENVECTORS_NAME,
     EIGENDECOMPOSITION_FACTOR_NAMES, FACTOR_TYPE, GRADIENT_COVARIANCE_MATRIX_NAME, GRADIENT_EIGENVALUES_NAME,
@@ -155,8 +156,9 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
             evals = torch.empty(d, dtype=original_dtype, device=state.device)
             evecs = torch.empty((d, d), dtype=original_dtype, device=state.device)
         if world > 1:
-            dist.broadcast(evals, src=owner)
-            dist.broadcast(evecs, src=owner)
+            with exchange("eigen_broadcast", (evals.numel() + evecs.numel()) * evecs.element_size()):
+                dist.broadcast(evals, src=owner)
+                dist.broadcast(evecs, src=owner)
         target = "cpu" if cpu else state.device
         out[val_name][module_name] = evals.to(device=target).contiguous()
         out[vec_name][module_name] = evecs.to(device=target).contiguous()

@@ -44,6 +44,16 @@ def _all_reduce_sum(tensors) -> None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
 
+def _to_covariance_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
+    """The reference casts the hooked tensor to ``activation_covariance_dtype`` / ``gradient_covariance_dtype`` ahead of the
+    update (tracker/factor.py:101-107, 118).  Here the accumulator is fp32 whatever that dtype and the kernels take bf16 /
+    fp16 / fp32 rows with exact products, so only a NARROWING cast changes the result -- and it moves e.g. the fp32 LayerNorm
+    outputs of an autocast model onto the bf16 LDS-DMA covariance kernel under the reference's low-precision presets."""
+    if dtype in (torch.bfloat16, torch.float16) and t.is_floating_point() and t.dtype != dtype:
+        return t.to(dtype)
+    return t
+
+
 class CovarianceTracker(BaseTracker):
     def register_hooks(self) -> None:
         module = self.module
@@ -54,7 +64,7 @@ class CovarianceTracker(BaseTracker):
             del mod
             cov, count = module.accumulate_activation_covariance(
                 storage[ACTIVATION_COVARIANCE_MATRIX_NAME], storage[NUM_ACTIVATION_COVARIANCE_PROCESSED],
-                inputs[0].detach())
+                _to_covariance_dtype(inputs[0].detach(), module.factor_args.activation_covariance_dtype))
             storage[ACTIVATION_COVARIANCE_MATRIX_NAME] = cov
             storage[NUM_ACTIVATION_COVARIANCE_PROCESSED] = count
             self.cached_hooks.append(outputs.register_hook(backward_hook))
@@ -65,7 +75,7 @@ class CovarianceTracker(BaseTracker):
             alpha = module.gradient_scale**2.0 if module.gradient_scale != 1.0 else 1.0  # factor.py:90-92
             cov, count = module.accumulate_gradient_covariance(
                 storage[GRADIENT_COVARIANCE_MATRIX_NAME], storage[NUM_GRADIENT_COVARIANCE_PROCESSED],
-                output_gradient.detach(), alpha)
+                _to_covariance_dtype(output_gradient.detach(), module.factor_args.gradient_covariance_dtype), alpha)
             storage[GRADIENT_COVARIANCE_MATRIX_NAME] = cov
             storage[NUM_GRADIENT_COVARIANCE_PROCESSED] = count
 

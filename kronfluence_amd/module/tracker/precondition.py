@@ -16,6 +16,7 @@ from torch import nn
 from kronfluence_amd import ops
 from kronfluence_amd.factor.config import FactorConfig
 from kronfluence_amd.module.tracker.base import BaseTracker, QueryBlocks, QueryBuffer
+from kronfluence_amd.utils.comm import exchange
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
     AGGREGATED_GRADIENT_NAME,
@@ -34,6 +35,13 @@ class PreconditionTracker(BaseTracker):
     # was 70 % of the MNIST-MLP pairwise stage).  `storage["preconditioned_gradient"]` then holds M_q; set this
     # to False to store the reference's P_q.
     EIGENBASIS_QUERIES = True
+
+    # Multi-GPU: the all-gather of a layer's block (C4, reference precondition.py:181-201) is ISSUED from the backward hook
+    # that produced it, asynchronously -- it travels over xGMI while autograd runs the remaining layers' backward and their
+    # preconditioners -- and ``synchronize`` only waits for it and interleaves.  All ranks run the same graph, so the
+    # collectives are issued in the same order everywhere.
+    ASYNC_QUERY_GATHER = True
+    _pending = None  # (work, gathered, local) of the all-gather in flight
 
     def _out_dtype(self) -> torch.dtype:
         """``score_dtype`` of the reference (precondition.py:73): bf16 keeps P in bf16 for the bf16 MFMA
@@ -59,7 +67,7 @@ class PreconditionTracker(BaseTracker):
                             padded.t().contiguous().to(torch.bfloat16))
         return self._bf16_q[1], self._bf16_q[2], self._bf16_q[3]
 
-    def _store(self, preconditioned: torch.Tensor) -> None:
+    def _store(self, preconditioned: torch.Tensor, from_hook: bool = False) -> None:
         """Keeps the ``[q, O, I']`` block, or -- with ``query_gradient_low_rank = k < min(O, I')`` -- its rank-k factors
         ``[left [q,O,k], right [q,k,I']]`` (reference ``precondition.py:19-75``; ``use_full_svd`` buys two more
         subspace iterations instead of a dense SVD)."""
@@ -77,7 +85,13 @@ class PreconditionTracker(BaseTracker):
             return
         if preconditioned.dtype != self._out_dtype():
             preconditioned = preconditioned.to(self._out_dtype())
+        preconditioned = preconditioned.contiguous()
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = preconditioned
+        if from_hook and self.ASYNC_QUERY_GATHER and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            local = preconditioned
+            world = dist.get_world_size()
+            gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            self._pending = (dist.all_gather_into_tensor(gathered, local, async_op=True), gathered, local)
 
     def register_hooks(self) -> None:
         module = self.module
@@ -106,7 +120,7 @@ class PreconditionTracker(BaseTracker):
                              alpha=module.gradient_scale, mul=storage[LAMBDA_MATRIX_NAME])
                     module.queries_in_eigenbasis = True
                     module.query_padding = 0
-                    self._store(rotated)
+                    self._store(rotated, from_hook=True)
                     return
                 module.queries_in_eigenbasis = False
                 qa16, qgt16, qat16 = self._bf16_eigenvectors()
@@ -117,7 +131,7 @@ class PreconditionTracker(BaseTracker):
                 # the bf16 engine hands back rows zero-padded to a multiple of 8 (odd I'); the score trackers consume that
                 # width as it is, every other reader strips it (``unpadded_queries``)
                 module.query_padding = out.shape[-1] - (a.shape[-1] + int(ones))
-                self._store(out)
+                self._store(out, from_hook=True)
             else:
                 module.queries_in_eigenbasis = False
                 module.query_padding = 0
@@ -125,7 +139,7 @@ class PreconditionTracker(BaseTracker):
                 out = FactorConfig.CONFIGS[module.factor_args.strategy].precondition_gradient(psg, storage)
                 if module.gradient_scale != 1.0:
                     out.mul_(module.gradient_scale)
-                self._store(out)
+                self._store(out, from_hook=True)
 
         @torch.no_grad()
         def shared_backward_hook(output_gradient: torch.Tensor) -> None:
@@ -157,13 +171,19 @@ class PreconditionTracker(BaseTracker):
                 or storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] is not None)
 
     @staticmethod
-    def _gather_interleaved(local: torch.Tensor, num_processes: int) -> torch.Tensor:
+    def _interleave(gathered: torch.Tensor, q: int, num_processes: int) -> torch.Tensor:
+        """rank-major ``[P * q, ...]`` -> row ``j * P + r`` = rank ``r``'s ``j``-th query."""
+        stacked = gathered.reshape((num_processes, q) + tuple(gathered.shape[1:]))
+        return stacked.transpose(0, 1).reshape((num_processes * q,) + tuple(gathered.shape[1:]))
+
+    @classmethod
+    def _gather_interleaved(cls, local: torch.Tensor, num_processes: int) -> torch.Tensor:
         local = local.contiguous()
         q = local.shape[0]
         gathered = torch.empty((num_processes * q,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-        dist.all_gather_into_tensor(gathered, local)  # rank-major concatenation (layout both RCCL and gloo accept)
-        stacked = gathered.reshape((num_processes, q) + tuple(local.shape[1:]))
-        return stacked.transpose(0, 1).reshape((num_processes * q,) + tuple(local.shape[1:]))
+        with exchange("query_all_gather", gathered.numel() * gathered.element_size()):
+            dist.all_gather_into_tensor(gathered, local)  # rank-major concatenation (layout both RCCL and gloo accept)
+        return cls._interleave(gathered, q, num_processes)
 
     def synchronize(self, num_processes: int = 1) -> None:
         """C4: all-gather the ``[q, O, I']`` block (or both low-rank factors) of every rank and interleave so that
@@ -171,8 +191,17 @@ class PreconditionTracker(BaseTracker):
         (reference ``precondition.py:181-201``)."""
         storage = self.module.storage
         local = storage[PRECONDITIONED_GRADIENT_NAME]
+        pending, self._pending = self._pending, None
         if not dist.is_initialized() or local is None:
             return
+        if pending is not None and pending[2] is local:  # issued from the backward hook: only the exposed wait is left
+            work, gathered, _ = pending
+            with exchange("query_all_gather", gathered.numel() * gathered.element_size()):
+                work.wait()
+            storage[PRECONDITIONED_GRADIENT_NAME] = self._interleave(gathered, local.shape[0], num_processes)
+            return
+        if pending is not None:
+            pending[0].wait()
         if isinstance(local, list):
             storage[PRECONDITIONED_GRADIENT_NAME] = [self._gather_interleaved(t, num_processes) for t in local]
         else:
@@ -220,6 +249,9 @@ class PreconditionTracker(BaseTracker):
         self.accumulate_iterations()
 
     def release_memory(self) -> None:
+        if self._pending is not None:
+            self._pending[0].wait()
+            self._pending = None
         self._bf16_q = None
         self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None

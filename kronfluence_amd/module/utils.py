@@ -15,6 +15,7 @@ from kronfluence_amd.module.conv2d import TrackedConv2d  # noqa: F401  (register
 from kronfluence_amd.module.linear import TrackedLinear  # noqa: F401  (registers nn.Linear)
 from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
 from kronfluence_amd.task import Task
+from kronfluence_amd.utils.comm import exchange
 from kronfluence_amd.utils.constants import FACTOR_TYPE
 from kronfluence_amd.utils.exceptions import IllegalTaskConfigurationError, TrackedModuleNotFoundError
 
@@ -174,7 +175,8 @@ def synchronize_factors(model: nn.Module, factor_names: List[str], tracked_modul
         if not tensors:
             return
         flat = torch.cat([t.reshape(-1).to(device=device, dtype=dtype) for t in tensors])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        with exchange("factor_all_reduce", flat.numel() * flat.element_size()):
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
         offset = 0
         for item, t in zip(group, tensors):
             n = t.numel()
@@ -191,7 +193,8 @@ def synchronize_factors(model: nn.Module, factor_names: List[str], tracked_modul
         t = item[2]
         size = t.numel() * 4
         if size > limit and t.dtype == torch.float32 and t.device == device and t.is_contiguous():
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)  # big enough on its own: no staging copy
+            with exchange("factor_all_reduce", size):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)  # big enough on its own: no staging copy
             continue
         if bucket and held + size > limit:
             reduce_bucket(bucket, torch.float32)

@@ -19,6 +19,13 @@ from kronfluence_amd import _native as nat
 from kronfluence_amd._native import kf_view
 
 
+def _require(condition, what: str) -> None:
+    """Argument validation that survives ``python -O`` (an ``assert`` does not): a violated precondition of the C ABI is a
+    ``KfError`` like every other failure of this layer."""
+    if not condition:
+        raise nat.KfError(f"invalid argument: {what}")
+
+
 def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
@@ -34,7 +41,7 @@ def _contig(t: torch.Tensor) -> torch.Tensor:
 def view(t: torch.Tensor, batch_stride: int, row_stride: int, k_stride: int, rows: int, depth: int,
          ones_row: bool = False, ones_k: bool = False, square: bool = False, k_tile_stride: int = 0) -> kf_view:
     """Strided operand view over the STORAGE of ``t`` (strides in elements); ``t`` must be contiguous."""
-    assert t.is_contiguous(), "kf_view describes raw storage; pass a contiguous tensor"
+    _require(t.is_contiguous(), "kf_view describes raw storage; pass a contiguous tensor")
     return kf_view(t.data_ptr(), nat.dtype_code(t.dtype), batch_stride, row_stride, k_stride, rows, depth,
                    int(ones_row), int(ones_k), int(square), k_tile_stride)
 
@@ -44,7 +51,7 @@ def k_tile_major(p: torch.Tensor) -> torch.Tensor:
     (see ``kf_view.k_tile_stride``).  ``D`` must be a multiple of 64."""
     rows = p.shape[0]
     flat = p.reshape(rows, -1)
-    assert flat.shape[1] % 64 == 0
+    _require(flat.shape[1] % 64 == 0, 'flat.shape[1] % 64 == 0')
     return flat.view(rows, flat.shape[1] // 64, 64).transpose(0, 1).contiguous()
 
 
@@ -57,14 +64,14 @@ def syrk_accum(cov: torch.Tensor, x: torch.Tensor, n_rows: int, d_in: int, rows_
     """``cov += alpha * X'^T X'`` (kf_syrk_accum).  ``cov``: fp32 ``[d, d]`` device tensor."""
     nat.require_device(cov, "cov")
     nat.require_device(x, "x")
-    assert cov.dtype == torch.float32 and cov.is_contiguous()
+    _require(cov.dtype == torch.float32 and cov.is_contiguous(), 'cov.dtype == torch.float32 and cov.is_contiguous()')
     if mask is not None:
         nat.require_device(mask, "mask")
         mask = _contig(mask)
-        assert mask.numel() == n_rows
+        _require(mask.numel() == n_rows, 'mask.numel() == n_rows')
     if count is not None:
         nat.require_device(count, "count")
-        assert count.dtype == torch.int64
+        _require(count.dtype == torch.int64, 'count.dtype == torch.int64')
     d = d_in + int(append_ones)
     with _Timed("syrk_accum", x.device, float(n_rows) * d * (d + 1), float(n_rows) * d_in * x.element_size()):
         nat.check(
@@ -244,7 +251,7 @@ def conv_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, a
 def gemm(c: torch.Tensor, ldc: int, c_batch_stride: int, a: kf_view, b: kf_view, batch: int = 1, alpha: float = 1.0,
          beta: float = 0.0, mul: Optional[torch.Tensor] = None) -> None:
     nat.require_device(c, "c")
-    assert c.dtype == torch.float32
+    _require(c.dtype == torch.float32, 'c.dtype == torch.float32')
     nat.check(
         nat.lib().kf_gemm(c.data_ptr(), ldc, c_batch_stride, ctypes.byref(a), ctypes.byref(b), batch, alpha, beta,
                           _ptr(mul), mul.shape[-1] if mul is not None else 0, nat.stream_ptr(c.device)),
@@ -270,7 +277,7 @@ def rotate_bf16(x: torch.Tensor, q_t: torch.Tensor, bias_row: Optional[torch.Ten
     x, q_t = _contig(x), _contig(q_t)
     n, d = x.shape
     m, ld = q_t.shape
-    assert ld >= d and x.dtype == q_t.dtype == torch.bfloat16
+    _require(ld >= d and x.dtype == q_t.dtype == torch.bfloat16, 'ld >= d and x.dtype == q_t.dtype == torch.bfloat16')
     out = torch.empty((n, m), dtype=torch.bfloat16, device=x.device)
     nat.require_device(x, "x")
     if bias_row is None:
@@ -281,7 +288,7 @@ def rotate_bf16(x: torch.Tensor, q_t: torch.Tensor, bias_row: Optional[torch.Ten
         )
         return out
     bias_row = _contig(bias_row)
-    assert bias_row.dtype == torch.float32 and bias_row.numel() <= m
+    _require(bias_row.dtype == torch.float32 and bias_row.numel() <= m, 'bias_row.dtype == torch.float32 and bias_row.numel() <= m')
     nat.check(
         nat.lib().kf_gemm_bias_out(out.data_ptr(), m, ctypes.byref(view(x, 0, d, 1, n, d)), ctypes.byref(view(q_t, 0, ld, 1, m, d)),
                                    bias_row.data_ptr(), bias_row.numel(), nat.stream_ptr(x.device)),
@@ -307,7 +314,7 @@ def per_sample_gradient(g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> 
 def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """fp64 ``eigh(0.5 (cov + cov^T) / count)`` (factor/eigen.py:193-205) -> (evals, evecs, sweeps)."""
     nat.require_device(cov, "cov")
-    assert cov.dim() == 2 and cov.shape[0] == cov.shape[1] and cov.dtype in (torch.float32, torch.float64)
+    _require(cov.dim() == 2 and cov.shape[0] == cov.shape[1] and cov.dtype in (torch.float32, torch.float64), 'cov.dim() == 2 and cov.shape[0] == cov.shape[1] and cov.dtype in (torch.float32, torch.float64)')
     cov = _contig(cov)
     d = cov.shape[0]
     evals = torch.empty(d, dtype=torch.float64, device=cov.device)
@@ -332,7 +339,7 @@ def eigh_small(g: torch.Tensor, inv_sqrt: bool = False, floor_rel: float = 1e-12
     nat.require_device(g, "g")
     g = _contig(g)
     batch, l, l2 = g.shape
-    assert g.dtype == torch.float32 and l == l2 and l <= EIGH_SMALL_MAX
+    _require(g.dtype == torch.float32 and l == l2 and l <= EIGH_SMALL_MAX, 'g.dtype == torch.float32 and l == l2 and l <= EIGH_SMALL_MAX')
     evals = torch.empty((batch, l), dtype=torch.float32, device=g.device)
     evecs = torch.empty((batch, l, l), dtype=torch.float32, device=g.device)
     nat.check(
@@ -362,7 +369,7 @@ def low_rank_factors(p: torch.Tensor, rank: int, power_iterations: int = 2, over
     ``orth(Y) = Y V S^-1`` from the eigendecomposition of the ``l x l`` Gram matrix ``Y^T Y`` (``l = rank + oversample``,
     capped by ``min(O, I')`` -- where the range finder, hence the truncated SVD, is exact)."""
     p = _contig(p)
-    assert p.dtype == torch.float32 and p.dim() == 3
+    _require(p.dtype == torch.float32 and p.dim() == 3, 'p.dtype == torch.float32 and p.dim() == 3')
     q, o, ip = p.shape
     l = min(rank + oversample, o, ip, EIGH_SMALL_MAX)
     k = min(rank, l)
@@ -408,11 +415,11 @@ def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, 
     """``lam += sum_b (Gt_b^T At_b)^2`` with rotated factors (kf_lambda_accum; tracker/factor.py:218-226).  ``at`` may be
     wider than ``lam`` (bf16 rows zero-padded to a multiple of 8, see ``rotate_bf16``)."""
     nat.require_device(lam, "lam")
-    assert lam.dtype == torch.float32 and gt.dtype == at.dtype and gt.dtype in (torch.float32, torch.bfloat16)
-    assert gt.is_contiguous() and at.is_contiguous()
+    _require(lam.dtype == torch.float32 and gt.dtype == at.dtype and gt.dtype in (torch.float32, torch.bfloat16), 'lam.dtype == torch.float32 and gt.dtype == at.dtype and gt.dtype in (torch.float32, torch.bfloat16)')
+    _require(gt.is_contiguous() and at.is_contiguous(), 'gt.is_contiguous() and at.is_contiguous()')
     o, ip = lam.shape
     ld_at = at.shape[-1]
-    assert gt.numel() == b * r * o and at.numel() == b * r * ld_at and ld_at >= ip
+    _require(gt.numel() == b * r * o and at.numel() == b * r * ld_at and ld_at >= ip, 'gt.numel() == b * r * o and at.numel() == b * r * ld_at and ld_at >= ip')
     # the product of the rotated factors, squared and summed (the rotations themselves are kf_gemm calls)
     with _Timed("lambda_accum", lam.device, 2.0 * b * r * o * ip, float(b) * r * (o + ip) * gt.element_size()):
         nat.check(
@@ -452,16 +459,16 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     q, r, o = g.shape
     i = a.shape[2]
     ip = i + int(append_ones)
-    assert q_g.shape == (o, o) and q_a.shape == (ip, ip) and lam_inv.shape == (o, ip)
-    assert q_g.dtype == q_a.dtype == lam_inv.dtype == torch.float32 and g.dtype == a.dtype
+    _require(q_g.shape == (o, o) and q_a.shape == (ip, ip) and lam_inv.shape == (o, ip), 'q_g.shape == (o, o) and q_a.shape == (ip, ip) and lam_inv.shape == (o, ip)')
+    _require(q_g.dtype == q_a.dtype == lam_inv.dtype == torch.float32 and g.dtype == a.dtype, 'q_g.dtype == q_a.dtype == lam_inv.dtype == torch.float32 and g.dtype == a.dtype')
     q_g, q_a, lam_inv = _contig(q_g), _contig(q_a), _contig(lam_inv)  # keep the contiguous copies alive
-    assert out_dtype in (torch.float32, torch.bfloat16)
+    _require(out_dtype in (torch.float32, torch.bfloat16), 'out_dtype in (torch.float32, torch.bfloat16)')
     width, ldq = ip, ip
     low = (q_a_bf16 is not None and q_g_t_bf16 is not None and q_a_t_bf16 is not None and out_dtype == torch.bfloat16
            and g.dtype == torch.bfloat16 and r > 1 and o % 8 == 0 and i % 8 == 0 and i >= 64 and o >= 64)
     if low:
         ldq = q_a_bf16.shape[0]
-        assert q_a_bf16.shape == q_a_t_bf16.shape == (ldq, ldq) and ldq % 8 == 0 and ip <= ldq < ip + 8
+        _require(q_a_bf16.shape == q_a_t_bf16.shape == (ldq, ldq) and ldq % 8 == 0 and ip <= ldq < ip + 8, 'q_a_bf16.shape == q_a_t_bf16.shape == (ldq, ldq) and ldq % 8 == 0 and ip <= ldq < ip + 8')
         width = ldq
     else:
         q_a_bf16 = q_g_t_bf16 = q_a_t_bf16 = None
@@ -515,15 +522,15 @@ def pairwise_score(scores: torch.Tensor, col_offset: int, p, g: torch.Tensor, a:
     tiled = getattr(p, "tiled", None)
     storage = tiled if tiled is not None else p
     nat.require_device(storage, "p")
-    assert scores.dtype == torch.float32 and storage.dtype in (torch.float32, torch.bfloat16)
-    assert scores.is_contiguous() and storage.is_contiguous()
+    _require(scores.dtype == torch.float32 and storage.dtype in (torch.float32, torch.bfloat16), 'scores.dtype == torch.float32 and storage.dtype in (torch.float32, torch.bfloat16)')
+    _require(scores.is_contiguous() and storage.is_contiguous(), 'scores.is_contiguous() and storage.is_contiguous()')
     g, a = _contig(g), _contig(a)
-    assert g.dtype == a.dtype
+    _require(g.dtype == a.dtype, 'g.dtype == a.dtype')
     b, r, o = g.shape
     i = a.shape[2]
     ip = i + int(append_ones)
     q = p.shape[0]
-    assert p.shape[1] == o and p.shape[2] == ip and scores.shape[0] == q and col_offset + b <= scores.shape[1]
+    _require(p.shape[1] == o and p.shape[2] == ip and scores.shape[0] == q and col_offset + b <= scores.shape[1], 'p.shape[1] == o and p.shape[2] == ip and scores.shape[0] == q and col_offset + b <= scores.shape[1]')
     ws_bytes = nat.lib().kf_pairwise_workspace_bytes(b, r, o, ip)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
     flops = 2.0 * q * b * o * ip + (2.0 * b * r * o * ip if r > 1 else 0.0)
@@ -559,14 +566,14 @@ def pairwise_score_conv2d(scores: torch.Tensor, col_offset: int, p, g_nchw: torc
     nat.require_device(scores, "scores")
     nat.require_device(g_nchw, "g_nchw")
     g_nchw, x = _contig(g_nchw), _contig(x)
-    assert g_nchw.dtype == x.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32
+    _require(g_nchw.dtype == x.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32, 'g_nchw.dtype == x.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32')
     b, c, h, w = x.shape
     o, o1, o2 = g_nchw.shape[1], g_nchw.shape[2], g_nchw.shape[3]
     geometry = conv2d_score_geometry(x.shape, o, conv)
-    assert geometry is not None, "layer not eligible for the implicit-im2col path"
+    _require(geometry is not None, "layer not eligible for the implicit-im2col path")
     k1, k2 = geometry[5], geometry[6]
     q, ip = p.shape[0], (c + (-c) % 8) * k1 * k2
-    assert p.shape == (q, o, ip) and scores.shape[0] == q and col_offset + b <= scores.shape[1]
+    _require(p.shape == (q, o, ip) and scores.shape[0] == q and col_offset + b <= scores.shape[1], 'p.shape == (q, o, ip) and scores.shape[0] == q and col_offset + b <= scores.shape[1]')
     ws_bytes = nat.lib().kf_pairwise_conv2d_workspace_bytes(*geometry)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     r, real_ip = o1 * o2, c * k1 * k2
@@ -589,11 +596,11 @@ def pairwise_score_rows(scores: torch.Tensor, col_offset: int, p, g: torch.Tenso
     nat.require_device(scores, "scores")
     nat.require_device(g, "g")
     g, a = _contig(g), _contig(a)
-    assert g.dtype == a.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32
+    _require(g.dtype == a.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32, 'g.dtype == a.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32')
     b, r, o = g.shape
     i = a.shape[2]
     q, ipp = p.shape[0], p.shape[2]
-    assert p.shape[1] == o and scores.shape[0] == q and col_offset + b <= scores.shape[1]
+    _require(p.shape[1] == o and scores.shape[0] == q and col_offset + b <= scores.shape[1], 'p.shape[1] == o and scores.shape[0] == q and col_offset + b <= scores.shape[1]')
     ws_bytes = nat.lib().kf_pairwise_rows_workspace_bytes(b, r, o, ipp)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
     ip = i + int(append_ones)
@@ -618,12 +625,12 @@ def rowwise_dot(out: torch.Tensor, x: torch.Tensor, y: torch.Tensor, weight: Opt
     x, y = _contig(x), _contig(y)
     rows = x.shape[0]
     d = x.numel() // max(rows, 1)
-    assert out.dtype == torch.float32 and out.is_contiguous() and out.numel() == rows and y.numel() == x.numel()
-    assert x.dtype in (torch.float32, torch.bfloat16) and y.dtype in (torch.float32, torch.bfloat16)
+    _require(out.dtype == torch.float32 and out.is_contiguous() and out.numel() == rows and y.numel() == x.numel(), 'out.dtype == torch.float32 and out.is_contiguous() and out.numel() == rows and y.numel() == x.numel()')
+    _require(x.dtype in (torch.float32, torch.bfloat16) and y.dtype in (torch.float32, torch.bfloat16), 'x.dtype in (torch.float32, torch.bfloat16) and y.dtype in (torch.float32, torch.bfloat16)')
     if weight is not None:
         nat.require_device(weight, "weight")
         weight = _contig(weight)
-        assert weight.dtype == torch.float32 and weight.numel() == d
+        _require(weight.dtype == torch.float32 and weight.numel() == d, 'weight.dtype == torch.float32 and weight.numel() == d')
     nat.check(
         nat.lib().kf_rowwise_dot(out.data_ptr(), x.data_ptr(), nat.dtype_code(x.dtype), y.data_ptr(), nat.dtype_code(y.dtype),
                                  _ptr(weight), rows, d, scale, int(accumulate), nat.stream_ptr(x.device)),
@@ -639,7 +646,7 @@ def mul_bcast(x: torch.Tensor, m: torch.Tensor, scale: float = 1.0) -> torch.Ten
     x, m = _contig(x), _contig(m)
     rows = x.shape[0]
     d = m.numel()
-    assert m.dtype == torch.float32 and x.numel() == rows * d and x.dtype in (torch.float32, torch.bfloat16)
+    _require(m.dtype == torch.float32 and x.numel() == rows * d and x.dtype in (torch.float32, torch.bfloat16), 'm.dtype == torch.float32 and x.numel() == rows * d and x.dtype in (torch.float32, torch.bfloat16)')
     out = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     nat.check(
         nat.lib().kf_mul_bcast(out.data_ptr(), x.data_ptr(), nat.dtype_code(x.dtype), m.data_ptr(), rows, d, scale,

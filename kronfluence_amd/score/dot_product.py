@@ -21,6 +21,7 @@ from kronfluence_amd.module.utils import (
     finalize_all_iterations, finalize_iteration, set_mode, set_score_sink, synchronize_modules,
 )
 from kronfluence_amd.task import Task
+from kronfluence_amd.utils.comm import exchange
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, AGGREGATED_GRADIENT_NAME, ALL_MODULE_NAME, SCORE_TYPE,
 )
@@ -34,7 +35,8 @@ def gather_score_blocks(block: torch.Tensor, state: State, dataset_size: int) ->
     if not state.use_distributed:
         return block[:, :dataset_size].cpu()
     gather_list = [torch.empty_like(block) for _ in range(state.num_processes)] if state.is_main_process else None
-    dist.gather(block, gather_list, dst=0)
+    with exchange("score_gather", block.numel() * block.element_size()):
+        dist.gather(block, gather_list, dst=0)
     if state.is_main_process:
         return torch.cat(gather_list, dim=1)[:, :dataset_size].cpu()
     return block.cpu()

@@ -1,0 +1,335 @@
+"""GPU parity of the ASSEMBLED BASELINE.json models and of the sizes that matter for them:
+
+(a) ``bench.WORKLOADS["bert_base"]`` / ``["gpt2_small"]`` -- the very models, tasks, data makers and argument presets
+    ``bench.py`` times -- at a small N, stage by stage against the fp64 oracle ON THE TENSORS THE TRACKERS CONSUMED: plain
+    torch hooks ride along the product's own passes and record every tracked layer's input and output gradient, so the
+    fp32 LayerNorm outputs under autocast, the padding masks (reference ``module/linear.py:30-54``), the one-row pooler
+    and the 2-row classifier are all in play, and nothing upstream of the hooks can differ.
+      covariances  all tracked layers                                        rel_F <= 2e-5, counters exact
+      Lambda       a sub-set of layers, product's own eigenvectors           rel_F <= 5e-2 (bf16 lambda_dtype)
+      scores       the same sub-set (per-module scores), default damping     rel_F <= 3e-2 / 6e-2 (bf16 P and gradients;
+                   bf16-rounded / exact eigenvectors in the oracle), and the sum over ALL modules is the "all_modules" run
+(c) ``kf_eigh_f64`` at d = 3073 and 4096 (the BERT / GPT-2 / Llama attention-side sizes): eigenvalues vs LAPACK
+    (``torch.linalg.eigh`` fp64 on the host) <= 1e-10 lambda_max, orthogonality / reconstruction <= 1e-11, ascending.
+(d) ONE Llama-3-8B MLP projection at its FULL width (14336 x 4096 and 4096 x 14336, T = 512, no bias,
+    reference ``examples/openwebtext/task.py:53-68``): covariance, Lambda and scores against fp64 restatements of
+    ``module/tracker/factor.py:58,93,218-226``, ``factor/config.py:331-353`` and ``module/linear.py:112-122`` evaluated on
+    the captured tensors.  The eigenvector matrices are exactly orthogonal Householder products (the stages only need
+    orthogonal ``Q_A``, ``Q_G``; the 14336^2 eigensolver itself is timed separately, it is not what these stages test).
+(b) lives in ``tests/test_layer_shapes_gpu.py`` (the three remaining GPT-2 shapes at T = 512).
+"""
+
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import ekfac_ref as ref  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).norm() / b.norm().clamp(min=1e-300))
+
+
+class Capture:
+    """Forward / tensor hooks on the tracked modules that record, per module and in call order, the (input, output
+    gradient) pairs of every pass while the product's own hooks consume the same tensors."""
+
+    def __init__(self, modules):
+        self.modules, self.handles, self.held = modules, [], {}
+
+    def __enter__(self):
+        for m in self.modules:
+            def fwd(mod, inputs, output, name=m.name):
+                slot = [inputs[0].detach().clone(), None]
+                self.held.setdefault(name, []).append(slot)
+                output.register_hook(lambda grad, slot=slot: slot.__setitem__(1, grad.detach().clone()))
+            self.handles.append(m.register_forward_hook(fwd))
+        return self
+
+    def __exit__(self, *exc):
+        for h in self.handles:
+            h.remove()
+        return False
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (a) assembled BERT-base / GPT-2-small
+# ------------------------------------------------------------------------------------------------------------------
+SUBSET = {
+    "bert_base": ["layers.0.query", "layers.0.intermediate", "layers.0.output", "layers.11.attn_out",
+                  "layers.11.intermediate", "layers.11.output", "pooler", "classifier"],
+    "gpt2_small": ["h.0.c_attn", "h.0.attn_proj", "h.0.c_fc", "h.0.mlp_proj", "h.11.c_attn", "h.11.mlp_proj"],
+}
+
+
+@pytest.mark.parametrize("name,n_train,n_query", [("bert_base", 24, 4), ("gpt2_small", 8, 3)])
+def test_assembled_model_stages_match_oracle(name, n_train, n_query):
+    import bench
+    from kronfluence_amd import prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    state = State()
+    dev = state.device
+    spec = bench.WORKLOADS[name]
+    torch.manual_seed(0)
+    raw = spec["model"]()
+    task, make_data, _, _, mask_fn, names = bench.workload_parts(spec, raw)
+    model = prepare_model(raw, task).to(dev)
+    tracked = [m for m in model.modules() if isinstance(m, TrackedModule)]
+    assert len(tracked) == (74 if name == "bert_base" else 48)
+    by_name = {m.name: m for m in tracked}
+    train, query = make_data(spec, n_train, 1, dev), make_data(spec, n_query, 2, dev)
+    fargs, sargs_of = bench.factor_arguments(spec), bench.score_arguments
+    fb = n_train // 2
+
+    def has_bias(m):
+        return m.original_module.bias is not None
+
+    # ---- covariance: every tracked layer ------------------------------------------------------------------------
+    with Capture(tracked) as cap:
+        _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, fb), fargs, cpu=False)
+    batches = [tuple(t[k:k + fb] for t in train) for k in range(0, n_train, fb)]
+    worst = {"activation": 0.0, "gradient": 0.0}
+    low_cov = fargs.activation_covariance_dtype == torch.bfloat16
+    for m in tracked:
+        o, i = m.original_module.weight.shape
+        ip = i + int(has_bias(m))
+        want_a, want_g = torch.zeros(ip, ip, dtype=torch.float64), torch.zeros(o, o, dtype=torch.float64)
+        count_a = count_g = 0
+        assert len(cap.held[m.name]) == len(batches)
+        for (x, g), batch in zip(cap.held[m.name], batches):
+            mask = mask_fn(batch).cpu() if mask_fn is not None else None
+            if low_cov:  # the reference casts the hooked tensors to the covariance dtype first (tracker/factor.py:101-107)
+                x, g = x.to(torch.bfloat16), g.to(torch.bfloat16)
+            flat, c = ref.linear_flat_activation(x.double().cpu(), mask.double() if mask is not None else None, has_bias(m))
+            ref.covariance_update(want_a, flat)
+            count_a += int(c)
+            flat, c = ref.linear_flat_gradient(g.double().cpu(), mask)
+            ref.covariance_update(want_g, flat)
+            count_g += int(c)
+        ea = rel(cov["activation_covariance"][m.name], want_a)
+        eg = rel(cov["gradient_covariance"][m.name], want_g)
+        worst["activation"], worst["gradient"] = max(worst["activation"], ea), max(worst["gradient"], eg)
+        assert ea <= 2e-5 and eg <= 2e-5, (m.name, ea, eg)
+        assert int(cov["num_activation_covariance_processed"][m.name]) == count_a, m.name
+        assert int(cov["num_gradient_covariance_processed"][m.name]) == count_g, m.name
+    print(f"{name}: covariance rel_F vs fp64 oracle on the hooked tensors, worst of {len(tracked)} layers: {worst}")
+
+    # ---- eigendecomposition (product) + invariants on the sub-set --------------------------------------------------
+    eig = perform_eigendecomposition(cov, model, state, fargs, cpu=False)
+    for mod in SUBSET[name][:3]:
+        for side in ("activation", "gradient"):
+            inv = ref.eigh_invariants(cov[f"{side}_covariance"][mod].cpu(), cov[f"num_{side}_covariance_processed"][mod].cpu(),
+                                      eig[f"{side}_eigenvalues"][mod].cpu(), eig[f"{side}_eigenvectors"][mod].cpu())
+            # fp32 storage of the eigenvectors bounds these at ~1e-6
+            assert inv["orthogonality"] <= 2e-6 and inv["reconstruction"] <= 2e-6 and inv["ascending"] == 0.0, (mod, side, inv)
+
+    # ---- Lambda: sub-set, oracle fed the product's eigenvectors ---------------------------------------------------
+    with Capture([by_name[n] for n in SUBSET[name]]) as cap:
+        _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, fb), fargs, eig, cpu=False)
+    lam_err = {}
+    for mod in SUBSET[name]:
+        m = by_name[mod]
+        q_a = eig["activation_eigenvectors"][mod].to(torch.bfloat16).double().cpu()
+        q_g = eig["gradient_eigenvectors"][mod].to(torch.bfloat16).double().cpu()
+        want = torch.zeros(q_g.shape[0], q_a.shape[0], dtype=torch.float64)
+        for x, g in cap.held[mod]:
+            x, g = x.to(g.dtype).double().cpu(), g.double().cpu()  # gradient_factors: both in the gradient's dtype
+            ref.lambda_update(want, ref.linear_per_sample_gradient(x, g, has_bias(m)), q_a, q_g)
+        lam_err[mod] = rel(lam["lambda_matrix"][mod], want)
+        assert int(lam["num_lambda_processed"][mod]) == n_train
+        assert lam_err[mod] <= 5e-2, lam_err
+    print(f"{name}: Lambda rel_F (bf16 rotations) vs fp64 oracle:", {k: f"{v:.1e}" for k, v in lam_err.items()})
+
+    # ---- scores: per-module on the sub-set; the total over all modules ----------------------------------------------
+    factors = {**eig, **lam}
+    tb = n_train // 2
+
+    def run(per_module):
+        sargs = sargs_of(spec, n_query, 1, n_query)
+        sargs.compute_per_module_scores = per_module
+        return compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query, n_query), n_query,
+                                                    ResidentLoader(train, tb), sargs, fargs, None)
+
+    with Capture([by_name[n] for n in SUBSET[name]]) as cap:
+        per = run(True)
+    total = run(False)["all_modules"]
+    assert set(per) == {m.name for m in tracked} and total.shape == (n_query, n_train)
+    summed = sum(v.double() for v in per.values())
+    assert rel(total.double(), summed) <= 2e-2, rel(total.double(), summed)  # two bf16 passes, scores exported in bf16
+    score_err = {}
+    for mod in SUBSET[name]:
+        m = by_name[mod]
+        (xq, gq), trains = cap.held[mod][0], cap.held[mod][1:]
+        xq, gq = xq.to(gq.dtype).double().cpu(), gq.double().cpu()
+        psg_q = ref.linear_per_sample_gradient(xq, gq, has_bias(m))
+        lam_inv = ref.ekfac_inverse_lambda(lam["lambda_matrix"][mod].double().cpu(), lam["num_lambda_processed"][mod].cpu(),
+                                           1e-8, torch.float64)
+        errs = []
+        for cast in (lambda v: v.to(torch.bfloat16), lambda v: v):
+            q_a = cast(eig["activation_eigenvectors"][mod]).double().cpu()
+            q_g = cast(eig["gradient_eigenvectors"][mod]).double().cpu()
+            p = ref.ekfac_precondition(psg_q, q_a, q_g, lam_inv)
+            want = torch.cat([ref.linear_pairwise_score(p, xt.to(gt.dtype).double().cpu(), gt.double().cpu(), has_bias(m))
+                              for xt, gt in trains], dim=1)
+            errs.append(rel(per[mod], want))
+        score_err[mod] = errs
+        assert errs[0] <= 3e-2 and errs[1] <= 6e-2, score_err
+    print(f"{name}: per-module scores rel_F vs fp64 oracle (bf16-rounded / exact eigenvectors):",
+          {k: [f"{e:.1e}" for e in v] for k, v in score_err.items()})
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (c) eigensolver at transformer sizes
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d", [3073, 4096])
+def test_eigh_transformer_sizes(d):
+    from kronfluence_amd import ops
+
+    gen = torch.Generator().manual_seed(d)
+    n = 2 * d
+    # a covariance as the stage produces them: n rows with a decaying spectrum (condition ~1e6), fp32 accumulator
+    x = torch.randn(n, d, generator=gen, dtype=torch.float64) * torch.logspace(0, -3, d, dtype=torch.float64)
+    mix = torch.linalg.qr(torch.randn(d, d, generator=gen, dtype=torch.float64))[0]
+    cov = ((x @ mix).t() @ (x @ mix)).float()
+    evals, evecs, sweeps = ops.eigh(cov.cuda(), float(n))
+    c = cov.double() / n
+    c = 0.5 * (c + c.t())
+    want = torch.linalg.eigvalsh(c)
+    lam, q = evals.cpu(), evecs.cpu()
+    scale = float(want.abs().max())
+    assert float((lam - want).abs().max()) <= 1e-10 * scale, float((lam - want).abs().max()) / scale
+    inv = ref.eigh_invariants(cov, torch.tensor([n]), lam, q)
+    print(f"kf_eigh_f64 d={d}: {sweeps} sweeps, invariants {inv}")
+    assert inv["orthogonality"] <= 1e-11 and inv["reconstruction"] <= 1e-11 and inv["ascending"] == 0.0, inv
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# (d) one Llama-3-8B MLP projection at full width
+# ------------------------------------------------------------------------------------------------------------------
+class Projection(nn.Module):
+    def __init__(self, i: int, o: int) -> None:
+        super().__init__()
+        self.lin = nn.Linear(i, o, bias=False)
+
+    def forward(self, x):
+        return self.lin(torch.tanh(x))
+
+
+def _proj_loss(model, batch):
+    x, labels = batch
+    logits = model(x.to(next(model.parameters()).dtype))
+    return F.cross_entropy(logits.reshape(-1, logits.shape[-1]).float(), labels.reshape(-1), reduction="sum")
+
+
+def _proj_measure(model, batch):
+    x, labels = batch
+    logits = model(x.to(next(model.parameters()).dtype)).float()
+    return (logits.gather(-1, labels[..., None])[..., 0] - 0.5 * torch.logsumexp(logits, dim=-1)).sum()
+
+
+def _householder(d: int, seed: int) -> torch.Tensor:
+    """An exactly orthogonal dense ``[d, d]`` matrix: the product of two Householder reflections."""
+    gen = torch.Generator().manual_seed(seed)
+    q = torch.eye(d, dtype=torch.float64)
+    for _ in range(2):
+        v = torch.randn(d, generator=gen, dtype=torch.float64)
+        v /= v.norm()
+        q = q - 2.0 * torch.outer(q @ v, v)
+    return q
+
+
+@pytest.mark.parametrize("o,i", [pytest.param(14336, 4096, id="llama-up-full-width"),
+                                 pytest.param(4096, 14336, id="llama-down-full-width")])
+def test_llama_projection_full_width(o, i):
+    from kronfluence_amd import FactorArguments, ScoreArguments, Task, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    class ProjTask(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return _proj_loss(model, tuple(batch))
+
+        def compute_measurement(self, batch, model):
+            return _proj_measure(model, tuple(batch))
+
+    t, n_train, n_query = 512, 2, 1
+    state = State()
+    dev = state.device
+    torch.manual_seed(0)
+    task = ProjTask()
+    model = prepare_model(Projection(i, o), task).to(dev)
+    tracked = [m for m in model.modules() if isinstance(m, TrackedModule)]
+    gen = torch.Generator().manual_seed(1)
+    train = (torch.randn(n_train, t, i, generator=gen).to(dev), torch.randint(0, o, (n_train, t), generator=gen).to(dev))
+    query = (torch.randn(n_query, t, i, generator=gen).to(dev), torch.randint(0, o, (n_query, t), generator=gen).to(dev))
+    low = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16, activation_covariance_dtype=torch.bfloat16,
+                          gradient_covariance_dtype=torch.bfloat16, per_sample_gradient_dtype=torch.bfloat16,
+                          lambda_dtype=torch.bfloat16)  # the reference's all_low_precision preset (AMP bf16: C5)
+
+    # ---- covariance ---------------------------------------------------------------------------------------------------
+    with Capture(tracked) as cap:
+        _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 1), low, cpu=False)
+    xs = torch.cat([x.to(torch.bfloat16).double().cpu().reshape(-1, i) for x, _ in cap.held["lin"]])
+    gs = torch.cat([g.to(torch.bfloat16).double().cpu().reshape(-1, o) for _, g in cap.held["lin"]])
+    for key, rows in (("activation_covariance", xs), ("gradient_covariance", gs)):
+        want = torch.zeros(rows.shape[1], rows.shape[1], dtype=torch.float64)
+        ref.covariance_update(want, rows)
+        err = rel(cov[key]["lin"], want)
+        assert err <= 2e-5, (key, err)
+    assert int(cov["num_activation_covariance_processed"]["lin"]) == n_train * t
+    del cov, want
+
+    # ---- Lambda with given orthogonal eigenvector matrices: a 384 x 320 sub-block in fp64 ---------------------------
+    q_a64, q_g64 = _householder(i, 11), _householder(o, 12)
+    eig = {"activation_eigenvectors": {"lin": q_a64.float()}, "gradient_eigenvectors": {"lin": q_g64.float()},
+           "activation_eigenvalues": {"lin": torch.ones(i)}, "gradient_eigenvalues": {"lin": torch.ones(o)}}
+    with Capture(tracked) as cap:
+        _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 1), low, eig, cpu=False)
+    rows, cols = slice(o - 384, o), slice(64, 384)
+    q_a16, q_g16 = q_a64.float().to(torch.bfloat16).double(), q_g64.float().to(torch.bfloat16).double()
+    want = torch.zeros(384, 320, dtype=torch.float64)
+    for x, g in cap.held["lin"]:
+        psg = ref.linear_per_sample_gradient(x.to(g.dtype).double().cpu(), g.double().cpu(), False)  # [1, O, I]
+        rotated = torch.matmul(q_g16[:, rows].t(), torch.matmul(psg, q_a16[:, cols]))  # tracker/factor.py:218-226, sub-block
+        want += rotated.square().sum(dim=0)
+    err = rel(lam["lambda_matrix"]["lin"][rows, cols], want)
+    print(f"llama {o}x{i}: Lambda sub-block rel_F (bf16) {err:.2e}")
+    assert err <= 5e-2, err
+    assert int(lam["num_lambda_processed"]["lin"]) == n_train
+
+    # ---- scores (bf16 queries / gradients, default damping), full [1, 2] block ----------------------------------------
+    factors = {**eig, **lam}
+    sargs = ScoreArguments(amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16,
+                           per_sample_gradient_dtype=torch.bfloat16)
+    with Capture(tracked) as cap:
+        got = compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query, n_query), n_query,
+                                                   ResidentLoader(train, 1), sargs, low, None)["all_modules"]
+    (xq, gq), trains = cap.held["lin"][0], cap.held["lin"][1:]
+    psg_q = ref.linear_per_sample_gradient(xq.to(gq.dtype).double().cpu(), gq.double().cpu(), False)
+    lam_inv = ref.ekfac_inverse_lambda(lam["lambda_matrix"]["lin"].double().cpu(), lam["num_lambda_processed"]["lin"].cpu(), 1e-8,
+                                       torch.float64)
+    p = ref.ekfac_precondition(psg_q, q_a16, q_g16, lam_inv)
+    want = torch.cat([ref.linear_pairwise_score(p, xt.to(gt.dtype).double().cpu(), gt.double().cpu(), False) for xt, gt in trains], dim=1)
+    err = rel(got, want)
+    print(f"llama {o}x{i}: scores rel_F (bf16, damping 1e-8) {err:.2e}; got {got.flatten().tolist()} want {want.flatten().tolist()}")
+    assert got.shape == (n_query, n_train) and err <= 4e-2, err

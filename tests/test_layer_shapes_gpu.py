@@ -1,7 +1,7 @@
 """GPU parity at the REAL layer shapes of the BERT-base and GPT-2-small configs (C3, C4):
 one tracked ``nn.Linear`` with bias on ``[b, T, d]`` activations -- (O, I') = (768, 769), (3072, 769), (768, 3073) at
-T = 128 with random-length padding masks (reference mask semantics: ``kronfluence/module/linear.py:30-54``), and
-(2304, 769) at T = 512, plus the Llama-3-8B MLP projections at 1/8 width (no bias, T = 512) -- against the CPU oracle run in
+T = 128 with random-length padding masks (reference mask semantics: ``kronfluence/module/linear.py:30-54``), all four
+GPT-2-small shapes -- (2304, 769), (768, 769), (3072, 769), (768, 3073) -- at T = 512, plus the Llama-3-8B MLP projections at 1/8 width (no bias, T = 512) -- against the CPU oracle run in
 fp64 on the same seeded inputs.
 
 Every stage is compared on its own, so an error cannot hide behind (or be blamed on) an earlier stage:
@@ -69,6 +69,9 @@ SHAPES = [  # (O, I, T, n_train, bias): rows = n_train * T real tokens exceed I'
     pytest.param(3072, 768, 128, 16, True, id="bert-3072x769"),
     pytest.param(768, 3072, 128, 48, True, id="bert-768x3073"),
     pytest.param(2304, 768, 512, 4, True, id="gpt2-2304x769-T512"),
+    pytest.param(768, 768, 512, 4, True, id="gpt2-768x769-T512"),
+    pytest.param(3072, 768, 512, 4, True, id="gpt2-3072x769-T512"),
+    pytest.param(768, 3072, 512, 10, True, id="gpt2-768x3073-T512"),
     # Llama-3-8B MLP projections (14336 x 4096 / 4096 x 14336, no bias, T = 512) at 1/8 width: the C5 parity slice
     pytest.param(1792, 512, 512, 3, False, id="llama-up-1/8-width"),
     pytest.param(512, 1792, 512, 5, False, id="llama-down-1/8-width"),
