@@ -1,0 +1,182 @@
+// kf_pingpong.h -- 256 x 256 x 64 bf16 MFMA main loop with WAVE ROLE SPLIT for gfx950 (round 3).
+//
+// Why: the round-2 main loop (kf_score_v2.hip: every wave reads fragments, waits for them, issues MFMAs, and all eight
+// waves drain vmcnt + barrier once per k-step) left the two waves that share a SIMD in lock-step: both wait for LDS at the
+// same time, both want the matrix pipe at the same time (47 % MFMA utilisation, SQ_WAIT_INST_ANY 41 %).  Here the two waves
+// of a SIMD run HALF A PHASE APART: waves 0-3 ("X") and waves 4-7 ("Y", which sit on the same four SIMDs) alternate between
+//
+//     L segment   ds_read the fragments of the next MFMA block, issue LDS-DMA requests for later k-tiles, wait for the
+//                 fragments (lgkmcnt) and for exactly the DMA pieces the NEXT segment needs (counted vmcnt, never 0)
+//     M segment   16 back-to-back v_mfma_f32_32x32x16_bf16 at raised priority
+//
+// separated by raw s_barriers.  Y executes one extra barrier up front, so while X is in M(P), Y is in L(P); after the next
+// barrier X is in L(P + 1) and Y in M(P).  Per SIMD the matrix pipe is handed back and forth and every LDS / DMA latency of
+// one wave is covered by the other wave's MFMAs (cdna_hip_programming.md section 5, "8-phase" template / T3-T5; this is a
+// 4-segment-per-k-tile variant of it on the 32x32x16 instruction with the fragment set of a whole half tile in registers).
+//
+// Tile: 512 threads = 8 wave64, wave (wm, wn) = (wave >> 2, wave & 3) owns rows wm*128 .. +128 and columns wn*64 .. +64
+// = 4 x 2 accumulators of 32 x 32.  One k-tile (64 deep) of the wave tile is TWO phases:
+//     phase 0: A blocks i = 0, 1 (8 ds_read_b128) + B blocks jn = 0, 1 (8 reads)  ->  acc[0..1][0..1] += ...   16 MFMAs
+//     phase 1: A blocks i = 2, 3 (8 reads), B fragments kept in registers          ->  acc[2..3][0..1] += ...   16 MFMAs
+// (24 fragment reads per wave and k-tile: the minimum for a 128 x 64 wave tile.)
+//
+// LDS: two 64 KB buffers (k-tile t lives in buffer t & 1), each A rows 0..255 then B rows 0..255, 128 bytes per row, the
+// 16-byte chunk c of row r at position c ^ ((r >> 1) & 7) (XOR on the DMA source address and on the fragment read alike:
+// bank-conflict free, measured round 2).  The DMA moves a k-tile in FOUR pieces of 16 KB ordered by liveness -- a piece is
+// re-staged for k-tile t + 2 as soon as k-tile t is done with it:
+//     A0 = A rows of blocks i = 0, 1 of both wave rows (read in phase 0 only)      re-staged in L(2t + 1)
+//     B0 = B rows 0..127, B1 = B rows 128..255 (read in phase 0 only)              re-staged in L(2t + 1) / L(2t + 2)
+//     A1 = A rows of blocks i = 2, 3 (read in phase 1 only)                        re-staged in L(2t + 2)
+// Issue order per wave (2 requests = 2 KB per piece):  L(2t): B1(t+1), A1(t+1);   L(2t+1): A0(t+2), B0(t+2).
+//
+// Ordering argument (S_k = the interval between global barrier events E_k and E_k+1; X runs L(P) in S_2P and M(P) in
+// S_2P+1, Y runs L(P) in S_2P+1 and M(P) in S_2P+2):
+//   RAW  a piece is complete once EVERY wave's part has landed: each wave waits (counted vmcnt) for its own requests at the
+//        end of an L segment, i.e. before a barrier, and the piece is first read one phase later.  End of L(2t): A1(t) must
+//        be there for L(2t+1) -> everything issued after it may stay in flight: A0, B0, B1, A1 of t+1 = 8 requests
+//        (vmcnt(8)).  End of L(2t+1): A0, B0, B1 of t+1 must be there for L(2t+2) -> in flight: A1(t+1), A0(t+2), B0(t+2) = 6
+//        (vmcnt(6)).  X's wait finishes in S_4t / S_4t+2, Y's one interval later, both before the barrier that opens the
+//        first reading segment (X: S_4t+2 / S_4t+4).
+//   WAR  a request issued in L(P) overwrites rows last read in L(P-1) (or earlier).  Every L segment ends with
+//        s_waitcnt lgkmcnt(0) BEFORE its barrier, so when any wave passes that barrier all fragment reads of L(P-1) of both
+//        groups have returned (Y's L(P-1) is S_2P-1, X's L(P) is S_2P).  Pieces written in L(P) are never read in L(P) or
+//        L(P+1) of the other group: L(2t) writes buffer (t+1)&1 while tile t (buffer t&1) is being read; L(2t+1) writes A0 /
+//        B0 of buffer t&1 while L(2t+1) reads only A1 of it and L(2t+2) reads the other buffer.
+// Nothing else orders an LDS-DMA against a ds_read (MI355X_MICROARCH.md, "Two waves per SIMD", item 7).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "kf_engine.h"
+
+namespace kf {
+namespace pp {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int THREADS = 512;
+constexpr int STAGE_BYTES = 65536, B_OFFSET = 32768, SMEM_BYTES = 2 * STAGE_BYTES;
+
+// per-lane DMA sources of this wave's 8 requests per k-tile, for k-tile 0; k-tile t is kt_a / kt_b elements further on
+//   p[0], p[1]: A0 (wave row j = 0, 1)   p[2], p[3]: A1   p[4], p[5]: B0 (rows j*128 ..)   p[6], p[7]: B1
+struct Sources {
+    const uint16_t* p[8];
+    int64_t kt_a, kt_b;
+};
+
+// row (within the 256-row operand tile) whose 8-row group request `r` (0..7, order of Sources::p) of wave `wave` stages
+__device__ __forceinline__ int request_row0(int r, int wave) {
+    const int j = r & 1, h = (r >> 1) & 1;
+    return r < 4 ? j * 128 + h * 64 + wave * 8                               // A: piece h, wave row j
+                 : h * 128 + j * 64 + (wave >> 2) * 32 + (wave & 3) * 8;     // B: piece h = rows h*128.., two requests 64 rows apart
+}
+__device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
+
+__device__ __forceinline__ void glds16(const void* src, void* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void wait_lds_reads() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void barrier() {
+    asm volatile("s_barrier" ::: "memory");   // raw: no vmcnt drain (LDS-DMA requests stay in flight across it)
+    __builtin_amdgcn_sched_barrier(0);        // nothing is scheduled across a segment boundary
+}
+
+// Fills the per-lane source table for an operand pair whose element (row, k) of the A / B tile lives at
+// A + row_a(row) ... given by two functors returning the address of k = 0 of a row.
+template <class RowA, class RowB>
+__device__ __forceinline__ void make_sources(Sources& s, int wave, int lane, RowA row_a, RowB row_b) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = request_row0(r, wave) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        s.p[r] = (r < 4 ? row_a(row) : row_b(row)) + chunk * 8;
+    }
+}
+
+// acc[i][jn] (i = 0..3 row blocks, jn = 0..1 column blocks of the wave's 128 x 64 tile) += A B^T over k-tiles [0, nt).
+// `wave` must be wave-uniform (readfirstlane'd).  All 512 threads; sm: SMEM_BYTES of LDS.  On return every wave has
+// finished reading LDS (the buffers may be reused after one more barrier).
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane) {
+    const int wm = wave >> 2, wn = wave & 3;
+    const int lr = lane & 31, hi = lane >> 5, sw = (lr >> 1) & 7;
+    int co[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) co[kk] = ((kk * 2 + hi) ^ sw) * 16;
+    const unsigned char* frag_a = sm + (wm * 128 + lr) * 128;
+    const unsigned char* frag_b = sm + B_OFFSET + (wn * 64 + lr) * 128;
+
+    // request r of k-tile t -> buffer t & 1
+    auto issue = [&](int r, int t) {
+        unsigned char* dst = sm + (t & 1) * STAGE_BYTES + (r < 4 ? 0 : B_OFFSET) + request_row0(r, wave) * 128;
+        glds16(src.p[r] + t * (r < 4 ? src.kt_a : src.kt_b), dst);
+    };
+    auto issue_piece = [&](int piece /* 0 A0, 1 A1, 2 B0, 3 B1 */, int t) { issue(2 * piece, t); issue(2 * piece + 1, t); };
+
+    bf16x8 a[2][4], b[2][4];
+    auto read_a = [&](int half, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                a[i][kk] = *reinterpret_cast<const bf16x8*>(frag_a + buf * STAGE_BYTES + (half * 2 + i) * 4096 + co[kk]);
+    };
+    auto read_b = [&](int buf) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                b[jn][kk] = *reinterpret_cast<const bf16x8*>(frag_b + buf * STAGE_BYTES + jn * 4096 + co[kk]);
+    };
+#define KF_PP_MFMA(HALF)                                                                                               \
+    do {                                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
+                _Pragma("unroll") for (int jn = 0; jn < 2; ++jn)                                                       \
+                    acc[(HALF) * 2 + i][jn] =                                                                          \
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[jn][kk], acc[(HALF) * 2 + i][jn], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+    } while (0)
+
+    // prologue: k-tile 0 complete, A0 / B0 of k-tile 1 on their way
+    issue_piece(0, 0); issue_piece(2, 0); issue_piece(3, 0); issue_piece(1, 0);
+    if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); wait_vmcnt<6>(); }   // in flight: A1(0), A0(1), B0(1)
+    else wait_vmcnt<2>();                                                     // in flight: A1(0)
+    barrier();
+    if (wm == 1) barrier();   // Y runs half a phase behind X from here on (wave-uniform branch)
+
+    // one k-tile = L(2t) M(2t) L(2t+1) M(2t+1);  MORE1: k-tile t+1 exists, MORE2: k-tile t+2 exists
+#define KF_PP_TILE(T, MORE1, MORE2)                                                                                    \
+    do {                                                                                                               \
+        const int t_ = (T), buf_ = t_ & 1;                                                                             \
+        read_a(0, buf_);                                                                                               \
+        read_b(buf_);                                                                                                  \
+        if (MORE1) { issue_piece(3, t_ + 1); issue_piece(1, t_ + 1); wait_vmcnt<8>(); }                                \
+        else wait_vmcnt<0>();                                                                                          \
+        wait_lds_reads();                                                                                              \
+        barrier();                                                                                                     \
+        KF_PP_MFMA(0);                                                                                                 \
+        barrier();                                                                                                     \
+        read_a(1, buf_);                                                                                               \
+        if (MORE2) { issue_piece(0, t_ + 2); issue_piece(2, t_ + 2); wait_vmcnt<6>(); }                                \
+        else if (MORE1) wait_vmcnt<2>();                                                                               \
+        wait_lds_reads();                                                                                              \
+        barrier();                                                                                                     \
+        KF_PP_MFMA(1);                                                                                                 \
+        barrier();                                                                                                     \
+    } while (0)
+
+    int t = 0;
+    for (; t + 2 < nt; ++t) KF_PP_TILE(t, true, true);
+    if (t + 1 < nt) { KF_PP_TILE(t, true, false); ++t; }
+    KF_PP_TILE(t, false, false);
+    if (wm == 0) barrier();   // X waits for Y's last segment: barrier counts match, all LDS reads are done
+#undef KF_PP_TILE
+#undef KF_PP_MFMA
+}
+
+}  // namespace pp
+}  // namespace kf

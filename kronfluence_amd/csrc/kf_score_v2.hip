@@ -32,6 +32,7 @@
 
 #include "../../include/kronfluence_hip.h"
 #include "kf_engine.h"
+#include "kf_pingpong.h"
 
 using namespace kf;
 
@@ -296,6 +297,127 @@ __global__ __launch_bounds__(SV2_THREADS) void rotate_gemm_v2_kernel(RotateArgs 
             *reinterpret_cast<u32x4*>(a.C + static_cast<int64_t>(m) * a.ldc + n) =
                 *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ch ^ (ml & 31)) << 4));
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 3: the same two 256 x 256 kernels on the wave-role-split main loop of kf_pingpong.h (two waves per SIMD half a
+// phase apart, counted vmcnt, raw barriers).  Work decomposition, operand layouts and epilogues are those of the v2 kernels
+// above, which stay as the 256 x 128 / 128 x 256 shapes and as the KF_ENGINE=2 fallback.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.ksplit) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int chunk = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int m0 = (tile / a.tiles_n) * 256, n0 = (tile % a.tiles_n) * 256;
+    const int kt_begin = chunk * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
+    if (kt_begin >= kt_end) return;
+
+    pp::Sources src;
+    src.kt_a = static_cast<int64_t>(a.M) * 64;
+    src.kt_b = static_cast<int64_t>(a.N) * 64;
+    const uint16_t* abase = a.A + kt_begin * src.kt_a;
+    const uint16_t* bbase = a.B + kt_begin * src.kt_b;
+    pp::make_sources(src, wave, lane,
+                     [&](int row) { return abase + static_cast<int64_t>(min(m0 + row, a.M - 1)) * 64; },
+                     [&](int row) { return bbase + static_cast<int64_t>(min(n0 + row, a.N - 1)) * 64; });
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    pp::mainloop(acc, sm, src, kt_end - kt_begin, wave, lane);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 64 + jn * 32 + (lane & 31);
+                if (m < a.M && n < a.N) atomicAdd(a.C + static_cast<int64_t>(m) * a.ldc + n, a.alpha * acc[i][jn][r]);
+            }
+}
+
+// RotateArgs with two additions: col_add (per output ROW m: the bias row when the roles of the operands are swapped to get a
+// transposed result) and a blocked result layout -- element (m, n) at (n / c_inner) * c_outer + m * c_inner + n % c_inner
+// (c_inner == 0: plain row-major with ldc) -- which is how "Gt^T[n][o][r]" (K-contiguous per sample) is written.
+struct RotateV3Args {
+    RotateArgs r;
+    const float* col_add; int col_add_m;
+    int64_t c_inner, c_outer;
+    int n_major;   // work order: consecutive items share the B (n) tile instead of the A (m) tile
+};
+
+__global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Args v) {
+    const RotateArgs& a = v.r;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int64_t items = static_cast<int64_t>(a.tiles_m) * a.tiles_n, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int tm = v.n_major ? static_cast<int>(item % a.tiles_m) : static_cast<int>(item / a.tiles_n);
+    const int tn = v.n_major ? static_cast<int>(item / a.tiles_m) : static_cast<int>(item % a.tiles_n);
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    pp::Sources src;
+    src.kt_a = 64;
+    src.kt_b = 64;
+    pp::make_sources(src, wave, lane,
+                     [&](int row) { return a.A + static_cast<int64_t>(min(m0 + row, a.M - 1)) * a.lda; },
+                     [&](int row) { return a.B + static_cast<int64_t>(min(n0 + row, a.N - 1)) * a.ldb; });
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    pp::mainloop(acc, sm, src, a.KT, wave, lane);
+    __syncthreads();  // every wave is done with the stage buffers: the epilogue reuses them
+    // epilogue: element (ml, nl) of the tile as bf16 at ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + (nl & 7) * 2
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int nl = wn * 64 + jn * 32 + (lane & 31), n = n0 + nl;
+            const float add = (a.row_add && n < a.row_add_n) ? a.row_add[n] : 0.0f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float cadd = (v.col_add && m0 + ml < v.col_add_m) ? v.col_add[m0 + ml] : 0.0f;
+                uint32_t u = __float_as_uint(a.alpha * acc[i][jn][r] + add + cadd);
+                if ((u & 0x7fffffffu) > 0x7f800000u) u |= 0x00400000u;
+                else u += 0x7fffu + ((u >> 16) & 1u);
+                *reinterpret_cast<uint16_t*>(sm + ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + (nl & 7) * 2) = static_cast<uint16_t>(u >> 16);
+            }
+        }
+    __syncthreads();
+    // 512 threads = 16 rows x 32 chunks per pass: a thread's chunk column is the same in all 16 passes
+    const int ch = tid & 31, n = n0 + ch * 8;
+    if (n < a.N) {  // N % 8 == 0 (and c_inner % 8 == 0): a chunk is entirely in or out, never across blocks
+        const int inner = static_cast<int>(v.c_inner);
+        const int64_t col = inner ? static_cast<int64_t>(n / inner) * v.c_outer + n % inner : n;
+        const int64_t row_stride = inner ? inner : a.ldc;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int ml = (tid >> 5) + 16 * it, m = m0 + ml;
+            if (m < a.M)
+                *reinterpret_cast<u32x4*>(a.C + col + m * row_stride) = *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ch ^ (ml & 31)) << 4));
+        }
+    }
+}
+
+inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A/B measurements, fallback)
+    const char* e = getenv("KF_ENGINE");
+    return (e && atoi(e) == 2) ? 2 : 3;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -690,6 +812,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
@@ -719,7 +843,8 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     ksplit = cdiv(s.KT, kchunk);
     s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(ksplit * tiles, 8)));
-    if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
+    if (shape == 0 && engine_generation() == 3) hipLaunchKernelGGL(score_gemm_v3_kernel, grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, s);
+    else if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
     else if (shape == 1) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 128, 4>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     else hipLaunchKernelGGL((score_gemm_v2_kernel<128, 256, 2>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     return launch_status();
@@ -758,6 +883,12 @@ int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void*
     r.tiles_m = static_cast<int>(cdiv(M, 256)); r.tiles_n = static_cast<int>(cdiv(N, 256));
     r.alpha = alpha; r.row_add = row_add; r.row_add_n = row_add_n;
     const int64_t blocks = 8 * cdiv(static_cast<int64_t>(r.tiles_m) * r.tiles_n, 8);
+    if (engine_generation() == 3) {
+        RotateV3Args v{};
+        v.r = r;
+        hipLaunchKernelGGL(rotate_gemm_v3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, as_stream(stream), v);
+        return launch_status();
+    }
     hipLaunchKernelGGL(rotate_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), 2 * 512 * 128, as_stream(stream), r);
     return launch_status();
 }

@@ -130,6 +130,38 @@ def test_query_allgather_restores_dataset_order(tmp_path):
         assert got[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
 
 
+def _query_allgather_async(rank, world, out_dir):
+    """The path the backward hook takes: ``_store(..., from_hook=True)`` issues the all-gather asynchronously, ``synchronize``
+    waits and interleaves; the exchange log counts one call and the gathered bytes."""
+    from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
+    from kronfluence_amd.utils import comm
+    from torch.utils.data import DistributedSampler
+
+    model = _model()
+    m = [x for x in model.modules() if isinstance(x, TrackedModule)][0]
+    m.current_mode = ModuleMode.PRECONDITION_GRADIENT
+    tracker = m._trackers[ModuleMode.PRECONDITION_GRADIENT]
+    n_query, per_rank = 5, 3
+    idx = list(DistributedSampler(range(n_query), world, rank, shuffle=False, drop_last=False))[:per_rank]
+    comm.EXCHANGE_LOG = {}
+    tracker._store(torch.stack([torch.full((2, 3), float(i)) for i in idx]), from_hook=True)
+    assert tracker._pending is not None
+    m.synchronize(num_processes=world)
+    assert tracker._pending is None
+    log, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
+    assert log["query_all_gather"]["calls"] == 1 and log["query_all_gather"]["bytes"] == world * per_rank * 6 * 4
+    m.truncate(keep_size=n_query % (per_rank * world) or per_rank * world)
+    m.accumulate_iterations()
+    torch.save(m.storage["accumulated_preconditioned_gradient"].dense(), os.path.join(out_dir, f"rank{rank}.pt"))
+
+
+def test_async_query_allgather_from_the_hook(tmp_path):
+    _run("_query_allgather_async", tmp_path)
+    for rank in range(2):
+        got = torch.load(os.path.join(tmp_path, f"rank{rank}.pt"))
+        assert got[:, 0, 0].tolist() == [0.0, 1.0, 2.0, 3.0, 4.0]
+
+
 # ---- C5 ----------------------------------------------------------------------------------------
 def _score_gather(rank, world, out_dir):
     from kronfluence_amd.score.dot_product import gather_score_blocks

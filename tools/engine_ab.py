@@ -1,0 +1,102 @@
+"""A/B of the two 256 x 256 LDS-DMA main loops (KF_ENGINE=2: round-2 lock-step loop, KF_ENGINE=3: wave-role-split loop of
+csrc/kf_pingpong.h) through the public entry points, plus a correctness sweep of the new loop over k-tile counts and ragged
+edges against a plain torch reference.
+
+    gpurun -- 'python tools/engine_ab.py'            (add `rocprofv3 --kernel-trace --stats` in front for per-kernel times)
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+from kronfluence_amd import ops
+from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+DEV = "cuda:0"
+
+
+def timed(fn, reps=10):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        fn()
+    e.record()
+    torch.cuda.synchronize()
+    return s.elapsed_time(e) / reps
+
+
+def engine(gen):
+    os.environ["KF_ENGINE"] = str(gen)
+
+
+def score_case(q, b, o, ip, r=64):
+    """kf_pairwise_score on a k-tile-major P: v1 gradient kernel (common to both arms) + the 256 x 256 score GEMM."""
+    g = torch.randn(b, r, o, device=DEV).bfloat16()
+    a = torch.randn(b, r, ip, device=DEV).bfloat16()
+    p = torch.randn(q, o, ip, device=DEV).bfloat16()
+    tiled = TiledQueries(p, 0)
+    out = {}
+    for gen in (2, 3):
+        engine(gen)
+        s = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(s, 0, tiled, g, a, False)
+        out[gen] = s
+    psg = torch.einsum("bro,bri->boi", g.float(), a.float()).bfloat16().float()
+    want = torch.einsum("qoi,boi->qb", p.float(), psg)
+    return [float((out[gen] - want).norm() / want.norm()) for gen in (2, 3)] + [float((out[3] - out[2]).abs().max() / want.abs().max())]
+
+
+def main():
+    torch.manual_seed(0)
+    print("== correctness: score GEMM (rel_F vs torch fp32 on the same bf16 gradients) engine 2 / engine 3 / max|3-2|")
+    # D = o * ip; KT = D / 64 -> 1, 2, 3, 5 k-tiles without split-K, then split-K shapes; ragged Q / b
+    for q, b, o, ip in [(256, 256, 8, 8), (256, 256, 8, 16), (256, 256, 8, 24), (250, 300, 8, 40), (1000, 1000, 64, 64),
+                        (513, 777, 128, 1152), (1000, 1000, 128, 1152), (1024, 2048, 256, 2304)]:
+        for rep in range(2 if o * ip > 4096 else 1):
+            e2, e3, d = score_case(q, b, o, ip)
+            flag = "" if (e3 < 1e-4 and d < 1e-4) else "   <-- MISMATCH"
+            print(f"  Q={q:5d} b={b:5d} D={o * ip:7d} (KT={o * ip // 64:5d}): {e2:.1e} / {e3:.1e} / {d:.1e}{flag}", flush=True)
+
+    print("== correctness + timing: rotation GEMM X @ Q (bf16 -> bf16)")
+    for name, n, d in [("256000 x 1152", 256000, 1152), ("256000 x 1600", 256000, 1600), ("131072 x 768", 131072, 768),
+                       ("64000 x 2304", 64000, 2304), ("140000 x 128 (K=128)", 140000, 128 * 9)]:
+        x = torch.randn(n, d, device=DEV).bfloat16()
+        qm = torch.linalg.qr(torch.randn(d, d, device=DEV))[0]
+        q_t = qm.t().contiguous().bfloat16()
+        bias = torch.randn(d, device=DEV)
+        res = {}
+        for gen in (2, 3):
+            engine(gen)
+            t = timed(lambda: ops.rotate_bf16(x, q_t))
+            got = ops.rotate_bf16(x, q_t, bias)
+            rows = torch.cat([got[:300], got[n // 2:n // 2 + 300], got[-300:]]).float()
+            xs = torch.cat([x[:300], x[n // 2:n // 2 + 300], x[-300:]]).float()
+            want = xs @ q_t.float().t() + bias
+            res[gen] = (t, float((rows - want).norm() / want.norm()))
+        print(f"  {name:24s} engine2 {res[2][0]:7.3f} ms {2.0 * n * d * d / res[2][0] / 1e9:6.0f} TF/s err {res[2][1]:.1e} | "
+              f"engine3 {res[3][0]:7.3f} ms {2.0 * n * d * d / res[3][0] / 1e9:6.0f} TF/s err {res[3][1]:.1e}", flush=True)
+
+    print("== timing: score entry point (gradient kernel + score GEMM), Q = b = 1000")
+    for name, o, ip, r in [("resnet 128x1152 R=256", 128, 1152, 256), ("resnet 256x2304 R=64", 256, 2304, 64),
+                           ("resnet 128x1600 R=256", 128, 1600, 256), ("bert 768x776 R=128 b=250", 768, 776, 128)]:
+        q = 1000
+        b = 250 if "bert" in name else 1000
+        g = torch.randn(b, r, o, device=DEV).bfloat16()
+        a = torch.randn(b, r, ip, device=DEV).bfloat16()
+        tiled = TiledQueries(torch.randn(q, o, ip, device=DEV).bfloat16(), 0)
+        s = torch.zeros(q, b, device=DEV)
+        line = f"  {name:26s}"
+        for gen in (2, 3):
+            engine(gen)
+            t = timed(lambda: ops.pairwise_score(s, 0, tiled, g, a, False), 5)
+            line += f" engine{gen} {t:7.3f} ms ({2.0 * q * b * o * ip / t / 1e9:6.0f} TF/s on the score flops)"
+        print(line, flush=True)
+    engine(3)
+
+
+if __name__ == "__main__":
+    main()
