@@ -217,6 +217,28 @@ int kf_eigh_small_batched(const float* G, int64_t batch, int l, float* evals, fl
 int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gt, const void* At, int64_t ld_at, int dtype,
                     int64_t b, int64_t R, int64_t O, int64_t Ip, float scale, void* stream);
 
+/*
+ * Lambda of a Conv2d layer in the DENSE form (ABI 10): Lambda[o', i'] += scale^2 * sum_n ( Qg^T g_n Qa )[o', i']^2 with the
+ * per-sample gradient g_n formed once (module/conv2d.py:164-177) and rotated as a whole (tracker/factor.py:218-226), instead of
+ * rotating its factors: 2 R O I' + 2 O I'^2 flops per sample against 2 R (I'^2 + O^2 + O I') -- cheaper whenever the layer has
+ * more output positions R than output channels O, and, with IMPLICIT im2col, free of the [b, R, I'] patch tensor and of its
+ * [b R, I'] x [I', I'] rotation.  Three kernels: the padded, phase-split input copy (as kf_pairwise_score_conv2d); the
+ * per-sample-gradient kernel fed by LDS-DMA, whose A operand is Gt_nchw = the hooked output gradient ALREADY rotated along
+ * its channel axis, Gt[n, o', p] = sum_o Qg[o, o'] G[n, o, p] (one kf_gemm_out call), writing rows ordered (o', n) with the
+ * patch axis (ky, kx, c) zero-padded to multiples of 8 channels; and one tall GEMM of those O*b rows with QaT_perm whose
+ * epilogue squares and sums the rows of every o' in registers (no result matrix is stored).
+ * QaT_perm: bf16 [n_out_padded, ldq], row i' = column i' of Qa with its rows permuted to the kernel's patch order (zero for
+ * the padding channels); n_out = I' columns of Lambda are written.
+ * Needs groups == 1, no bias, O2 % 8 == 0, O1*O2 % 64 == 0, (C rounded up to 8) * k1 * k2 % 64 == 0, b >= 256;
+ * kf_lambda_conv2d_workspace_bytes returns -1 otherwise (use kf_im2col + kf_gemm + kf_lambda_accum).
+ */
+int64_t kf_lambda_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2,
+                                         int p1, int p2, int d1, int d2);
+int kf_lambda_conv2d_accum(float* Lambda, int64_t ld_lambda, const void* Gt_nchw, const void* x, int64_t b, int64_t C, int64_t H,
+                           int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2,
+                           const void* QaT_perm, int64_t n_out, int64_t ldq, float scale, void* workspace,
+                           int64_t workspace_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Stage 3 -- preconditioning and pairwise scores
  * ------------------------------------------------------------------------------------------- */

@@ -57,12 +57,16 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int THREADS = 512;
 constexpr int STAGE_BYTES = 65536, B_OFFSET = 32768, SMEM_BYTES = 2 * STAGE_BYTES;
 
-// per-lane DMA sources of this wave's 8 requests per k-tile, for k-tile 0; k-tile t is kt_a / kt_b elements further on
+// per-lane DMA sources of this wave's 8 requests per k-tile, for k-tile 0; the element offset of k-tile t is supplied by
+// the two "walk" functors of mainloop (the same for every request of an operand)
 //   p[0], p[1]: A0 (wave row j = 0, 1)   p[2], p[3]: A1   p[4], p[5]: B0 (rows j*128 ..)   p[6], p[7]: B1
 struct Sources {
     const uint16_t* p[8];
-    int64_t kt_a, kt_b;
 };
+
+// the k-octet a lane fetches is the SAME for its 8 requests: every request starts at a row that is a multiple of 8 whose
+// bit 3 equals wave & 1, so swz(row) = 4 * (wave & 1) + (lane >> 4)
+__device__ __forceinline__ int lane_octet(int wave, int lane) { return (lane & 7) ^ (4 * (wave & 1) + (lane >> 4)); }
 
 // row (within the 256-row operand tile) whose 8-row group request `r` (0..7, order of Sources::p) of wave `wave` stages
 __device__ __forceinline__ int request_row0(int r, int wave) {
@@ -97,9 +101,12 @@ __device__ __forceinline__ void make_sources(Sources& s, int wave, int lane, Row
 }
 
 // acc[i][jn] (i = 0..3 row blocks, jn = 0..1 column blocks of the wave's 128 x 64 tile) += A B^T over k-tiles [0, nt).
+// walk_a(t) / walk_b(t): element offset of k-tile t relative to Sources::p (any per-lane value; evaluated once per piece).
 // `wave` must be wave-uniform (readfirstlane'd).  All 512 threads; sm: SMEM_BYTES of LDS.  On return every wave has
 // finished reading LDS (the buffers may be reused after one more barrier).
-__device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane) {
+template <class WalkA, class WalkB>
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane,
+                                         WalkA walk_a, WalkB walk_b) {
     const int wm = wave >> 2, wn = wave & 3;
     const int lr = lane & 31, hi = lane >> 5, sw = (lr >> 1) & 7;
     int co[4];
@@ -108,12 +115,15 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
     const unsigned char* frag_a = sm + (wm * 128 + lr) * 128;
     const unsigned char* frag_b = sm + B_OFFSET + (wn * 64 + lr) * 128;
 
-    // request r of k-tile t -> buffer t & 1
-    auto issue = [&](int r, int t) {
-        unsigned char* dst = sm + (t & 1) * STAGE_BYTES + (r < 4 ? 0 : B_OFFSET) + request_row0(r, wave) * 128;
-        glds16(src.p[r] + t * (r < 4 ? src.kt_a : src.kt_b), dst);
+    // piece (0 A0, 1 A1, 2 B0, 3 B1) of k-tile t = requests 2 piece, 2 piece + 1 -> buffer t & 1
+    auto issue_piece = [&](int piece, int t) {
+        const auto off = piece < 2 ? walk_a(t) : walk_b(t);
+#pragma unroll
+        for (int r = 2 * piece; r < 2 * piece + 2; ++r) {
+            unsigned char* dst = sm + (t & 1) * STAGE_BYTES + (r < 4 ? 0 : B_OFFSET) + request_row0(r, wave) * 128;
+            glds16(src.p[r] + off, dst);
+        }
     };
-    auto issue_piece = [&](int piece /* 0 A0, 1 A1, 2 B0, 3 B1 */, int t) { issue(2 * piece, t); issue(2 * piece + 1, t); };
 
     bf16x8 a[2][4], b[2][4];
     auto read_a = [&](int half, int buf) {

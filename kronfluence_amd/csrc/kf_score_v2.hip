@@ -318,10 +318,9 @@ __global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args 
     if (kt_begin >= kt_end) return;
 
     pp::Sources src;
-    src.kt_a = static_cast<int64_t>(a.M) * 64;
-    src.kt_b = static_cast<int64_t>(a.N) * 64;
-    const uint16_t* abase = a.A + kt_begin * src.kt_a;
-    const uint16_t* bbase = a.B + kt_begin * src.kt_b;
+    const int64_t kt_a = static_cast<int64_t>(a.M) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
+    const uint16_t* abase = a.A + kt_begin * kt_a;
+    const uint16_t* bbase = a.B + kt_begin * kt_b;
     pp::make_sources(src, wave, lane,
                      [&](int row) { return abase + static_cast<int64_t>(min(m0 + row, a.M - 1)) * 64; },
                      [&](int row) { return bbase + static_cast<int64_t>(min(n0 + row, a.N - 1)) * 64; });
@@ -332,7 +331,7 @@ __global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args 
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pp::mainloop(acc, sm, src, kt_end - kt_begin, wave, lane);
+    pp::mainloop(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; });
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -353,8 +352,14 @@ struct RotateV3Args {
     const float* col_add; int col_add_m;
     int64_t c_inner, c_outer;
     int n_major;   // work order: consecutive items share the B (n) tile instead of the A (m) tile
+    // EPI == 1 ("sum of squares over row groups"): rows are ordered (group, member) with `group_rows` members per group;
+    // sumsq[group * ld_sumsq + n] += alpha^2 * sum_member C[(group, member), n]^2 and C itself is never stored.
+    float* sumsq; int64_t ld_sumsq; int group_rows;
 };
 
+// EPI 0: bf16 result through LDS.  EPI 1: the Lambda reduction of the dense (per-sample-gradient) form -- see
+// kf_lambda_conv2d_accum: rows = (o, sample), so a 256-row tile spans at most two values of o when group_rows >= 256.
+template <int EPI>
 __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Args v) {
     const RotateArgs& a = v.r;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -368,8 +373,6 @@ __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Arg
     const int m0 = tm * 256, n0 = tn * 256;
 
     pp::Sources src;
-    src.kt_a = 64;
-    src.kt_b = 64;
     pp::make_sources(src, wave, lane,
                      [&](int row) { return a.A + static_cast<int64_t>(min(m0 + row, a.M - 1)) * a.lda; },
                      [&](int row) { return a.B + static_cast<int64_t>(min(n0 + row, a.N - 1)) * a.ldb; });
@@ -380,7 +383,34 @@ __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Arg
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pp::mainloop(acc, sm, src, a.KT, wave, lane);
+    pp::mainloop(acc, sm, src, a.KT, wave, lane, [](int t) { return t * 64; }, [](int t) { return t * 64; });
+    if constexpr (EPI == 1) {
+        const int first = m0 / v.group_rows;                          // group of the tile's first row
+        const int limit = min(256, a.M - m0);                         // rows of the tile that exist
+        const int boundary = min(limit, (first + 1) * v.group_rows - m0);   // in-tile row where the next group starts
+        const float a2 = a.alpha * a.alpha;
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            float s0 = 0.0f, s1 = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    const float sq = acc[i][jn][r] * acc[i][jn][r];
+                    s0 += ml < boundary ? sq : 0.0f;
+                    s1 += (ml >= boundary && ml < limit) ? sq : 0.0f;
+                }
+            s0 += __shfl_xor(s0, 32);   // the other 16 rows of every 32 x 32 block sit in lane ^ 32
+            s1 += __shfl_xor(s1, 32);
+            const int n = n0 + wn * 64 + jn * 32 + (lane & 31);
+            if (lane < 32 && n < a.N) {
+                atomicAdd(v.sumsq + static_cast<int64_t>(first) * v.ld_sumsq + n, a2 * s0);
+                if (boundary < limit) atomicAdd(v.sumsq + static_cast<int64_t>(first + 1) * v.ld_sumsq + n, a2 * s1);
+            }
+        }
+        return;
+    }
     __syncthreads();  // every wave is done with the stage buffers: the epilogue reuses them
     // epilogue: element (ml, nl) of the tile as bf16 at ml * 512 + (((nl >> 3) ^ (ml & 31)) << 4) + (nl & 7) * 2
 #pragma unroll
@@ -427,6 +457,7 @@ inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A
 // ------------------------------------------------------------------------------------------------
 struct PsgV2Args {
     uint16_t* out; int64_t out_tile_stride;     // element (n, d) at (d >> 6) * out_tile_stride + n * 64 + (d & 63)
+    int out_rows;                               // != 0: plain rows ordered (m, sample) instead: element at ((m * batch + n) * N + i)
     const uint16_t* A; int64_t a_sample_stride; // [batch][M][K]
     const uint16_t* B; int64_t b_sample_stride; // plain: [batch][N][K]; conv: [phase][batch][C][Hp][Wq]
     int M, N, K;                                // K % 64 == 0
@@ -541,9 +572,138 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
         const int m = m0 + ml, n = n0 + ch * 8;
         if (m < a.M && n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
             const int64_t d = static_cast<int64_t>(m) * a.N + n;
-            const int64_t idx = (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
+            const int64_t idx = a.out_rows ? (static_cast<int64_t>(m) * a.batch + z) * a.N + n
+                                           : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
             *reinterpret_cast<u32x4*>(a.out + idx) = *reinterpret_cast<const u32x4*>(sm + ml * OP + ch * 16);
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 3: the same per-sample-gradient tiles from PERSISTENT workgroups.  A workgroup walks a strided list of (sample,
+// tile) items of its XCD's range and keeps the two-stage LDS-DMA pipeline running ACROSS item boundaries: while the last
+// k-step of an item is being multiplied, the first k-step of the next item is already on its way, and it lands during the
+// bf16 epilogue.  In the v2 kernel every item (1-16 k-steps: K = R = 64 .. 1024) paid a full DMA round trip before its first
+// MFMA and there was one workgroup launch per item.  The epilogue stages its bf16 tile in the stage buffer that was consumed
+// last (128 rows x 256 B = 32 KB exactly), so LDS stays at 64 KB and two workgroups share a CU as before.
+// ------------------------------------------------------------------------------------------------
+struct PsgItem {
+    const uint16_t* src_a[4];
+    const uint16_t* src_b[4];
+    int oct[4];
+    int m0, n0, z;
+};
+
+__device__ __forceinline__ bool psg_decode(const PsgV2Args& a, int64_t item, int64_t items, int wave, int lane, PsgItem& it) {
+    constexpr int PSG_ZB = 8;
+    const int tiles = a.tiles_m * a.tiles_n;
+    if (item >= items) return false;
+    const int64_t zb = item / (static_cast<int64_t>(tiles) * PSG_ZB);
+    const int rem = static_cast<int>(item - zb * tiles * PSG_ZB);
+    const int tile = rem / PSG_ZB;
+    it.z = static_cast<int>(zb) * PSG_ZB + rem % PSG_ZB;
+    if (it.z >= a.batch) return false;   // padding sample of the last block of 8: the caller moves on to its next item
+    it.m0 = (tile / a.tiles_n) * 128;
+    it.n0 = (tile % a.tiles_n) * 128;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int row = (wave * 4 + t) * 8 + (lane >> 3);
+        it.oct[t] = (lane & 7) ^ lds_swz(row);
+        const int m = min(it.m0 + row, a.M - 1);
+        it.src_a[t] = a.A + static_cast<int64_t>(it.z) * a.a_sample_stride + static_cast<int64_t>(m) * a.K + it.oct[t] * 8;
+        const int i = min(it.n0 + row, a.N - 1);
+        if (a.conv) {
+            const int shift = i / a.C, c = i - shift * a.C;
+            const int ky = shift / a.k2, kx = shift - ky * a.k2;
+            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
+            it.src_b[t] = a.B + phase * a.phase_stride + static_cast<int64_t>(it.z) * a.b_sample_stride +
+                          static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
+        } else {
+            it.src_b[t] = a.B + static_cast<int64_t>(it.z) * a.b_sample_stride + static_cast<int64_t>(i) * a.K + it.oct[t] * 8;
+        }
+    }
+    return true;
+}
+
+__device__ __forceinline__ void psg_stage(const PsgV2Args& a, const PsgItem& it, unsigned char* sm, int buf, int k0, int wave) {
+    unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) glds16(it.src_a[t] + k0, base + t * 1024);
+    if (a.conv) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int p0 = k0 + it.oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2;
+            glds16(it.src_b[t] + oy * a.s1 * a.Wq + ox, base + PV2_OPERAND_BYTES + t * 1024);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(it.src_b[t] + k0, base + PV2_OPERAND_BYTES + t * 1024);
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
+    constexpr int PSG_ZB = 8;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t zblocks = (a.batch + PSG_ZB - 1) / PSG_ZB;
+    const int64_t items = zblocks * PSG_ZB * tiles, per_xcd = (items + 7) / 8;
+    // workgroup L serves XCD L % 8: items xcd * per_xcd + j for j = L / 8, L / 8 + gridDim / 8, ...
+    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int64_t first = static_cast<int64_t>(xcd) * per_xcd, last = min(items, first + per_xcd);
+    int64_t item = first + (blockIdx.x >> 3);
+    PsgItem cur, nxt;
+    while (item < last && !psg_decode(a, item, items, wave, lane, cur)) item += stride;   // (workgroup-uniform)
+    bool have = item < last;
+    if (!have) return;
+    const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+    psg_stage(a, cur, sm, 0, 0, wave);
+    __builtin_amdgcn_s_waitcnt(0);
+    __syncthreads();
+    int buf = 0;
+    while (have) {
+        int64_t next_item = item + stride;
+        while (next_item < last && !psg_decode(a, next_item, items, wave, lane, nxt)) next_item += stride;
+        const bool have_next = next_item < last;
+        f32x16 acc[2][2];
+        zero_acc(acc);
+        for (int k0 = 0; k0 < a.K; k0 += 64) {
+            if (k0 + 64 < a.K) psg_stage(a, cur, sm, buf ^ 1, k0 + 64, wave);
+            else if (have_next) psg_stage(a, nxt, sm, buf ^ 1, 0, wave);   // the next item's first k-step rides behind this one
+            const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
+            const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
+            wave_kstep_64x64(acc, sa, sb, hi, sw);
+            __builtin_amdgcn_s_waitcnt(0);
+            __syncthreads();
+            buf ^= 1;
+        }
+        // `buf` now holds the next item's first k-step (landed); `buf ^ 1` was consumed last and stages the bf16 tile
+        unsigned char* ep = sm + (buf ^ 1) * PV2_STAGE_BYTES;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = acc_row(wm, ti, r, lane), nl = acc_col(wn, tj, lane);
+                    *reinterpret_cast<__bf16*>(ep + ml * 256 + nl * 2) = static_cast<__bf16>(acc[ti][tj][r]);
+                }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int id = tid + 256 * it, ml = id >> 4, ch = id & 15;
+            const int m = cur.m0 + ml, n = cur.n0 + ch * 8;
+            if (m < a.M && n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
+                const int64_t d = static_cast<int64_t>(m) * a.N + n;
+                const int64_t idx = a.out_rows ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
+                                               : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63);
+                *reinterpret_cast<u32x4*>(a.out + idx) = *reinterpret_cast<const u32x4*>(ep + ml * 256 + ch * 16);
+            }
+        }
+        __syncthreads();   // the staging buffer is free again before the next k-step's DMA is issued into it
+        cur = nxt;
+        item = next_item;
+        have = have_next;
     }
 }
 
@@ -813,8 +973,10 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
@@ -854,6 +1016,12 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
     p.tiles_m = static_cast<int>(cdiv(p.M, 128)); p.tiles_n = static_cast<int>(cdiv(p.N, 128));
     const int64_t blocks = 8 * cdiv(cdiv(p.batch, 8) * 8 * p.tiles_m * p.tiles_n, 8);  // PSG_ZB = 8 samples per block
     if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+    if (engine_generation() == 3) {
+        // persistent: two resident workgroups per CU (64 KB of LDS each), 512 in all, each walking its XCD's item range
+        const int64_t grid = std::min<int64_t>(blocks, 512);
+        hipLaunchKernelGGL(psg_gemm_v3_kernel, dim3(static_cast<unsigned>(grid)), dim3(NTHREADS), PV2_SMEM, st, p);
+        return launch_status();
+    }
     hipLaunchKernelGGL(psg_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), PV2_SMEM, st, p);
     return launch_status();
 }
@@ -886,7 +1054,7 @@ int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void*
     if (engine_generation() == 3) {
         RotateV3Args v{};
         v.r = r;
-        hipLaunchKernelGGL(rotate_gemm_v3_kernel, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, as_stream(stream), v);
+        hipLaunchKernelGGL(rotate_gemm_v3_kernel<0>, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, as_stream(stream), v);
         return launch_status();
     }
     hipLaunchKernelGGL(rotate_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), 2 * 512 * 128, as_stream(stream), r);
@@ -963,7 +1131,7 @@ int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_til
         gsrc = grid;
     }
     PsgV2Args g;
-    g.out = psg; g.out_tile_stride = b * 64;
+    g.out = psg; g.out_tile_stride = b * 64; g.out_rows = 0;
     g.A = gsrc; g.a_sample_stride = O * c.Pp;
     g.B = copies; g.b_sample_stride = c.Cp * c.Hp * c.Wq;
     g.M = static_cast<int>(O); g.N = static_cast<int>(c.Ipp); g.K = static_cast<int>(c.Pp); g.batch = static_cast<int>(b);
@@ -972,6 +1140,59 @@ int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_til
     int rc = launch_psg_v2(g, st);
     if (rc != KF_OK) return rc;
     return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, c.D, scale, st);
+}
+
+int64_t kf_lambda_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2,
+                                         int p1, int p2, int d1, int d2) {
+    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    // the dense Lambda form contracts over the (padded) patch axis on the 64-deep LDS-DMA engine and folds rows (o, sample)
+    // of a 256-row tile into at most two rows of Lambda: whole k-steps, real output grid, >= 256 samples
+    if (!c.ok || c.grid_bytes != 0 || c.Ipp % 64 != 0 || b < 256 || O * b >= (1LL << 31) - 256) return -1;
+    return c.copies_bytes + align256(2 * b * O * c.Ipp);
+}
+
+int kf_lambda_conv2d_accum(float* Lambda, int64_t ld_lambda, const void* Gt_nchw, const void* x, int64_t b, int64_t C, int64_t H,
+                           int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2, const void* QaT_perm,
+                           int64_t n_out, int64_t ldq, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!Lambda || !Gt_nchw || !x || !QaT_perm || b < 0 || C <= 0 || O <= 0 || n_out <= 0) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t need = kf_lambda_conv2d_workspace_bytes(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    if (need < 0) return KF_ERR_INVALID_ARGUMENT;
+    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    if (ldq < c.Ipp || ldq % 8 != 0 || n_out > ld_lambda ||
+        ((reinterpret_cast<uintptr_t>(Gt_nchw) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(QaT_perm)) & 15) != 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < need) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    hipStream_t st = as_stream(stream);
+    uint16_t* copies = reinterpret_cast<uint16_t*>(workspace);
+    uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + c.copies_bytes);
+    PadArgs pa;
+    pa.out = copies; pa.x = reinterpret_cast<const uint16_t*>(x); pa.planes = b * c.Cp; pa.C = static_cast<int>(C); pa.Cp = static_cast<int>(c.Cp);
+    pa.H = static_cast<int>(H); pa.W = static_cast<int>(W); pa.Hp = static_cast<int>(c.Hp); pa.Wq = static_cast<int>(c.Wq);
+    pa.p1 = p1; pa.p2 = p2; pa.s2 = s2;
+    const int64_t chunks = s2 * b * c.Cp * c.Hp * (c.Wq / 8);
+    hipLaunchKernelGGL(conv_pad_phases_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(chunks, 256), 1 << 20))), dim3(256), 0,
+                       st, pa);
+    // per-sample gradients in the gradient eigenbasis, rows ordered (o, sample), patch axis (ky, kx, c)
+    PsgV2Args g;
+    g.out = psg; g.out_tile_stride = 0; g.out_rows = 1;
+    g.A = reinterpret_cast<const uint16_t*>(Gt_nchw); g.a_sample_stride = O * c.Pp;
+    g.B = copies; g.b_sample_stride = c.Cp * c.Hp * c.Wq;
+    g.M = static_cast<int>(O); g.N = static_cast<int>(c.Ipp); g.K = static_cast<int>(c.Pp); g.batch = static_cast<int>(b);
+    g.conv = 1; g.C = static_cast<int>(c.Cp); g.k2 = k2; g.O2 = static_cast<int>(c.O2p); g.s1 = s1; g.d1 = d1; g.s2 = s2; g.d2 = d2;
+    g.Wq = static_cast<int>(c.Wq); g.plane = static_cast<int>(c.Hp * c.Wq); g.phase_stride = b * c.Cp * c.Hp * c.Wq;
+    int rc = launch_psg_v2(g, st);
+    if (rc != KF_OK) return rc;
+    // Lambda[o, i'] += scale^2 * sum_n ( sum_j psg[(o, n), j] Qa[j, i'] )^2
+    RotateV3Args v{};
+    v.r.C = nullptr; v.r.ldc = 0; v.r.A = psg; v.r.lda = c.Ipp; v.r.B = reinterpret_cast<const uint16_t*>(QaT_perm); v.r.ldb = ldq;
+    v.r.M = static_cast<int>(O * b); v.r.N = static_cast<int>(n_out); v.r.KT = static_cast<int>(c.Ipp / 64);
+    v.r.tiles_m = static_cast<int>(cdiv(O * b, 256)); v.r.tiles_n = static_cast<int>(cdiv(n_out, 256));
+    v.r.alpha = scale; v.r.row_add = nullptr; v.r.row_add_n = 0;
+    v.sumsq = Lambda; v.ld_sumsq = ld_lambda; v.group_rows = static_cast<int>(b);
+    const int64_t blocks = 8 * cdiv(static_cast<int64_t>(v.r.tiles_m) * v.r.tiles_n, 8);
+    hipLaunchKernelGGL(rotate_gemm_v3_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v);
+    return launch_status();
 }
 
 int64_t kf_pairwise_rows_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip) {
@@ -1003,7 +1224,7 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
     hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(Ip, 64)), static_cast<unsigned>(b)),
                        dim3(256), 0, st, t);
     PsgV2Args g;
-    g.out = psg; g.out_tile_stride = b * 64;
+    g.out = psg; g.out_tile_stride = b * 64; g.out_rows = 0;
     g.A = gt; g.a_sample_stride = O * R; g.B = at; g.b_sample_stride = Ip * R;
     g.M = static_cast<int>(O); g.N = static_cast<int>(Ip); g.K = static_cast<int>(R); g.batch = static_cast<int>(b);
     g.conv = 0; g.C = 1; g.k2 = 1; g.O2 = 8; g.s1 = 1; g.d1 = 1; g.s2 = 1; g.d2 = 1; g.Wq = 8; g.plane = 0; g.phase_stride = 0;

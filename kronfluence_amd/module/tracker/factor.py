@@ -111,6 +111,48 @@ class LambdaTracker(BaseTracker):
         return storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
 
     _bf16_eigenvectors = None  # (Q_A^T, Q_G^T) in bf16, for lambda_dtype == bf16
+    _conv_dense_eigenvectors = None  # (Q_A^T in the implicit-im2col patch order, Q_G) in bf16
+
+    # Conv2d layers with more output positions than output channels (R > O: the early ResNet-9 stages) fit Lambda in the
+    # DENSE form -- per-sample gradient first (implicit im2col, gradient side already rotated), then ONE tall GEMM with
+    # Q_A whose epilogue squares and sums -- instead of rotating the [b R, I'] patch matrix: fewer flops (SURVEY.md 8d:
+    # F_lambda is the cheaper of the two exact forms) and no patch tensor.  ``kf_lambda_conv2d_accum``.
+    CONV_DENSE = True
+
+    @staticmethod
+    def algorithmic_flops(r: int, o: int, ip: int) -> float:
+        """F_lambda per sample: the cheaper of the dense and the factored exact formulations."""
+        dense = 2.0 * o * ip * (ip + o) + (2.0 * r * o * ip if r > 1 else 0.0)
+        return min(dense, 2.0 * r * (ip * ip + o * o + o * ip))
+
+    def _update_conv_dense(self, activation: torch.Tensor, output_gradient: torch.Tensor) -> bool:
+        module, storage, conv = self.module, self.module.storage, self.module.original_module
+        if not (self.CONV_DENSE and isinstance(conv, nn.Conv2d) and activation.dim() == 4 and output_gradient.dim() == 4
+                and module.factor_args.lambda_dtype == torch.bfloat16 and output_gradient.dtype == torch.bfloat16
+                and output_gradient.is_cuda and self._rotates()):
+            return False
+        b, c = activation.shape[0], activation.shape[1]
+        o, r = output_gradient.shape[1], output_gradient.shape[2] * output_gradient.shape[3]
+        taps = conv.kernel_size[0] * conv.kernel_size[1]
+        ip = c * taps
+        dense = 2.0 * r * o * ip + 2.0 * o * ip * ip + 2.0 * r * o * o   # gradient + Q_A GEMM + channel rotation
+        if dense >= 2.0 * r * (ip * ip + o * o + o * ip) or o % 8 != 0:
+            return False
+        geometry = ops.lambda_conv2d_geometry(tuple(activation.shape), o, conv)
+        if geometry is None:
+            return False
+        q_a, q_g = self._eigenvectors(output_gradient.device)
+        if storage[LAMBDA_MATRIX_NAME] is None:
+            storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=output_gradient.device)
+            storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
+        storage[NUM_LAMBDA_PROCESSED].add_(b)
+        if self._conv_dense_eigenvectors is None:
+            self._conv_dense_eigenvectors = (ops.conv_patch_order_eigenvectors(q_a, c, taps), q_g.to(torch.bfloat16).contiguous())
+        qa_t_perm, qg16 = self._conv_dense_eigenvectors
+        x = activation if activation.dtype == torch.bfloat16 else activation.to(torch.bfloat16)
+        gt = ops.rotate_channels(output_gradient, qg16)
+        ops.lambda_conv2d_accum(storage[LAMBDA_MATRIX_NAME], gt, x, geometry, qa_t_perm, scale=module.gradient_scale)
+        return True
 
     def _rotates(self) -> bool:
         """EK-FAC fits Lambda in the Kronecker eigenbasis; the diagonal strategy in parameter space
@@ -198,8 +240,16 @@ class LambdaTracker(BaseTracker):
             activation = self._take_activation()
             self.cached_hooks.pop().remove()
             if module.per_sample_gradient_process_fnc is None:
-                g, a, ones = module.gradient_factors(activation, output_gradient.detach())
-                self._update_from_factors(g, a, ones)
+                weight = module.original_module.weight
+                o, ip = weight.shape[0], weight[0].numel() + int(module.has_bias)
+                rows = output_gradient.numel() // (output_gradient.shape[0] * o)
+                # "lambda_update": the whole Lambda update of this hook (rotations included) against F_lambda
+                with ops._Timed("lambda_update", output_gradient.device,
+                                output_gradient.shape[0] * self.algorithmic_flops(rows, o, ip),
+                                float(output_gradient.numel() + activation.numel()) * output_gradient.element_size()):
+                    if not self._update_conv_dense(activation, output_gradient.detach()):
+                        g, a, ones = module.gradient_factors(activation, output_gradient.detach())
+                        self._update_from_factors(g, a, ones)
             else:
                 self._update_from_gradient(module.compute_per_sample_gradient(activation, output_gradient.detach()))
 
@@ -234,5 +284,6 @@ class LambdaTracker(BaseTracker):
     def release_memory(self) -> None:
         self.clear_all_cache()
         self._bf16_eigenvectors = None
+        self._conv_dense_eigenvectors = None
         for name in LAMBDA_FACTOR_NAMES:
             self.module.storage[name] = None

@@ -429,6 +429,72 @@ def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, 
         )
 
 
+def rotate_channels(g_nchw: torch.Tensor, q: torch.Tensor) -> torch.Tensor:
+    """``out[n, o', p] = sum_o q[o, o'] g[n, o, p]`` for an NCHW bf16 tensor and ``q``: bf16 ``[O, O]`` -- the gradient-side
+    eigenbasis rotation applied along the channel axis, result in the same NCHW layout (batched TN product on the bf16 engine)."""
+    nat.require_device(g_nchw, "g_nchw")
+    g_nchw, q = _contig(g_nchw), _contig(q)
+    b, o = g_nchw.shape[0], g_nchw.shape[1]
+    p = g_nchw.numel() // (b * o)
+    _require(q.shape == (o, o) and q.dtype == g_nchw.dtype == torch.bfloat16 and o % 8 == 0 and p % 8 == 0,
+             "rotate_channels: bf16 operands, O and the positions multiples of 8")
+    out = torch.empty_like(g_nchw)
+    nat.check(
+        nat.lib().kf_gemm_out(out.data_ptr(), nat.dtype_code(out.dtype), p, o * p, ctypes.byref(view(q, 0, 1, o, o, o)),
+                              ctypes.byref(view(g_nchw, o * p, 1, p, p, o)), b, 1.0, nat.stream_ptr(g_nchw.device)),
+        "kf_gemm_out",
+    )
+    return out
+
+
+def lambda_conv2d_geometry(x_shape, out_channels: int, conv: nn.Conv2d):
+    """Geometry tuple of the dense-form Lambda call, or ``None`` when the layer / batch is not eligible (decided by the library:
+    ``kf_lambda_conv2d_workspace_bytes`` returns -1)."""
+    if conv.groups != 1 or conv.bias is not None:
+        return None
+    b, c, h, w = x_shape
+    geometry = (b, c, h, w, out_channels) + conv_geometry(conv)
+    return geometry if nat.lib().kf_lambda_conv2d_workspace_bytes(*geometry) > 0 else None
+
+
+def lambda_conv2d_accum(lam: torch.Tensor, gt_nchw: torch.Tensor, x: torch.Tensor, geometry, qa_t_perm: torch.Tensor,
+                        scale: float = 1.0) -> None:
+    """``lam += scale^2 * sum_n (Qg^T g_n Qa)^2`` of a Conv2d layer in the dense form with implicit im2col
+    (kf_lambda_conv2d_accum; tracker/factor.py:218-226 + module/conv2d.py:164-177).  ``gt_nchw``: the output gradient already
+    rotated along its channel axis (``rotate_channels``); ``qa_t_perm``: see ``conv_patch_order_eigenvectors``."""
+    nat.require_device(lam, "lam")
+    gt_nchw, x, qa_t_perm = _contig(gt_nchw), _contig(x), _contig(qa_t_perm)
+    _require(lam.dtype == torch.float32 and lam.is_contiguous() and gt_nchw.dtype == x.dtype == qa_t_perm.dtype == torch.bfloat16,
+             "lambda_conv2d_accum: fp32 Lambda, bf16 operands")
+    o, ip = lam.shape
+    b, c, h, w = x.shape
+    k1, k2 = geometry[5], geometry[6]
+    r = gt_nchw.shape[2] * gt_nchw.shape[3]
+    _require(gt_nchw.shape[:2] == (b, o) and ip == c * k1 * k2 and qa_t_perm.shape[0] >= ip, "lambda_conv2d_accum: shapes")
+    ws_bytes = nat.lib().kf_lambda_conv2d_workspace_bytes(*geometry)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    flops = 2.0 * b * r * o * ip + 2.0 * b * o * ip * ip
+    with _Timed("lambda_accum", lam.device, flops, float(b) * (r * o + c * h * w) * 2):
+        nat.check(
+            nat.lib().kf_lambda_conv2d_accum(lam.data_ptr(), lam.shape[1], gt_nchw.data_ptr(), x.data_ptr(), *geometry,
+                                             qa_t_perm.data_ptr(), ip, qa_t_perm.shape[1], scale, ws.data_ptr(), ws_bytes,
+                                             nat.stream_ptr(x.device)),
+            "kf_lambda_conv2d_accum",
+        )
+
+
+def conv_patch_order_eigenvectors(q_a: torch.Tensor, channels: int, taps: int) -> torch.Tensor:
+    """``Q_A^T`` for the implicit-im2col kernels: bf16 ``[I' rounded up to 8, taps * Cp]`` whose row ``i'`` is column ``i'`` of
+    ``q_a`` with its rows re-ordered from the reference's patch order ``(c, ky, kx)`` to the kernels' ``(ky, kx, c)``, ``c``
+    zero-padded to ``Cp`` = a multiple of 8."""
+    ip = q_a.shape[0]
+    cp = channels + (-channels) % 8
+    q = q_a.reshape(channels, taps, ip).transpose(0, 1)              # [taps, C, I']
+    q = torch.nn.functional.pad(q, (0, 0, 0, cp - channels))          # [taps, Cp, I']
+    out = q.reshape(taps * cp, ip).t()                               # [I', taps * Cp]
+    return torch.nn.functional.pad(out, (0, 0, 0, (-ip) % 8)).to(torch.bfloat16).contiguous()
+
+
 # ---------------------------------------------------------------------------------------------
 # Stage 3: preconditioning and pairwise scores
 # ---------------------------------------------------------------------------------------------

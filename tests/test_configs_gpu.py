@@ -7,8 +7,10 @@
     and the 2-row classifier are all in play, and nothing upstream of the hooks can differ.
       covariances  all tracked layers                                        rel_F <= 2e-5, counters exact
       Lambda       a sub-set of layers, product's own eigenvectors           rel_F <= 5e-2 (bf16 lambda_dtype)
-      scores       the same sub-set (per-module scores), default damping     rel_F <= 3e-2 / 6e-2 (bf16 P and gradients;
-                   bf16-rounded / exact eigenvectors in the oracle), and the sum over ALL modules is the "all_modules" run
+      scores       the same sub-set (per-module scores), default damping     rel_F <= 3e-2 (bf16 P and gradients; the oracle is
+                   given the bf16-rounded eigenvectors the reference's ``Ekfac.prepare`` would use, factor/config.py:323-328;
+                   the error against EXACT eigenvectors is printed, not bounded: with 8-24 train samples Lambda is rank
+                   deficient and damping 1e-8 amplifies the cast itself), and the sum over ALL modules is the "all_modules" run
 (c) ``kf_eigh_f64`` at d = 3073 and 4096 (the BERT / GPT-2 / Llama attention-side sizes): eigenvalues vs LAPACK
     (``torch.linalg.eigh`` fp64 on the host) <= 1e-10 lambda_max, orthogonality / reconstruction <= 1e-11, ascending.
 (d) ONE Llama-3-8B MLP projection at its FULL width (14336 x 4096 and 4096 x 14336, T = 512, no bias,
@@ -122,10 +124,13 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
             flat, c = ref.linear_flat_gradient(g.double().cpu(), mask)
             ref.covariance_update(want_g, flat)
             count_g += int(c)
+        if low_cov:  # the factors are exported in the covariance dtype (bf16): compare with the oracle's sums rounded likewise
+            want_a, want_g = want_a.to(torch.bfloat16), want_g.to(torch.bfloat16)
         ea = rel(cov["activation_covariance"][m.name], want_a)
         eg = rel(cov["gradient_covariance"][m.name], want_g)
         worst["activation"], worst["gradient"] = max(worst["activation"], ea), max(worst["gradient"], eg)
-        assert ea <= 2e-5 and eg <= 2e-5, (m.name, ea, eg)
+        bound = 2e-4 if low_cov else 2e-5  # bf16 export: an fp32-vs-fp64 difference can flip a rounding (one 2^-8 ulp, rarely)
+        assert ea <= bound and eg <= bound, (m.name, ea, eg)
         assert int(cov["num_activation_covariance_processed"][m.name]) == count_a, m.name
         assert int(cov["num_gradient_covariance_processed"][m.name]) == count_g, m.name
     print(f"{name}: covariance rel_F vs fp64 oracle on the hooked tensors, worst of {len(tracked)} layers: {worst}")
@@ -189,7 +194,7 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
                               for xt, gt in trains], dim=1)
             errs.append(rel(per[mod], want))
         score_err[mod] = errs
-        assert errs[0] <= 3e-2 and errs[1] <= 6e-2, score_err
+        assert errs[0] <= 3e-2, score_err
     print(f"{name}: per-module scores rel_F vs fp64 oracle (bf16-rounded / exact eigenvectors):",
           {k: [f"{e:.1e}" for e in v] for k, v in score_err.items()})
 
@@ -294,8 +299,9 @@ def test_llama_projection_full_width(o, i):
     for key, rows in (("activation_covariance", xs), ("gradient_covariance", gs)):
         want = torch.zeros(rows.shape[1], rows.shape[1], dtype=torch.float64)
         ref.covariance_update(want, rows)
-        err = rel(cov[key]["lin"], want)
-        assert err <= 2e-5, (key, err)
+        assert cov[key]["lin"].dtype == torch.bfloat16  # exported in the covariance dtype, accumulated in fp32
+        err = rel(cov[key]["lin"], want.to(torch.bfloat16))
+        assert err <= 2e-4, (key, err)
     assert int(cov["num_activation_covariance_processed"]["lin"]) == n_train * t
     del cov, want
 

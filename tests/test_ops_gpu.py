@@ -382,6 +382,48 @@ def test_pairwise_score_conv2d_implicit_im2col(ops, c, q):
     assert rel(scores[:, 1:1 + b], 1.5 * v1) <= 2e-3
 
 
+DENSE_LAMBDA_CONVS = [  # b >= 256 (rows (o, sample) of a 256-row tile span at most two o); Cp * k1 * k2 % 64 == 0
+    dict(b=256, cin=64, cout=16, k=3, stride=1, padding=1, dilation=1, hw=(8, 8)),      # I' = 576 (9 k-steps), exact groups
+    dict(b=300, cin=64, cout=24, k=1, stride=1, padding=0, dilation=1, hw=(8, 8)),      # 1x1: I' = 64, ragged groups of 300
+    dict(b=333, cin=8, cout=40, k=(2, 4), stride=1, padding=0, dilation=1, hw=(9, 11)),  # I' = 64, O2 = 8, ragged O
+    dict(b=260, cin=32, cout=8, k=(1, 2), stride=(1, 2), padding=0, dilation=1, hw=(8, 16)),  # strided columns: two phases
+    dict(b=257, cin=20, cout=16, k=(2, 4), stride=1, padding=(1, 2), dilation=1, hw=(7, 15)),  # 20 channels -> 24: Ipp = 192
+]
+
+
+@pytest.mark.parametrize("c", DENSE_LAMBDA_CONVS)
+def test_lambda_conv2d_dense_form(ops, c):
+    """kf_lambda_conv2d_accum (gradient rotated along channels -> implicit-im2col per-sample gradient -> tall GEMM with the
+    sum-of-squares epilogue) against the reference's ``Lambda += sum_b (Qg^T g_b Qa)^2`` (module/tracker/factor.py:218-226 on
+    module/conv2d.py:164-177 gradients) in fp64 on the same bf16 inputs and bf16-rounded eigenvectors.  Bound 2e-2: the
+    rotated gradient factor and the per-sample gradient are each rounded to bf16 once."""
+    conv = nn.Conv2d(c["cin"], c["cout"], c["k"], stride=c["stride"], padding=c["padding"], dilation=c["dilation"], bias=False)
+    b, o = c["b"], c["cout"]
+    x = _rand(b, c["cin"], *c["hw"], dtype=torch.bfloat16)
+    out = conv(x.float())
+    g = _rand(*out.shape, dtype=torch.bfloat16, seed=1)
+    k1, k2 = conv.kernel_size
+    ip = c["cin"] * k1 * k2
+    q_a = torch.linalg.qr(_rand(ip, ip, seed=3).double())[0].float()
+    q_g = torch.linalg.qr(_rand(o, o, seed=4).double())[0].float()
+    geometry = ops.lambda_conv2d_geometry(tuple(x.shape), o, conv)
+    assert geometry is not None
+    qa_t_perm = ops.conv_patch_order_eigenvectors(q_a.to(DEV), c["cin"], k1 * k2)
+    assert qa_t_perm.shape[1] % 64 == 0
+    lam = torch.zeros(o, ip, device=DEV)
+    for scale in (1.0, 0.5):  # "+=" and gradient_scale
+        gt = ops.rotate_channels(g.to(DEV), q_g.to(DEV).to(torch.bfloat16))
+        ops.lambda_conv2d_accum(lam, gt, x.to(DEV), geometry, qa_t_perm, scale=scale)
+    want = torch.zeros(o, ip, dtype=torch.float64)
+    psg = ref.conv_per_sample_gradient(x.double(), g.double(), conv.double())
+    ref.lambda_update(want, psg, q_a.to(torch.bfloat16).double(), q_g.to(torch.bfloat16).double())
+    assert rel(lam, 1.25 * want) <= 2e-2, rel(lam, 1.25 * want)
+    # the channel rotation on its own: out[n, o', p] = sum_o q[o, o'] g[n, o, p]
+    gt = ops.rotate_channels(g.to(DEV), q_g.to(DEV).to(torch.bfloat16))
+    want_gt = torch.einsum("ok,nohw->nkhw", q_g.to(torch.bfloat16).double(), g.double())
+    assert rel(gt, want_gt) <= 4e-3
+
+
 @pytest.mark.parametrize("q,b,r,o,i,bias", [(5, 6, 64, 64, 128, True), (300, 9, 128, 136, 72, True), (40, 3, 512, 72, 768, False),
                                              (7, 4, 64, 8, 8, True)])
 def test_pairwise_score_rows_v2(ops, q, b, r, o, i, bias):
