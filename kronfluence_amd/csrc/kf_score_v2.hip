@@ -754,13 +754,18 @@ __global__ __launch_bounds__(256) void conv_pad_phases_kernel(PadArgs a) {
 struct TransposeArgs {
     uint16_t* out; const uint16_t* x;
     int T, C, Cp, ones;
-    const void* mask; int mask_dtype;  // nullable [batch * T] 0/1 mask (KF_I64 / KF_I32 / KF_U8): masked rows (incl. their one) -> 0
+    const void* mask; int mask_dtype;  // nullable [batch * T] integer mask (KF_I64 / KF_I32 / KF_U8): every row (incl. its one) times its mask value
 };
 
-__device__ __forceinline__ bool mask_on(const void* mask, int dtype, int64_t idx) {
-    if (dtype == I64) return reinterpret_cast<const int64_t*>(mask)[idx] != 0;
-    if (dtype == I32) return reinterpret_cast<const int32_t*>(mask)[idx] != 0;
-    return reinterpret_cast<const uint8_t*>(mask)[idx] != 0;
+__device__ __forceinline__ float mask_value(const void* mask, int dtype, int64_t idx) {
+    if (dtype == I64) return static_cast<float>(reinterpret_cast<const int64_t*>(mask)[idx]);
+    if (dtype == I32) return static_cast<float>(reinterpret_cast<const int32_t*>(mask)[idx]);
+    return static_cast<float>(reinterpret_cast<const uint8_t*>(mask)[idx]);
+}
+
+__device__ __forceinline__ uint32_t scale_bf16_pair(uint32_t w, float m) {  // both bf16 halves of w times m, rounded to bf16
+    const __bf16 lo = static_cast<__bf16>(__uint_as_float(w << 16) * m), hi = static_cast<__bf16>(__uint_as_float(w & 0xffff0000u) * m);
+    return static_cast<uint32_t>(__builtin_bit_cast(uint16_t, lo)) | (static_cast<uint32_t>(__builtin_bit_cast(uint16_t, hi)) << 16);
 }
 
 __global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
@@ -775,10 +780,16 @@ __global__ __launch_bounds__(256) void transpose_rows_kernel(TransposeArgs a) {
         const int id = threadIdx.x + 256 * it, r = id >> 3, ch = id & 7;
         const int c = c0 + ch * 8;
         u32x4 v = {0u, 0u, 0u, 0u};
-        const bool keep = !a.mask || mask_on(a.mask, a.mask_dtype, z * a.T + t0 + r);
-        if (!keep) { /* masked token: whole row zero (module/linear.py:39-43 multiplies the ones column too) */ }
-        else if (c < a.C) v = *reinterpret_cast<const u32x4*>(x + static_cast<int64_t>(t0 + r) * a.C + c);
-        else if (a.ones && c == a.C) v[0] = 0x3f80u;  // bf16 1.0 in column C, zeros after it
+        // the row times its mask value, bias one included (module/linear.py:39-43 multiplies both): 0 -> zeros, 1 -> a copy,
+        // anything else (a weighted integer mask) -> the product rounded to bf16, as the reference's in-place ``mul_`` does
+        const float mv = a.mask ? mask_value(a.mask, a.mask_dtype, z * a.T + t0 + r) : 1.0f;
+        if (mv == 0.0f) { /* masked token: whole row zero */ }
+        else if (c < a.C) {
+            v = *reinterpret_cast<const u32x4*>(x + static_cast<int64_t>(t0 + r) * a.C + c);
+            if (mv != 1.0f) v = u32x4{scale_bf16_pair(v[0], mv), scale_bf16_pair(v[1], mv), scale_bf16_pair(v[2], mv), scale_bf16_pair(v[3], mv)};
+        } else if (a.ones && c == a.C) {
+            v[0] = static_cast<uint32_t>(__builtin_bit_cast(uint16_t, static_cast<__bf16>(mv)));  // column C: the (masked) one, zeros after it
+        }
         uint16_t* d = &tile[r][ch * 8];
         d[0] = static_cast<uint16_t>(v[0]); d[1] = static_cast<uint16_t>(v[0] >> 16);
         d[2] = static_cast<uint16_t>(v[1]); d[3] = static_cast<uint16_t>(v[1] >> 16);
@@ -919,10 +930,77 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
             }
 }
 
+// Round 3: the covariance contraction on the wave-role-split 256 x 256 main loop (kf_pingpong.h).  Same work items as the
+// v2 kernel -- (sample range, upper-triangular tile pair), sample range major per XCD -- with 256-row tiles: one k-tile of the
+// loop is one (sample, k-step), walked without a break; the 8 DMA requests of a lane share one k-octet, so the implicit-im2col
+// offset (one division by the output width) is computed once per k-tile and lane.  A 128 x 128 / 4-wave tile issues twice
+// the LDS-DMA requests per MFMA of this one, which is what bound the v2 kernel (485 TFLOP/s with its epilogue switched off).
+__global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int pairs = a.tiles * (a.tiles + 1) / 2;
+    const int64_t items = static_cast<int64_t>(a.zblocks) * pairs, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, jx = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + jx;
+    if (jx >= per_xcd || item >= items) return;
+    const int zb = static_cast<int>(item / pairs);
+    int t = static_cast<int>(item % pairs), ti = 0;
+    while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
+    const int tj = ti + t;
+    const int m0 = ti * 256, n0 = tj * 256;
+    const int z_begin = zb * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
+    if (z_begin >= z_end) return;
+
+    const int oct = pp::lane_octet(wave, lane);
+    auto row_source = [&](int i) -> const uint16_t* {
+        if (a.conv) {
+            const int shift = i / a.Cp, c = i - shift * a.Cp;
+            const int ky = shift / a.k2, kx = shift - ky * a.k2;
+            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
+            return a.X + phase * a.phase_stride + static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
+        }
+        return a.X + static_cast<int64_t>(i) * a.K + oct * 8;
+    };
+    pp::Sources src;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int row = pp::request_row0(r, wave) + (lane >> 3);
+        src.p[r] = row_source(min((r < 4 ? m0 : n0) + row, a.N - 1));
+    }
+    const int ksteps = a.K >> 6;
+    const int64_t base = static_cast<int64_t>(z_begin) * a.sample_stride;
+    auto walk = [&](int kt) -> int64_t {   // k-tile kt of this item = sample z_begin + kt / ksteps, k-step kt % ksteps
+        const int zq = kt / ksteps, k0 = (kt - zq * ksteps) * 64;
+        int koff = k0;
+        if (a.conv) { const int p0 = k0 + oct * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
+        return base + static_cast<int64_t>(zq) * a.sample_stride + koff;
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    pp::mainloop(acc, sm, src, (z_end - z_begin) * ksteps, wave, lane, walk, walk);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = wn * 64 + jn * 32 + (lane & 31);
+                float* dst = a.stage + static_cast<int64_t>(m0 + ml) * a.np + n0 + nl;
+                if (a.plain_store) *dst = acc[i][jn][r];
+                else atomicAdd(dst, acc[i][jn][r]);
+            }
+}
+
 // covariance[i][j] += alpha * stage[p(i)][p(j)] (or its transpose: only tile pairs ti <= tj are computed); p = operand row of
 // covariance index i: identity for plain rows, (i % taps) * Cp + i / taps for the (c, ky, kx) patch order of a convolution.
 struct CovFinalizeArgs {
     float* out; int64_t ldc; const float* stage; int np, d, conv, Cp, taps; float alpha;
+    int tile_shift;   // log2 of the tile size the staging matrix was filled with (7 or 8)
 };
 
 __global__ __launch_bounds__(256) void cov_finalize_kernel(CovFinalizeArgs a) {
@@ -930,18 +1008,46 @@ __global__ __launch_bounds__(256) void cov_finalize_kernel(CovFinalizeArgs a) {
     if (j >= a.d) return;
     int pi = i, pj = j;
     if (a.conv) { pi = (i % a.taps) * a.Cp + i / a.taps; pj = (j % a.taps) * a.Cp + j / a.taps; }
-    if ((pi >> 7) > (pj >> 7)) { const int t = pi; pi = pj; pj = t; }
+    if ((pi >> a.tile_shift) > (pj >> a.tile_shift)) { const int t = pi; pi = pj; pj = t; }
     a.out[static_cast<int64_t>(i) * a.ldc + j] += a.alpha * a.stage[static_cast<int64_t>(pi) * a.np + pj];
 }
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~static_cast<int64_t>(255); }
 inline int64_t cov_stage_bytes(int64_t n_operand_rows) {
-    const int64_t np = cdiv(n_operand_rows, 128) * 128;
+    const int64_t np = cdiv(n_operand_rows, 256) * 256;   // whole 256-row tiles (the v3 kernel; a superset of the v2 need)
     return align256(np * np * 4);
 }
 
+inline int cov_engine(int64_t n_rows) {  // 2 = 128-row tiles / 4 waves, 3 = 256-row tiles on the wave-role-split loop
+    if (const char* e = getenv("KF_COV_ENGINE")) return atoi(e) == 2 ? 2 : 3;
+    if (engine_generation() == 2) return 2;
+    const int64_t t2 = cdiv(n_rows, 128), t3 = cdiv(n_rows, 256);
+    // MFMA work in 128 x 128 units: the 256-row tiling pads more and computes whole diagonal tiles; its loop sustains about
+    // twice the rate of the 4-wave kernel (half the LDS-DMA requests per MFMA)
+    return (t3 * (t3 + 1) / 2) * 4 * 10 <= (t2 * (t2 + 1) / 2) * 17 ? 3 : 2;
+}
+
 // tile geometry, split over sample ranges, launch of the covariance kernel and of its finalize pass
+int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
+    c.tiles = static_cast<int>(cdiv(c.N, 256));
+    c.np = c.tiles * 256;
+    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);
+    // one workgroup per CU (128 KB of LDS): about two rounds of items, each at least 16 k-tiles long
+    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(512, pairs), steps / 16}));
+    c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
+    const int64_t zblocks = cdiv(c.batch, c.zchunk);
+    c.zblocks = static_cast<int>(zblocks);
+    c.plain_store = zblocks == 1;
+    const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
+    if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    hipLaunchKernelGGL(cov_gemm_v3_kernel, grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, c);
+    f.stage = c.stage; f.np = c.np; f.tile_shift = 8;
+    hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
+    return launch_status();
+}
+
 int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
+    if (cov_engine(c.N) == 3) return launch_cov_v3(c, f, st);
     c.tiles = static_cast<int>(cdiv(c.N, 128));
     c.np = c.tiles * 128;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);
@@ -958,7 +1064,7 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
     if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
     hipLaunchKernelGGL(cov_gemm_v2_kernel, grid, dim3(NTHREADS), PV2_SMEM, st, c);
-    f.stage = c.stage; f.np = c.np;
+    f.stage = c.stage; f.np = c.np; f.tile_shift = 7;
     hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();
 }
@@ -977,7 +1083,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
@@ -1241,7 +1348,7 @@ int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int app
 int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T, int64_t d_in, const void* mask, int mask_dtype,
                       int append_ones, float alpha, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!C || !X || b < 0 || T <= 0 || d_in <= 0) return KF_ERR_INVALID_ARGUMENT;
-    if (T % 64 != 0 || d_in % 8 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || b > 65535) return KF_ERR_INVALID_ARGUMENT;
+    if (T % 64 != 0 || d_in % 8 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || b > 65535 || d_in >= 32768) return KF_ERR_INVALID_ARGUMENT;
     if (mask && mask_dtype != KF_I64 && mask_dtype != KF_I32 && mask_dtype != KF_U8) return KF_ERR_UNSUPPORTED_DTYPE;
     if (!workspace || workspace_bytes < kf_syrk_rows_workspace_bytes(b, T, d_in, append_ones)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (b == 0) return KF_OK;
@@ -1268,7 +1375,7 @@ int64_t kf_syrk_planes_workspace_bytes(int64_t d) { return cov_stage_bytes(d); }
 int kf_syrk_planes_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t d, int64_t K, float alpha, void* workspace,
                         int64_t workspace_bytes, void* stream) {
     if (!C || !X || b < 0 || d <= 0 || K <= 0) return KF_ERR_INVALID_ARGUMENT;
-    if (K % 64 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || b > 65535) return KF_ERR_INVALID_ARGUMENT;
+    if (K % 64 != 0 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || b > 65535 || d >= 32768) return KF_ERR_INVALID_ARGUMENT;
     if (!workspace || workspace_bytes < cov_stage_bytes(d)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (b == 0) return KF_OK;
     if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;

@@ -305,6 +305,12 @@ class PairwiseScoreTracker(BaseTracker):
                     tiled, a_in, ones_in = fast
                     ops.pairwise_score(scores, offset, tiled, g, a_in, ones_in, scale=module.gradient_scale)
                 else:
+                    if module.query_padding and not isinstance(preconditioned, (TiledQueries, list)):
+                        # the padded-width kernels do not apply to this batch: strip the zero columns ONCE and keep the
+                        # stripped blocks (a per-batch ``unpadded_queries`` copied the whole query set on every hook call)
+                        preconditioned = unpadded_queries(module, preconditioned)
+                        storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = preconditioned
+                        module.query_padding = 0
                     for first, block in self._query_blocks(unpadded_queries(module, preconditioned)):
                         rows = scores[first:first + block.shape[0]]
                         ops.pairwise_score(rows, offset, block, g, a, ones, scale=module.gradient_scale)

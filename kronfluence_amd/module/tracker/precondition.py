@@ -42,6 +42,7 @@ class PreconditionTracker(BaseTracker):
     # collectives are issued in the same order everywhere.
     ASYNC_QUERY_GATHER = True
     _pending = None  # (work, gathered, local) of the all-gather in flight
+    _held_layout = None  # (block shape, query_padding, queries_in_eigenbasis) of the blocks accumulated so far
 
     def _out_dtype(self) -> torch.dtype:
         """``score_dtype`` of the reference (precondition.py:73): bf16 keeps P in bf16 for the bf16 MFMA
@@ -228,7 +229,19 @@ class PreconditionTracker(BaseTracker):
             capacity = self.module.query_capacity
             storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = (
                 QueryBuffer(new, capacity) if capacity and capacity >= new.shape[0] else QueryBlocks([new.contiguous()]))
+            self._held_layout = (tuple(new.shape[1:]), self.module.query_padding, self.module.queries_in_eigenbasis)
         else:
+            # ``query_padding`` / ``queries_in_eigenbasis`` are per-module flags describing ALL held blocks: a later query
+            # batch laid out differently (a one-row batch after sequence batches, say) is brought to the held layout or refused
+            layout = (tuple(new.shape[1:]), self.module.query_padding, self.module.queries_in_eigenbasis)
+            if layout != self._held_layout:
+                shape, padding, eigen = self._held_layout
+                if eigen != layout[2] or tuple(new.shape[1:-1]) != shape[:-1] or new.shape[-1] - layout[1] != shape[-1] - padding:
+                    raise RuntimeError(
+                        f"Module '{self.module.name}': query batches produced preconditioned gradients in different layouts "
+                        f"({self._held_layout} then {layout}); use query batches of one kind per score call.")
+                new = torch.nn.functional.pad(new[..., :new.shape[-1] - layout[1]], (0, padding))
+                self.module.query_padding = padding
             held.append(new.contiguous())
         storage[PRECONDITIONED_GRADIENT_NAME] = None
 

@@ -30,12 +30,19 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def _contig(t: torch.Tensor) -> torch.Tensor:
+def _contig(t: torch.Tensor, align: bool = True) -> torch.Tensor:
     """Input operand as the kernels want it: contiguous and 16-byte aligned (a contiguous VIEW into a larger tensor, e.g. a
-    slice along the batch axis of an odd-sized sample, may start anywhere; the vector loads / LDS-DMA requests may not)."""
-    if t.is_contiguous() and t.data_ptr() % 16 == 0:
+    slice along the batch axis of an odd-sized sample, may start anywhere; the vector loads / LDS-DMA requests may not).
+    ``align=False``: the consumer reads element-wise (the fp32 covariance / GEMM loaders), so an unaligned contiguous view is
+    taken as it is instead of being cloned."""
+    if t.is_contiguous() and (not align or t.data_ptr() % 16 == 0):
         return t
     return t.clone(memory_format=torch.contiguous_format)
+
+
+def _vector_engines(t: torch.Tensor) -> bool:
+    """Whether ``t``'s dtype is consumed by the 16-byte vector / LDS-DMA engines (bf16, fp16)."""
+    return t.element_size() == 2
 
 
 def view(t: torch.Tensor, batch_stride: int, row_stride: int, k_stride: int, rows: int, depth: int,
@@ -83,12 +90,18 @@ def syrk_accum(cov: torch.Tensor, x: torch.Tensor, n_rows: int, d_in: int, rows_
         )
 
 
+# The staged covariance kernels keep a [d_pad, d_pad] fp32 matrix in their workspace and finalize it with one workgroup row
+# per matrix row (gridDim.y <= 65535): wider layers (a vocabulary-sized head) use kf_syrk_accum, which writes C directly.
+COV_STAGED_MAX_DIM = 32768
+
+
 def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor], has_bias: bool, alpha: float) -> bool:
     """bf16 ``[b, T, d]`` rows of a sequence layer on the LDS-DMA covariance kernel (exact bf16 products, fp32 accumulation);
-    ``False`` when the shape / dtype is not eligible.  The mask must be 0/1 (integer / bool dtype): it is a row select."""
+    ``False`` when the shape / dtype is not eligible.  Integer / bool masks: every row (and its bias one) is multiplied by its
+    mask value inside the transposition kernel (0 and 1 exactly; other weights rounded to bf16 like the reference's ``mul_``)."""
     d_in = x.shape[-1]
     if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 3 and x.shape[1] % 64 == 0 and d_in % 8 == 0 and d_in >= 64
-            and 0 < x.shape[0] <= 65535 and x.data_ptr() % 16 == 0
+            and d_in < COV_STAGED_MAX_DIM and 0 < x.shape[0] <= 65535 and x.data_ptr() % 16 == 0
             and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
         return False
     b, t = x.shape[0], x.shape[1]
@@ -109,7 +122,7 @@ def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Ten
 def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor],
                           has_bias: bool) -> None:
     """Flatten + mask + ones column + ``addmm_`` of module/linear.py:30-46 and tracker/factor.py:58, fused."""
-    x = _contig(x)
+    x = _contig(x, align=_vector_engines(x))
     d_in = x.shape[-1]
     n = x.numel() // d_in
     if mask is not None and mask.numel() != n:
@@ -126,7 +139,7 @@ def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tenso
 def linear_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, mask: Optional[torch.Tensor],
                         alpha: float = 1.0) -> None:
     """module/linear.py:48-54 + tracker/factor.py:93: gradient rows are never masked; the count is."""
-    g = _contig(g)
+    g = _contig(g, align=_vector_engines(g))
     d = g.shape[-1]
     n = g.numel() // d
     if not _syrk_rows_bf16(cov, g, None, False, alpha):
@@ -225,7 +238,8 @@ def conv_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor, a
     g = _contig(g)
     b, o, h, w = g.shape
     p = h * w
-    if g.is_cuda and g.dtype == torch.bfloat16 and p % 64 == 0 and 0 < b <= 65535 and g.data_ptr() % 16 == 0:
+    if (g.is_cuda and g.dtype == torch.bfloat16 and p % 64 == 0 and 0 < b <= 65535 and g.data_ptr() % 16 == 0
+            and o < COV_STAGED_MAX_DIM):
         # the NCHW gradient IS the operand layout of the covariance kernel: C_out rows of O1*O2 contiguous values per sample
         ws_bytes = nat.lib().kf_syrk_planes_workspace_bytes(o)
         ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)

@@ -79,36 +79,39 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
     remaining = len(query_loader.dataset)  # queries still to be preconditioned (each rank ends up holding all of them)
     window = score_args.query_gradient_accumulation_steps * total_query_batch_size
     set_query_capacity(model, tracked_module_names, min(window, remaining))
-    for query_index, query_batch in enumerate(query_loader):
-        query_batch = send_to_device(query_batch, state.device)
-        with no_sync(model, state):
-            model.zero_grad(set_to_none=True)
-            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
-                measurement = task.compute_measurement(batch=query_batch, model=model)
-            (measurement * scale if scale != 1.0 else measurement).backward()
-        if factor_args.has_shared_parameters:
-            finalize_iteration(model, tracked_module_names)
-        if state.use_distributed:
-            synchronize_modules(model, tracked_module_names, num_processes=state.num_processes)  # C4
-            if query_index == num_batches - 1 and query_remainder > 0:
-                truncate(model, tracked_module_names, keep_size=query_remainder)
-        accumulate_iterations(model, tracked_module_names)
-        del query_batch, measurement
-        held += 1
-        if held < score_args.query_gradient_accumulation_steps and query_index != num_batches - 1:
-            continue
-        dot_products = (compute_aggregated_dot_products_with_loader if score_args.aggregate_train_gradients
-                        else compute_dot_products_with_loader)
-        scores = dot_products(model=model, state=state, task=task, train_loader=train_loader, factor_args=factor_args,
-                              score_args=score_args, tracked_module_names=tracked_module_names, loss_scale=scale)
-        if state.is_main_process:
-            for key, value in scores.items():
-                chunks.setdefault(key, []).append(value)
-        del scores
-        state.wait_for_everyone()
-        held = 0
-        remaining -= window
-        set_query_capacity(model, tracked_module_names, min(window, max(remaining, 0)))
+    try:
+        for query_index, query_batch in enumerate(query_loader):
+            query_batch = send_to_device(query_batch, state.device)
+            with no_sync(model, state):
+                model.zero_grad(set_to_none=True)
+                with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                    measurement = task.compute_measurement(batch=query_batch, model=model)
+                (measurement * scale if scale != 1.0 else measurement).backward()
+            if factor_args.has_shared_parameters:
+                finalize_iteration(model, tracked_module_names)
+            if state.use_distributed:
+                synchronize_modules(model, tracked_module_names, num_processes=state.num_processes)  # C4
+                if query_index == num_batches - 1 and query_remainder > 0:
+                    truncate(model, tracked_module_names, keep_size=query_remainder)
+            accumulate_iterations(model, tracked_module_names)
+            del query_batch, measurement
+            held += 1
+            if held < score_args.query_gradient_accumulation_steps and query_index != num_batches - 1:
+                continue
+            dot_products = (compute_aggregated_dot_products_with_loader if score_args.aggregate_train_gradients
+                            else compute_dot_products_with_loader)
+            scores = dot_products(model=model, state=state, task=task, train_loader=train_loader, factor_args=factor_args,
+                                  score_args=score_args, tracked_module_names=tracked_module_names, loss_scale=scale)
+            if state.is_main_process:
+                for key, value in scores.items():
+                    chunks.setdefault(key, []).append(value)
+            del scores
+            state.wait_for_everyone()
+            held = 0
+            remaining -= window
+            set_query_capacity(model, tracked_module_names, min(window, max(remaining, 0)))
+    finally:
+        set_query_capacity(model, tracked_module_names, None)  # also when the score loop raises
 
     total: SCORE_TYPE = {}
     if state.is_main_process:

@@ -141,8 +141,11 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
         for side in ("activation", "gradient"):
             inv = ref.eigh_invariants(cov[f"{side}_covariance"][mod].cpu(), cov[f"num_{side}_covariance_processed"][mod].cpu(),
                                       eig[f"{side}_eigenvalues"][mod].cpu(), eig[f"{side}_eigenvectors"][mod].cpu())
-            # fp32 storage of the eigenvectors bounds these at ~1e-6
-            assert inv["orthogonality"] <= 2e-6 and inv["reconstruction"] <= 2e-6 and inv["ascending"] == 0.0, (mod, side, inv)
+            # the eigenpairs are stored in the covariance dtype (factor/eigen.py:214-219): fp32 bounds these at ~1e-6, bf16
+            # (the low-precision preset) at its 2^-9 rounding
+            bound = 1e-2 if low_cov else 2e-6
+            assert inv["orthogonality"] <= bound and inv["reconstruction"] <= bound, (mod, side, inv)
+            assert inv["ascending"] <= (1e-2 if low_cov else 0.0), (mod, side, inv)
 
     # ---- Lambda: sub-set, oracle fed the product's eigenvectors ---------------------------------------------------
     with Capture([by_name[n] for n in SUBSET[name]]) as cap:

@@ -158,6 +158,21 @@ def test_linear_activation_cov_bf16_sequence_rows(ops, b, t, d, bias, mask_dtype
     assert int(cnt) == 2 * int(count) and rel(cov, cov.t()) <= 1e-6
 
 
+def test_linear_activation_cov_weighted_integer_mask(ops):
+    """A non-binary integer mask weights the rows: the reference multiplies activations AND the bias one by the mask values in
+    the activation dtype (module/linear.py:39-43) and counts ``mask.sum()``; the bf16 sequence kernel does the same product
+    (rounded to bf16 once) instead of treating the mask as a row select."""
+    b, t, d = 3, 64, 72
+    x = _rand(b, t, d, dtype=torch.bfloat16)
+    mask = torch.randint(0, 4, (b, t), generator=torch.Generator().manual_seed(5))
+    cov, cnt = torch.zeros(d + 1, d + 1, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+    ops.linear_activation_cov(cov, cnt, x.to(DEV), mask.to(DEV), True)
+    rows = (x.float() * mask[..., None].float()).to(torch.bfloat16).double().flatten(0, 1)
+    rows = torch.cat([rows, mask.double().reshape(-1, 1)], dim=-1)
+    assert rel(cov, rows.t() @ rows) <= TOL, rel(cov, rows.t() @ rows)
+    assert int(cnt) == int(mask.sum())
+
+
 @pytest.mark.parametrize("c", [
     dict(b=5, cin=16, k=3, stride=1, padding=1, dilation=1, hw=(16, 16)),
     dict(b=3, cin=8, k=5, stride=2, padding=2, dilation=1, hw=(16, 16)),

@@ -1,6 +1,7 @@
 """Timing of the covariance entry points at the real layer shapes (HIP events on the launch stream).
 
-    gpurun -- 'python tools/cov_bench.py'        (KF_COV_TILE=128 forces the 128 x 128-tile kernel)
+    gpurun -- 'python tools/cov_bench.py'        (both engines: KF_COV_ENGINE=2 the 128-row / 4-wave kernel, 3 the 256-row
+                                                  wave-role-split kernel; the two results are compared)
 
 ResNet-9 convolutions through kf_conv2d_cov_accum (implicit im2col), BERT / GPT-2 activations through kf_syrk_rows_bf16:
 milliseconds per call and TFLOP/s on the algorithmic flops n d (d + 1)."""
@@ -33,6 +34,23 @@ def timed(fn, reps=10):
     return s.elapsed_time(e) / reps
 
 
+def both(fn, make_cov, flops, name):
+    """Times ``fn(cov)`` under both engines and compares the accumulated matrices."""
+    line, results = f"{name:40s}", {}
+    for gen in (2, 3):
+        os.environ["KF_COV_ENGINE"] = str(gen)
+        cov = make_cov()
+        t = timed(lambda: fn(cov))
+        cov.zero_()
+        fn(cov)
+        results[gen] = cov.clone()
+        line += f" engine{gen} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s |"
+    diff = float((results[3] - results[2]).norm() / results[2].norm())
+    sym = float((results[3] - results[3].t()).abs().max())
+    print(f"{line} rel diff {diff:.1e} asym {sym:.1e}{'' if diff < 1e-5 else '   <-- MISMATCH'}", flush=True)
+    os.environ.pop("KF_COV_ENGINE")
+
+
 def main():
     b = 1000
     for name, cin, cout, k, s, p, h in CONVS:
@@ -40,22 +58,25 @@ def main():
         x = torch.randn(b, cin, h, h, device=DEV).bfloat16()
         o = (h + 2 * p - k) // s + 1
         d = cin * k * k
-        cov, count = torch.zeros(d, d, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        count = torch.zeros(1, dtype=torch.int64, device=DEV)
         geometry = ops.conv2d_cov_geometry(x, conv)
         if geometry is None:
             print(f"{name:40s} not on the implicit path (materialised patches)", flush=True)
             continue
-        t = timed(lambda: ops.conv2d_cov_accum(cov, count, x, conv, geometry))
-        flops = float(b * o * o) * d * (d + 1)
-        print(f"{name:40s} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s", flush=True)
+        both(lambda cov: ops.conv2d_cov_accum(cov, count, x, conv, geometry), lambda: torch.zeros(d, d, device=DEV),
+             float(b * o * o) * d * (d + 1), name)
+    for name, cout, h in [("grad cov 128 ch 16x16", 128, 16), ("grad cov 256 ch 16x16", 256, 16), ("grad cov 256 ch 8x8", 256, 8)]:
+        g = torch.randn(b, cout, h, h, device=DEV).bfloat16()
+        count = torch.zeros(1, dtype=torch.int64, device=DEV)
+        both(lambda cov: ops.conv_gradient_cov(cov, count, g), lambda: torch.zeros(cout, cout, device=DEV),
+             float(b * h * h) * cout * (cout + 1), name)
     for name, bb, t_len, d_in in SEQS:
         x = torch.randn(bb, t_len, d_in, device=DEV).bfloat16()
         mask = (torch.rand(bb, t_len, device=DEV) < 0.9).to(torch.int64)
         d = d_in + 1
-        cov, count = torch.zeros(d, d, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
-        t = timed(lambda: ops.linear_activation_cov(cov, count, x, mask, True))
-        flops = float(bb * t_len) * d * (d + 1)
-        print(f"{name:40s} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s", flush=True)
+        count = torch.zeros(1, dtype=torch.int64, device=DEV)
+        both(lambda cov: ops.linear_activation_cov(cov, count, x, mask, True), lambda: torch.zeros(d, d, device=DEV),
+             float(bb * t_len) * d * (d + 1), name)
 
 
 if __name__ == "__main__":

@@ -30,8 +30,8 @@ if len(sys.argv) > 3 and sys.argv[1] == "multi":
     covs = []
     for k in range(count):
         g = torch.Generator().manual_seed(1000 + k)
-        x = torch.randn(2 * d, d, generator=g) * torch.logspace(0, -3, d)
-        covs.append((x.t() @ x).to(dev))
+        x = (torch.randn(2 * d, d, generator=g) * torch.logspace(0, -3, d)).to(dev)
+        covs.append(x.t() @ x)
     ops.eigh(covs[0], 2.0 * d)
     torch.cuda.synchronize()
     streams = [torch.cuda.Stream() for _ in range(lanes)]

@@ -95,7 +95,65 @@ def main():
             t = timed(lambda: ops.pairwise_score(s, 0, tiled, g, a, False), 5)
             line += f" engine{gen} {t:7.3f} ms ({2.0 * q * b * o * ip / t / 1e9:6.0f} TF/s on the score flops)"
         print(line, flush=True)
+    print("== implicit-im2col score entry point (pad + per-sample gradients v2 / v3 + score GEMM v2 / v3), Q = b = 1000")
+    from torch import nn
+    for name, cin, cout, k, st, pd, h in [("conv2 128->128 16x16", 128, 128, 3, 1, 1, 16), ("conv4 128->256 16x16", 128, 256, 3, 1, 1, 16),
+                                           ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8), ("conv1 64->128 k5 s2", 64, 128, 5, 2, 2, 32)]:
+        q = b = 1000
+        conv = nn.Conv2d(cin, cout, k, stride=st, padding=pd, bias=False)
+        x = torch.randn(b, cin, h, h, device=DEV).bfloat16()
+        o = (h + 2 * pd - k) // st + 1
+        g = torch.randn(b, cout, o, o, device=DEV).bfloat16()
+        ip = cin * k * k
+        tiled = TiledQueries(torch.randn(q, cout, ip, device=DEV).bfloat16(), 0, conv_channels=cin)
+        flops = 2.0 * q * b * cout * ip + 2.0 * b * o * o * cout * ip
+        line, outs = f"  {name:24s}", {}
+        for gen in (2, 3):
+            engine(gen)
+            s = torch.zeros(q, b, device=DEV)
+            t = timed(lambda: ops.pairwise_score_conv2d(s, 0, tiled, g, x, conv), 5)
+            s.zero_()
+            ops.pairwise_score_conv2d(s, 0, tiled, g, x, conv)
+            outs[gen] = s
+            line += f" engine{gen} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s |"
+        d = float((outs[3] - outs[2]).norm() / outs[2].norm())
+        print(f"{line} rel diff {d:.1e}{'' if d < 1e-4 else '   <-- MISMATCH'}", flush=True)
     engine(3)
+
+    print("== Lambda of a conv layer: factored form (im2col + 2 rotations + kf_lambda_accum) vs dense form (kf_lambda_conv2d_accum)")
+    for name, cin, cout, k, st, pd, h in [("conv2 128->128 16x16", 128, 128, 3, 1, 1, 16), ("conv4 128->256 16x16", 128, 256, 3, 1, 1, 16),
+                                           ("conv1 64->128 k5 s2", 64, 128, 5, 2, 2, 32)]:
+        b = 1000
+        conv = nn.Conv2d(cin, cout, k, stride=st, padding=pd, bias=False)
+        x = torch.randn(b, cin, h, h, device=DEV).bfloat16()
+        o = (h + 2 * pd - k) // st + 1
+        r = o * o
+        g = torch.randn(b, cout, o, o, device=DEV).bfloat16()
+        ip = cin * k * k
+        q_a = torch.linalg.qr(torch.randn(ip, ip, device=DEV))[0]
+        q_g = torch.linalg.qr(torch.randn(cout, cout, device=DEV))[0]
+        qa_t, qg_t = q_a.t().contiguous().bfloat16(), q_g.t().contiguous().bfloat16()
+        lam_f, lam_d = torch.zeros(cout, ip, device=DEV), torch.zeros(cout, ip, device=DEV)
+
+        def factored():
+            patches = ops.im2col(x, conv, False, torch.bfloat16)
+            rows = g.flatten(2).transpose(1, 2).contiguous()
+            gt = ops.rotate_bf16(rows.reshape(b * r, cout), qg_t)
+            at = ops.rotate_bf16(patches.reshape(b * r, ip), qa_t)
+            ops.lambda_accum(lam_f, gt, at, b, r)
+
+        geometry = ops.lambda_conv2d_geometry(tuple(x.shape), cout, conv)
+        qa_perm, qg16 = ops.conv_patch_order_eigenvectors(q_a, cin, k * k), q_g.bfloat16().contiguous()
+
+        def dense():
+            ops.lambda_conv2d_accum(lam_d, ops.rotate_channels(g, qg16), x, geometry, qa_perm)
+
+        tf, td = timed(factored, 5), timed(dense, 5)
+        lam_f.zero_(); lam_d.zero_(); factored(); dense()
+        d = float((lam_d - lam_f).norm() / lam_f.norm())
+        f_alg = b * min(2.0 * cout * ip * (ip + cout) + 2.0 * r * cout * ip, 2.0 * r * (ip * ip + cout * cout + cout * ip))
+        print(f"  {name:24s} factored {tf:7.3f} ms | dense {td:7.3f} ms ({f_alg / td / 1e9:6.0f} TF/s on F_lambda) | rel diff {d:.1e}"
+              f"{'' if d < 3e-2 else '   <-- MISMATCH'}", flush=True)
 
 
 if __name__ == "__main__":
