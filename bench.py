@@ -394,20 +394,44 @@ def _event_summary(events, peak_tflops: float, kernel: str, elapsed_s: Optional[
     return out
 
 
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources and the C header: identifies the code a kept PMC profile was taken on."""
+    import glob
+    import hashlib
+
+    digest = hashlib.sha256()
+    paths = sorted(glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for path in paths:
+        with open(path, "rb") as handle:
+            digest.update(os.path.basename(path).encode() + b"\0" + handle.read())
+    return digest.hexdigest()
+
+
 def _pmc_traffic(workload: str) -> Optional[dict]:
     """Per-launch HBM bytes of the hot kernels, from the kept ``rocprofv3 --pmc`` passes of the SAME bench command
-    (``profiles/r02_pmc_<workload>.json``, written by tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950
-    correction of MI355X_MICROARCH.md).  None when no such file has been committed."""
-    path = os.path.join(ROOT, "profiles", f"r02_pmc_{workload}.json")
+    (``profiles/pmc_<workload>.json``, written by tools/pmc_summary.py; FETCH_SIZE doubled per the gfx950 correction of
+    MI355X_MICROARCH.md).  The counters cannot be collected inside this process, so the numbers are only as current as that
+    file: it records a hash of the kernel sources it was taken on, and a file taken on OTHER sources is refused (traffic
+    null, with the reason) instead of being quoted.  None when no such file has been committed."""
+    path = os.path.join(ROOT, "profiles", f"pmc_{workload}.json")
     if not os.path.exists(path):
         return None
     with open(path, encoding="utf-8") as handle:
-        return json.load(handle)
+        summary = json.load(handle)
+    if summary.get("kernel_source_sha256") != kernel_source_hash():
+        return {"stale": f"profiles/pmc_{workload}.json was taken on other kernel sources "
+                         f"({str(summary.get('kernel_source_sha256'))[:12]} != {kernel_source_hash()[:12]}): not quoted"}
+    return summary
 
 
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int], steps: int, warmup: int,
-                 factor_reps: int, cpu_baseline: bool, full_cpu_parity: bool = False) -> dict:
+                 factor_reps: int, cpu_baseline: bool, n_fit: Optional[int] = None, warm_n_train: Optional[int] = None) -> dict:
+    """``n_fit``: fit the factors on the first ``n_fit`` train samples only (the pairwise stage does not care how many samples
+    the factors saw; used by the full-size extras to keep the default run within minutes -- reported in ``factor_fit.n_fit``).
+    ``warm_n_train``: the warm-up steps score against the first ``warm_n_train`` train samples (one-time costs -- allocator
+    growth, GEMM / MIOpen heuristics, the k-tile-major query layout code paths -- without paying a full-size step)."""
     from kronfluence_amd import ops, prepare_model
     from kronfluence_amd.utils import comm
     from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
@@ -419,6 +443,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     spec = WORKLOADS[name]
     n_train = n_train or spec["n_train"]
     n_query = n_query or spec["n_query"]
+    n_fit = min(n_fit or n_train, n_train)
 
     torch.manual_seed(0)
     raw_model = spec["model"]()
@@ -426,6 +451,12 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     model = prepare_model(raw_model, task).to(dev)
     train = make_data(spec, n_train, 1, dev)
     query = make_data(spec, n_query, 2, dev)
+    if spec["kind"] == "image" and os.environ.get("KF_BENCH_CHANNELS_LAST", "0") == "1":
+        # the MODEL's own convolutions in NHWC (a deployment choice like MIOpen's find mode; the hooks copy what they consume
+        # back to NCHW, so nothing of the EK-FAC path changes)
+        model = model.to(memory_format=torch.channels_last)
+        train = (train[0].contiguous(memory_format=torch.channels_last),) + tuple(train[1:])
+        query = (query[0].contiguous(memory_format=torch.channels_last),) + tuple(query[1:])
     amp = spec["amp"]
     low = amp == torch.bfloat16
     fargs = factor_arguments(spec)
@@ -455,12 +486,13 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
 
     # -- shards: factor fit strided without padding; train contiguous chunks; queries strided
     def factor_loader():
-        idx = list(DistributedEvalSampler(range(n_train), world, rank)) if world > 1 else None
+        idx = list(DistributedEvalSampler(range(n_fit), world, rank)) if world > 1 else (None if n_fit == n_train else list(range(n_fit)))
         return ResidentLoader(train, spec["factor_batch"], idx)
 
-    def train_loader():
-        idx = list(DistributedSamplerWithStack(range(n_train), world, rank)) if world > 1 else None
-        return ResidentLoader(train, spec["train_batch"], idx)
+    def train_loader(count: int = n_train):
+        subset = train if count == n_train else tuple(t[:count] for t in train)
+        idx = list(DistributedSamplerWithStack(range(count), world, rank)) if world > 1 else None
+        return ResidentLoader(subset, spec["train_batch"], idx)
 
     def query_loader():
         if world > 1:
@@ -493,12 +525,12 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     fit_total = sum(fit_times.values())
 
     # -- pairwise stage: W warm-up steps, K timed steps ------------------------------------------------
-    def step():
+    def step(count: int = n_train):
         return compute_pairwise_scores_with_loaders(factors, model, state, task, query_loader(), per_dev_q,
-                                                    train_loader(), sargs, fargs, None)
+                                                    train_loader(count), sargs, fargs, None)
 
     for _ in range(warmup):
-        step()
+        step(min(warm_n_train or n_train, n_train))
     gc.collect()
     gc.disable()  # no cyclic-GC pause between steps either (the stage loops already pause it inside a stage)
     ops.EVENT_LOG = {}
@@ -579,6 +611,10 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                                   "transpose_rows_kernel + psg_gemm_v2_kernel (per-sample gradients) + "
                                   "score_gemm_v2_kernel<TM,TN,W> (score GEMM; the dominant kernel)", elapsed)
         traffic = _pmc_traffic(name)
+        if traffic is not None and "stale" in traffic:
+            if roofline is not None:
+                roofline["traffic_source"] = traffic["stale"]
+            traffic = None
         if roofline is not None and traffic is not None:
             roofline["traffic"] = traffic.get("kf_pairwise_score_bytes_per_launch")
             roofline["traffic_source"] = traffic.get("source")
@@ -601,13 +637,20 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                        "score_dtype": str(sargs.score_dtype), "query_gradient_accumulation_steps": accumulate,
                        "train_batch": spec["train_batch"], "query_batch": per_dev_q,
                        "parallelism": f"train-shard-dp{world}",
+                       **({"warmup_n_train": min(warm_n_train, n_train)} if warm_n_train else {}),
                        **({"scaled_from": {"n_train": spec.get("full_n_train"), "n_query": spec.get("full_n_query", spec["n_query"])}}
                           if n_train < spec.get("full_n_train", 0) else {})},
             "roofline": roofline,
             "roofline_cov": roofline_cov,
-            "roofline_lambda": _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_accum (factored form)",
-                                              fit_times["lambda"]),
-            "factor_fit": {"samples_per_sec": n_train / fit_total, "seconds": fit_times, "n_fit": n_train,
+            "roofline_lambda": _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_accum (factored form: the product of "
+                                              "the rotated factors, 2 b R O I' flops) | kf_lambda_conv2d_accum (dense form of a Conv2d layer: "
+                                              "pad + psg_gemm + rotate_gemm_v3<sumsq>, 2 b R O I' + 2 b O I'^2 flops)", fit_times["lambda"]),
+            # the WHOLE Lambda update of a hook (eigenbasis rotations included) against F_lambda, the cheaper of the two exact
+            # formulations
+            "roofline_lambda_update": _event_summary(fit_events.get("lambda_update", []), peak, "LambdaTracker backward hook: "
+                                                     "rotations / per-sample gradient + squared product; algorithmic flops = F_lambda",
+                                                     fit_times["lambda"]),
+            "factor_fit": {"samples_per_sec": n_fit / fit_total, "seconds": fit_times, "n_fit": n_fit,
                            "eigen_dims": eig_dims},
             "peak_hbm_gib": round(peak_mem, 1),
             # rank 0's collectives (RCCL over xGMI; all inside the timed regions): seconds are stream time between events
@@ -653,12 +696,15 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip targets.mnist_mlp / other_configs in the default run")
     ap.add_argument("--factor-reps", type=int, default=1)
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
+    ap.add_argument("--channels-last", action="store_true", help="run the image model's own convolutions in NHWC (experiment)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
                     "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
                     "907 -> 862 ms; nothing of the EK-FAC path is affected)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _respawn_under_torchrun(args.gpus)
+    if args.channels_last:
+        os.environ["KF_BENCH_CHANNELS_LAST"] = "1"
     if args.train_batch:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
     if not args.no_miopen_find:
@@ -692,15 +738,23 @@ def main() -> None:
         # N = 1: BERT-base and GPT-2-small at bounded sizes.  N > 1: GPT-2-small only -- the config the north-star scaling
         # target (>= 6x strong scaling 1 -> 8) is stated on -- sharded like the headline, same fixed size at every N.
         others = ("bert_base", "gpt2_small") if world == 1 else ("gpt2_small",)
+        # BERT-base at its FULL 67 349 x 872 (configs[2]); GPT-2-small at 16 384 x 1 024 sequences of 512 tokens (the score
+        # contraction dominates the stage from there on; the full 100 k x 2 k is the 8-GPU configuration).  The factors are
+        # fitted on a bounded prefix (n_fit) and the warm-up step scores a small prefix, so the default run stays within minutes.
+        sizes = {"bert_base": dict(n_train=WORKLOADS["bert_base"]["full_n_train"], n_fit=8192, warm_n_train=1024),
+                 "gpt2_small": dict(n_train=16384, n_fit=2048, warm_n_train=512)}
         extras: Dict[str, dict] = {}
         for other in others:
             try:
                 # factor_reps=1: the reported fit is the second, warm one (the first GPT-2 covariance pass alone spends ~5 s in
                 # first-touch allocations and GEMM heuristics)
-                r = run_workload(other, state, None, None, steps=1, warmup=1, factor_reps=1, cpu_baseline=False)
+                size = sizes[other]
+                r = run_workload(other, state, size["n_train"], None, steps=1, warmup=1, factor_reps=1, cpu_baseline=False,
+                                 n_fit=size["n_fit"], warm_n_train=size["warm_n_train"])
                 if rank == 0:
                     extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline",
-                                                      "roofline_cov", "roofline_lambda", "factor_fit", "exchanges", "peak_hbm_gib")}
+                                                      "roofline_cov", "roofline_lambda", "roofline_lambda_update", "factor_fit",
+                                                      "exchanges", "peak_hbm_gib")}
             except Exception as error:  # an extra must never take the headline down with it
                 extras[other] = {"error": f"{type(error).__name__}: {error}"[:300]}
                 gc.collect()

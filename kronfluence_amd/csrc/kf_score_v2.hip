@@ -1018,16 +1018,18 @@ inline int64_t cov_stage_bytes(int64_t n_operand_rows) {
     return align256(np * np * 4);
 }
 
-inline int cov_engine(int64_t n_rows) {  // 2 = 128-row tiles / 4 waves, 3 = 256-row tiles on the wave-role-split loop
+inline int cov_engine(int64_t n_rows, int64_t steps) {  // 2 = 128-row tiles / 4 waves, 3 = 256-row tiles on the wave-role-split loop
     if (const char* e = getenv("KF_COV_ENGINE")) return atoi(e) == 2 ? 2 : 3;
     if (engine_generation() == 2) return 2;
     const int64_t t2 = cdiv(n_rows, 128), t3 = cdiv(n_rows, 256);
-    // MFMA work in 128 x 128 units: the 256-row tiling pads more and computes whole diagonal tiles; its loop sustains about
-    // twice the rate of the 4-wave kernel (half the LDS-DMA requests per MFMA)
-    return (t3 * (t3 + 1) / 2) * 4 * 10 <= (t2 * (t2 + 1) / 2) * 17 ? 3 : 2;
+    // MFMA work in 128 x 128 units: the 256-row tiling pads more and computes whole diagonal tiles.  Measured
+    // (profiles/r03_cov_bench.log): its loop runs 1.2-1.5x the rate of the 4-wave kernel when the contraction is long (1600
+    // rows, 4000 k-steps: 1.59 -> 1.32 ms; 2304 rows, 1000 k-steps: 0.63 -> 0.59 ms), but loses when the extra work exceeds a
+    // quarter (1152 rows: +33 %) or the contraction is short (transformer batches of 128 k-steps: the 64 K staging atomics of
+    // a 256 x 256 tile weigh more than its k-loop)
+    return ((t3 * (t3 + 1) / 2) * 4 * 100 <= (t2 * (t2 + 1) / 2) * 125 && steps >= 512) ? 3 : 2;
 }
 
-// tile geometry, split over sample ranges, launch of the covariance kernel and of its finalize pass
 int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.tiles = static_cast<int>(cdiv(c.N, 256));
     c.np = c.tiles * 256;
@@ -1047,7 +1049,7 @@ int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
 }
 
 int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
-    if (cov_engine(c.N) == 3) return launch_cov_v3(c, f, st);
+    if (cov_engine(c.N, static_cast<int64_t>(c.batch) * (c.K >> 6)) == 3) return launch_cov_v3(c, f, st);
     c.tiles = static_cast<int>(cdiv(c.N, 128));
     c.np = c.tiles * 128;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);

@@ -7,7 +7,7 @@
     and the 2-row classifier are all in play, and nothing upstream of the hooks can differ.
       covariances  all tracked layers                                        rel_F <= 2e-5, counters exact
       Lambda       a sub-set of layers, product's own eigenvectors           rel_F <= 5e-2 (bf16 lambda_dtype)
-      scores       the same sub-set (per-module scores), default damping     rel_F <= 3e-2 (bf16 P and gradients; the oracle is
+      scores       the same sub-set (per-module scores), heuristic damping   rel_F <= 3e-2 (bf16 P and gradients; the oracle is
                    given the bf16-rounded eigenvectors the reference's ``Ekfac.prepare`` would use, factor/config.py:323-328;
                    the error against EXACT eigenvectors is printed, not bounded: with 8-24 train samples Lambda is rank
                    deficient and damping 1e-8 amplifies the cast itself), and the sum over ALL modules is the "all_modules" run
@@ -171,6 +171,12 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
     def run(per_module):
         sargs = sargs_of(spec, n_query, 1, n_query)
         sargs.compute_per_module_scores = per_module
+        # heuristic damping (0.1 x mean Lambda, factor/config.py:331-338): with 8-24 train samples Lambda is rank deficient and
+        # the default 1e-8 multiplies every bf16 rounding of the rotated query gradient by up to 1e8 -- in the reference's bf16
+        # presets exactly as here (measured on this test: 1e-2 ... 3e-1 depending on the layer), which says nothing about the
+        # kernels.  The default damping is tested where the factors are well conditioned (tests/test_fullsize_gpu.py: 50 000
+        # samples; tests/test_pipeline_gpu.py: the *_mse fixtures).
+        sargs.damping_factor = None
         return compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query, n_query), n_query,
                                                     ResidentLoader(train, tb), sargs, fargs, None)
 
@@ -187,7 +193,7 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
         xq, gq = xq.to(gq.dtype).double().cpu(), gq.double().cpu()
         psg_q = ref.linear_per_sample_gradient(xq, gq, has_bias(m))
         lam_inv = ref.ekfac_inverse_lambda(lam["lambda_matrix"][mod].double().cpu(), lam["num_lambda_processed"][mod].cpu(),
-                                           1e-8, torch.float64)
+                                           None, torch.float64)
         errs = []
         for cast in (lambda v: v.to(torch.bfloat16), lambda v: v):
             q_a = cast(eig["activation_eigenvectors"][mod]).double().cpu()
@@ -326,19 +332,19 @@ def test_llama_projection_full_width(o, i):
     assert err <= 5e-2, err
     assert int(lam["num_lambda_processed"]["lin"]) == n_train
 
-    # ---- scores (bf16 queries / gradients, default damping), full [1, 2] block ----------------------------------------
+    # ---- scores (bf16 queries / gradients, heuristic damping: two train samples leave Lambda rank deficient), full [1, 2] block
     factors = {**eig, **lam}
     sargs = ScoreArguments(amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16,
-                           per_sample_gradient_dtype=torch.bfloat16)
+                           per_sample_gradient_dtype=torch.bfloat16, damping_factor=None)
     with Capture(tracked) as cap:
         got = compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query, n_query), n_query,
                                                    ResidentLoader(train, 1), sargs, low, None)["all_modules"]
     (xq, gq), trains = cap.held["lin"][0], cap.held["lin"][1:]
     psg_q = ref.linear_per_sample_gradient(xq.to(gq.dtype).double().cpu(), gq.double().cpu(), False)
-    lam_inv = ref.ekfac_inverse_lambda(lam["lambda_matrix"]["lin"].double().cpu(), lam["num_lambda_processed"]["lin"].cpu(), 1e-8,
+    lam_inv = ref.ekfac_inverse_lambda(lam["lambda_matrix"]["lin"].double().cpu(), lam["num_lambda_processed"]["lin"].cpu(), None,
                                        torch.float64)
     p = ref.ekfac_precondition(psg_q, q_a16, q_g16, lam_inv)
     want = torch.cat([ref.linear_pairwise_score(p, xt.to(gt.dtype).double().cpu(), gt.double().cpu(), False) for xt, gt in trains], dim=1)
     err = rel(got, want)
-    print(f"llama {o}x{i}: scores rel_F (bf16, damping 1e-8) {err:.2e}; got {got.flatten().tolist()} want {want.flatten().tolist()}")
+    print(f"llama {o}x{i}: scores rel_F (bf16, heuristic damping) {err:.2e}; got {got.flatten().tolist()} want {want.flatten().tolist()}")
     assert got.shape == (n_query, n_train) and err <= 4e-2, err

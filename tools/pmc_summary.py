@@ -1,5 +1,6 @@
-"""Summarises ``rocprofv3 --pmc`` passes of a bench command into ``profiles/r02_pmc_<workload>.json`` (read back by
-bench.py for ``roofline.traffic`` / ``roofline.mfma_util``).
+"""Summarises ``rocprofv3 --pmc`` passes of a bench command into ``profiles/pmc_<workload>.json`` (read back by bench.py for
+``roofline.traffic`` / ``roofline.mfma_util``; the summary records a hash of the kernel sources it was taken on and bench.py
+refuses it when the sources have changed since).
 
     python tools/pmc_summary.py <workload> <out.json> <pass_dir> [<pass_dir> ...]
 
@@ -15,13 +16,28 @@ Every pass directory holds one ``*_counter_collection.csv`` (one row per dispatc
 """
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 from collections import defaultdict
 
-SCORE_KERNELS = ("score_gemm_v2_kernel", "psg_gemm_v2_kernel", "conv_pad_phases_kernel", "pad_grid_kernel", "transpose_rows_kernel",
-                 "score_r1_kernel")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCORE_GEMM = ("score_gemm_v2_kernel", "score_gemm_v3_kernel")
+PSG = ("psg_gemm_v2_kernel", "psg_gemm_v3_kernel")
+COV_GEMM = ("cov_gemm_v2_kernel", "cov_gemm_v3_kernel")
+SCORE_KERNELS = SCORE_GEMM + PSG + ("conv_pad_phases_kernel", "pad_grid_kernel", "transpose_rows_kernel", "score_r1_kernel")
+
+
+def kernel_source_hash() -> str:
+    """sha256 over the HIP sources and the C header (same function as bench.py's): identifies the code a profile was taken on."""
+    digest = hashlib.sha256()
+    paths = sorted(glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for path in paths:
+        with open(path, "rb") as handle:
+            digest.update(os.path.basename(path).encode() + b"\0" + handle.read())
+    return digest.hexdigest()
 
 
 def short(name: str) -> str:
@@ -33,7 +49,7 @@ def score_call_bytes(kernels: dict) -> float:
     """HBM bytes of all kf_pairwise_score* calls.  The pad / transpose kernels also serve the covariance entry points when the
     profiled command ran the factor fit: a score call launches exactly one psg_gemm_v2_kernel with one conv_pad_phases_kernel
     (convolution) or two transpose_rows_kernel (sequence rows), so only that share of their launches is counted."""
-    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith("psg_gemm_v2_kernel"))
+    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG))
     total = 0.0
     for n, e in kernels.items():
         if not n.startswith(SCORE_KERNELS):
@@ -80,22 +96,23 @@ def main() -> None:
             entry["mfma_util"] = mean["SQ_VALU_MFMA_BUSY_CYCLES"] / (mean["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
         kernels[name] = entry
     # one kf_pairwise_score* call = its pad / transpose / gradient kernels + one score GEMM (or one score_r1 launch)
-    calls = sum(e["launches"] for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel") or n.startswith("score_r1_kernel"))
+    calls = sum(e["launches"] for n, e in kernels.items() if n.startswith(SCORE_GEMM) or n.startswith("score_r1_kernel"))
     total = score_call_bytes(kernels)
-    dominant = max((e for n, e in kernels.items() if n.startswith("score_gemm_v2_kernel")), key=lambda e: e["launches"], default=None)
+    dominant = max((e for n, e in kernels.items() if n.startswith(SCORE_GEMM)), key=lambda e: e["launches"], default=None)
+    cov = max((e for n, e in kernels.items() if n.startswith(COV_GEMM)), key=lambda e: e["launches"], default=None)
     summary = {
         "workload": workload,
+        "kernel_source_sha256": kernel_source_hash(),
         "source": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE | SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (separate passes) on the bench "
                   "command; FETCH_SIZE doubled (gfx950: MI355X_MICROARCH.md, HBM); summary by tools/pmc_summary.py",
         "kf_pairwise_score_bytes_per_launch": total / calls if calls else None,
         "kf_pairwise_score_calls_profiled": calls,
         "mfma_util": dominant.get("mfma_util") if dominant else None,
         # covariance stage (present when the profiled command ran the factor fit): the GEMM kernel of the LDS-DMA covariance path
-        "cov_gemm_bytes_per_launch": (lambda e: e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0) if e else None)(
-            kernels.get("cov_gemm_v2_kernel")),
-        "cov_gemm_mfma_util": (kernels.get("cov_gemm_v2_kernel") or {}).get("mfma_util"),
+        "cov_gemm_bytes_per_launch": (cov.get("hbm_read_bytes", 0.0) + cov.get("hbm_write_bytes", 0.0)) if cov else None,
+        "cov_gemm_mfma_util": (cov or {}).get("mfma_util"),
         "kernels": {n: e for n, e in kernels.items() if n.startswith(SCORE_KERNELS) or "gemm_bf16" in n or "syrk" in n or "lambda" in n
-                    or "im2col" in n or "eigh" in n or "jacobi" in n or n.startswith("cov_")},
+                    or "im2col" in n or "eigh" in n or "jacobi" in n or n.startswith("cov_") or n.startswith("rotate_gemm")},
     }
     with open(out_path, "w", encoding="utf-8") as handle:
         json.dump(summary, handle, indent=1)
