@@ -451,12 +451,6 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     model = prepare_model(raw_model, task).to(dev)
     train = make_data(spec, n_train, 1, dev)
     query = make_data(spec, n_query, 2, dev)
-    if spec["kind"] == "image" and os.environ.get("KF_BENCH_CHANNELS_LAST", "0") == "1":
-        # the MODEL's own convolutions in NHWC (a deployment choice like MIOpen's find mode; the hooks copy what they consume
-        # back to NCHW, so nothing of the EK-FAC path changes)
-        model = model.to(memory_format=torch.channels_last)
-        train = (train[0].contiguous(memory_format=torch.channels_last),) + tuple(train[1:])
-        query = (query[0].contiguous(memory_format=torch.channels_last),) + tuple(query[1:])
     amp = spec["amp"]
     low = amp == torch.bfloat16
     fargs = factor_arguments(spec)
@@ -696,15 +690,12 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip targets.mnist_mlp / other_configs in the default run")
     ap.add_argument("--factor-reps", type=int, default=1)
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
-    ap.add_argument("--channels-last", action="store_true", help="run the image model's own convolutions in NHWC (experiment)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
                     "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
                     "907 -> 862 ms; nothing of the EK-FAC path is affected)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         _respawn_under_torchrun(args.gpus)
-    if args.channels_last:
-        os.environ["KF_BENCH_CHANNELS_LAST"] = "1"
     if args.train_batch:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
     if not args.no_miopen_find:

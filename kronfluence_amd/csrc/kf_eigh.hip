@@ -15,7 +15,6 @@
 #include <stdlib.h>
 
 #include <algorithm>
-#include <type_traits>
 #include <mutex>
 
 #include "../../include/kronfluence_hip.h"
@@ -222,29 +221,9 @@ __global__ __launch_bounds__(EB) void jacobi_block_round_kernel(double* Wt, doub
 // rotation", the rotation test is the relative one of the scalar kernel.
 // ------------------------------------------------------------------------------------------------
 typedef double f64x4 __attribute__((ext_vector_type(4)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int KB = 32, KP = 2 * KB;          // columns per block / per pair
-constexpr int GK = 32;                       // gram: k-tile
+constexpr int GK = 32, GPITCH = GK + 2;      // gram: k-tile (doubles) and LDS pitch (bank-conflict free operand reads)
 constexpr int UT = 64, UPITCH = 80;          // update: tile width and LDS pitch (pitch % 32 == 16)
-
-// The blocked kernels exist in fp64 (the solver proper) and fp32 (the warm-start phase of the mixed-precision driver, see
-// kf_eigh_f64): same 16 x 16 x 4 matrix-core shape, A / B one value per lane (A[lane & 15][k = lane >> 4]); only the
-// accumulator rows differ (fp64: (lane >> 4) + 4 reg; fp32: 4 (lane >> 4) + reg -- MI355X cdna_hip_programming.md section 3).
-template <class T> struct Mx;
-template <> struct Mx<double> {
-    typedef f64x4 acc_t;
-    static constexpr int GPITCH = GK + 2;   // bank-conflict free operand reads (8-byte elements)
-    static __device__ __forceinline__ acc_t mfma(double a, double b, acc_t c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
-    static __device__ __forceinline__ double rsqrt1p(double t2) { return 1.0 / sqrt(1.0 + t2); }
-};
-template <> struct Mx<float> {
-    typedef f32x4 acc_t;
-    static constexpr int GPITCH = GK + 1;
-    static __device__ __forceinline__ acc_t mfma(float a, float b, acc_t c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
-    static __device__ __forceinline__ int row(int lane, int r) { return 4 * (lane >> 4) + r; }
-    static __device__ __forceinline__ float rsqrt1p(float t2) { return 1.0f / sqrtf(1.0f + t2); }
-};
 
 __device__ __forceinline__ void pair_of_round(int k, int round, int players, int& P, int& Q) {
     const int m = players - 1;
@@ -260,12 +239,10 @@ __device__ __forceinline__ int64_t pair_row(int r, int P, int Q, int nblocks, in
 }
 
 // partial[pair][split][64][64] = sum over this split's i-range of Wp[a][i] Wp[b][i]
-template <class T>
-__global__ __launch_bounds__(256) void eigh_gram_kernel(const T* __restrict__ Wt, T* __restrict__ partial, int64_t d,
+__global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict__ Wt, double* __restrict__ partial, int64_t d,
                                                         int nblocks, int players, int round, int gsplit, int64_t chunk,
                                                         const int* __restrict__ done) {
-    constexpr int GPITCH = Mx<T>::GPITCH;
-    __shared__ T tile[KP * GPITCH];
+    __shared__ double tile[KP * GPITCH];
     if (*done) return;  // converged in an earlier sweep of this batch of launches (device-side convergence flag)
     const int pair = blockIdx.x, split = blockIdx.y;
     int P, Q;
@@ -274,15 +251,15 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const T* __restrict__ Wt
     const int lrow = tid >> 2, lseg = tid & 3;  // loader: row of the pair, 8-double segment of the k-tile
     const int64_t grow = pair_row(lrow, P, Q, nblocks, d);
     const int64_t i_begin = split * chunk, i_end = min(d, i_begin + chunk);
-    typename Mx<T>::acc_t acc[4];
+    f64x4 acc[4];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = typename Mx<T>::acc_t{0, 0, 0, 0};
+    for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
     for (int64_t i0 = i_begin; i0 < i_end; i0 += GK) {
-        T v[8];
+        double v[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t i = i0 + lseg * 8 + e;
-            v[e] = (grow >= 0 && i < i_end) ? Wt[grow * d + i] : T(0);
+            v[e] = (grow >= 0 && i < i_end) ? Wt[grow * d + i] : 0.0;
         }
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
@@ -291,20 +268,20 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const T* __restrict__ Wt
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             const int k = ks * 4 + (lane >> 4);
-            const T a = tile[(wave * 16 + (lane & 15)) * GPITCH + k];
+            const double a = tile[(wave * 16 + (lane & 15)) * GPITCH + k];
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const T bv = tile[(b * 16 + (lane & 15)) * GPITCH + k];
-                acc[b] = Mx<T>::mfma(a, bv, acc[b]);
+                const double bv = tile[(b * 16 + (lane & 15)) * GPITCH + k];
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);
             }
         }
     }
-    T* out = partial + (static_cast<int64_t>(pair) * gsplit + split) * (KP * KP);
+    double* out = partial + (static_cast<int64_t>(pair) * gsplit + split) * (KP * KP);
 #pragma unroll
     for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r)
-            out[(wave * 16 + Mx<T>::row(lane, r)) * KP + b * 16 + (lane & 15)] = acc[b][r];
+            out[(wave * 16 + (lane >> 4) + 4 * r) * KP + b * 16 + (lane & 15)] = acc[b][r];
 }
 
 // Rotations of one pair from its 64 x 64 Gram matrix, held in LDS: U and the pair's "rotated" flag.
@@ -318,34 +295,33 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const T* __restrict__ Wt
 // The Gram matrix is rotated two-sidedly, G <- J^T G J, so the angles are exactly those of the one-sided method applied
 // to the columns.  Two barriers per round: the column pass reads G and writes a second buffer (every column belongs to
 // exactly one rotation, so all of it is rewritten), the row pass writes back.
-template <class T>
-__global__ __launch_bounds__(256) void eigh_solve_kernel(const T* __restrict__ partial, T* __restrict__ Ubuf, int* __restrict__ pair_flag,
-                                                         int gsplit, int cross, T tol, const double* __restrict__ frob2,
+__global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restrict__ partial, double* __restrict__ Ubuf, int* __restrict__ pair_flag,
+                                                         int gsplit, int cross, double tol, const double* __restrict__ frob2,
                                                          double null_scale, int* rotated, const int* __restrict__ done) {
     constexpr int LP = KP + 1;
     if (*done) return;
-    __shared__ T G[KP * LP];
-    __shared__ T H[KP * LP];
-    __shared__ T U[KP * LP];
-    __shared__ T cs[KB], sn[KB];
+    __shared__ double G[KP * LP];
+    __shared__ double H[KP * LP];
+    __shared__ double U[KP * LP];
+    __shared__ double cs[KB], sn[KB];
     __shared__ int pp[KB], qq[KB];
     __shared__ int any;
     const int pair = blockIdx.x, tid = threadIdx.x;
-    const T null2 = static_cast<T>(frob2[0] * null_scale);
-    const T* src = partial + static_cast<int64_t>(pair) * gsplit * (KP * KP);
+    const double null2 = frob2[0] * null_scale;
+    const double* src = partial + static_cast<int64_t>(pair) * gsplit * (KP * KP);
     for (int e = tid; e < KP * KP; e += 256) {
-        T s = 0;
+        double s = 0.0;
         for (int g = 0; g < gsplit; ++g) s += src[static_cast<int64_t>(g) * (KP * KP) + e];
         const int r = e / KP, c = e % KP;
         H[r * LP + c] = s;
-        U[r * LP + c] = r == c ? T(1) : T(0);
+        U[r * LP + c] = r == c ? 1.0 : 0.0;
     }
     if (tid == 0) any = 0;
     __syncthreads();
     // symmetrise (the two triangles were accumulated in different orders)
     for (int e = tid; e < KP * KP; e += 256) {
         const int r = e / KP, c = e % KP;
-        G[r * LP + c] = T(0.5) * (H[r * LP + c] + H[c * LP + r]);
+        G[r * LP + c] = 0.5 * (H[r * LP + c] + H[c * LP + r]);
     }
     __syncthreads();
     const int k = tid & 31, rg = tid >> 5;  // column pass: rotation k, rows rg + 8 j
@@ -360,15 +336,15 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const T* __restrict__ p
             if (kk == 0) { p = base + round % m; q = base + m; }
             else { p = base + (round + kk) % m; q = base + (round - kk + m) % m; }
         }
-        const T a = G[p * LP + p], b = G[q * LP + q], g = G[p * LP + q];
-        T c = 1, s = 0;
+        const double a = G[p * LP + p], b = G[q * LP + q], g = G[p * LP + q];
+        double c = 1.0, s = 0.0;
         // |g| > tol sqrt(a b), tested without square roots; the rotation with two square roots and two divisions instead
         // of four and three (the fp64 sqrt / div sequences are the critical path of a round):
         //   zeta = (b - a) / 2g,  t = sgn(zeta) / (|zeta| + sqrt(1 + zeta^2)) = sgn(b - a) 2g / (|b - a| + sqrt((b - a)^2 + 4 g^2))
         if (g * g > tol * tol * a * b && a > null2 && b > null2) {
-            const T w = b - a, h = T(2) * g;
-            const T t = (w < 0 ? -h : h) / (fabs(w) + sqrt(w * w + h * h));
-            c = Mx<T>::rsqrt1p(t * t);
+            const double w = b - a, h = 2.0 * g;
+            const double t = copysign(1.0, w) * h / (fabs(w) + sqrt(w * w + h * h));
+            c = 1.0 / sqrt(1.0 + t * t);
             s = c * t;
             did = 1;
         }
@@ -377,10 +353,10 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const T* __restrict__ p
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int r = rg + 8 * j;
-            const T gp = G[r * LP + p], gq = G[r * LP + q];
+            const double gp = G[r * LP + p], gq = G[r * LP + q];
             H[r * LP + p] = c * gp - s * gq; H[r * LP + q] = s * gp + c * gq;
-            if (s != T(0)) {
-                const T up = U[r * LP + p], uq = U[r * LP + q];
+            if (s != 0.0) {
+                const double up = U[r * LP + p], uq = U[r * LP + q];
                 U[r * LP + p] = c * up - s * uq; U[r * LP + q] = s * up + c * uq;
             }
         }
@@ -391,9 +367,9 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const T* __restrict__ p
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int kr = (tid >> 6) + 4 * j;
-                const T cr = cs[kr], sr = sn[kr];
+                const double cr = cs[kr], sr = sn[kr];
                 const int pr = pp[kr], qr = qq[kr];
-                const T tp = H[pr * LP + col], tq = H[qr * LP + col];
+                const double tp = H[pr * LP + col], tq = H[qr * LP + col];
                 G[pr * LP + col] = cr * tp - sr * tq; G[qr * LP + col] = sr * tp + cr * tq;
             }
         }
@@ -406,60 +382,58 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const T* __restrict__ p
         if (any) atomicAdd(rotated, 1);
     }
     if (any) {
-        T* out = Ubuf + static_cast<int64_t>(pair) * (KP * KP);
+        double* out = Ubuf + static_cast<int64_t>(pair) * (KP * KP);
         for (int e = tid; e < KP * KP; e += 256) out[e] = U[(e / KP) * LP + (e % KP)];
     }
 }
 
 // rows of the pair: new[j][i] = sum_c U[c][j] old[c][i], for W^T and V^T, over this workgroup's i-range
-template <class T>
-__global__ __launch_bounds__(256) void eigh_update_kernel(T* __restrict__ Wt, T* __restrict__ Vt, const T* __restrict__ Ubuf,
+__global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ Wt, double* __restrict__ Vt, const double* __restrict__ Ubuf,
                                                           const int* __restrict__ pair_flag, int64_t d, int nblocks, int players, int round,
                                                           int64_t chunk, const int* __restrict__ done) {
-    extern __shared__ double lds_raw[];
+    extern __shared__ double lds[];
     if (*done) return;
-    T* lds = reinterpret_cast<T*>(lds_raw);
-    T* Ul = lds;                 // [64 c][UPITCH]  (j contiguous)
-    T* Tl = lds + KP * UPITCH;   // [64 c][UPITCH]  (i contiguous)
+    double* Ul = lds;                 // [64 c][UPITCH]  (j contiguous)
+    double* Tl = lds + KP * UPITCH;   // [64 c][UPITCH]  (i contiguous)
     const int pair = blockIdx.x;
     if (!pair_flag[pair]) return;
     int P, Q;
     pair_of_round(pair, round, players, P, Q);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const T* usrc = Ubuf + static_cast<int64_t>(pair) * (KP * KP);
+    const double* usrc = Ubuf + static_cast<int64_t>(pair) * (KP * KP);
     for (int e = tid; e < KP * KP; e += 256) Ul[(e / KP) * UPITCH + (e % KP)] = usrc[e];
     const int lrow = tid >> 2, lseg = tid & 3;  // loader: row c of the pair, 16-double segment of the tile
     const int64_t grow = pair_row(lrow, P, Q, nblocks, d);
     // output rows of this wave: j = wave * 16 + (lane >> 4) + 4 r
     int64_t orow[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) orow[r] = pair_row(wave * 16 + Mx<T>::row(lane, r), P, Q, nblocks, d);
+    for (int r = 0; r < 4; ++r) orow[r] = pair_row(wave * 16 + (lane >> 4) + 4 * r, P, Q, nblocks, d);
     const int64_t i_begin = blockIdx.y * chunk, i_end = min(d, i_begin + chunk);
 #pragma unroll 1
     for (int which = 0; which < 2; ++which) {
-        T* Mat = which == 0 ? Wt : Vt;
+        double* Mx = which == 0 ? Wt : Vt;
         for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
-            T v[16];
+            double v[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t i = i0 + lseg * 16 + e;
-                v[e] = (grow >= 0 && i < i_end) ? Mat[grow * d + i] : T(0);
+                v[e] = (grow >= 0 && i < i_end) ? Mx[grow * d + i] : 0.0;
             }
             __syncthreads();  // previous tile consumed (and U staged, first time round)
 #pragma unroll
             for (int e = 0; e < 16; ++e) Tl[lrow * UPITCH + lseg * 16 + e] = v[e];
             __syncthreads();
-            typename Mx<T>::acc_t acc[4];
+            f64x4 acc[4];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[b] = typename Mx<T>::acc_t{0, 0, 0, 0};
+            for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int ks = 0; ks < KP / 4; ++ks) {
                 const int c = ks * 4 + (lane >> 4);
-                const T a = Ul[c * UPITCH + wave * 16 + (lane & 15)];  // A[j][k = c] = U[c][j]
+                const double a = Ul[c * UPITCH + wave * 16 + (lane & 15)];  // A[j][k = c] = U[c][j]
 #pragma unroll
                 for (int b = 0; b < 4; ++b) {
-                    const T bv = Tl[c * UPITCH + b * 16 + (lane & 15)];  // B[k = c][i]
-                    acc[b] = Mx<T>::mfma(a, bv, acc[b]);
+                    const double bv = Tl[c * UPITCH + b * 16 + (lane & 15)];  // B[k = c][i]
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -467,112 +441,10 @@ __global__ __launch_bounds__(256) void eigh_update_kernel(T* __restrict__ Wt, T*
                 const int64_t i = i0 + b * 16 + (lane & 15);
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (orow[r] >= 0 && i < i_end) Mat[orow[r] * d + i] = acc[b][r];
+                    if (orow[r] >= 0 && i < i_end) Mx[orow[r] * d + i] = acc[b][r];
             }
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Mixed-precision driver support (d >= MIXED_MIN_D): fp32 warm start, fp64 re-orthonormalisation, fp64 polish.
-//   dgemm_nt  C = alpha A B^T + diag I   (A [M, K], B [N, K] row-major: the Gram matrix V V^T and W^T = V^T S)
-//   dgemm_tn  C = A^T B                  (A [K, M], B [K, N] row-major: X V with X symmetric)
-// 64 x 64 output tile per workgroup on v_mfma_f64_16x16x4_f64, operands staged through LDS as in the gram / update kernels.
-// ------------------------------------------------------------------------------------------------
-__global__ void eigh_init32_kernel(float* Wt, float* Vt, const double* S, int64_t d) {
-    const int64_t total = d * d;
-    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total;
-         e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
-        Wt[e] = static_cast<float>(S[e]);
-        Vt[e] = (e / d == e % d) ? 1.0f : 0.0f;
-    }
-}
-
-__global__ void widen_kernel(double* out, const float* in, int64_t n) {
-    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n; e += static_cast<int64_t>(gridDim.x) * blockDim.x)
-        out[e] = static_cast<double>(in[e]);
-}
-
-__global__ __launch_bounds__(256) void dgemm_nt_kernel(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B,
-                                                       int64_t M, int64_t N, int64_t K, double alpha, double diag) {
-    constexpr int GPITCH = Mx<double>::GPITCH;
-    __shared__ double ta[64 * GPITCH];
-    __shared__ double tb[64 * GPITCH];
-    const int64_t m0 = static_cast<int64_t>(blockIdx.y) * 64, n0 = static_cast<int64_t>(blockIdx.x) * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = tid >> 2, lseg = tid & 3;
-    const int64_t arow = m0 + lrow, brow = n0 + lrow;
-    f64x4 acc[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int64_t k0 = 0; k0 < K; k0 += GK) {
-        double va[8], vb[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t k = k0 + lseg * 8 + e;
-            va[e] = (arow < M && k < K) ? A[arow * K + k] : 0.0;
-            vb[e] = (brow < N && k < K) ? B[brow * K + k] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { ta[lrow * GPITCH + lseg * 8 + e] = va[e]; tb[lrow * GPITCH + lseg * 8 + e] = vb[e]; }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < GK / 4; ++ks) {
-            const int k = ks * 4 + (lane >> 4);
-            const double a = ta[(wave * 16 + (lane & 15)) * GPITCH + k];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, tb[(b * 16 + (lane & 15)) * GPITCH + k], acc[b], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t m = m0 + wave * 16 + (lane >> 4) + 4 * r, n = n0 + b * 16 + (lane & 15);
-            if (m < M && n < N) C[m * N + n] = alpha * acc[b][r] + (m == n ? diag : 0.0);
-        }
-}
-
-__global__ __launch_bounds__(256) void dgemm_tn_kernel(double* __restrict__ C, const double* __restrict__ A, const double* __restrict__ B,
-                                                       int64_t M, int64_t N, int64_t K) {
-    extern __shared__ double lds_raw[];
-    double* Al = lds_raw;                // [64 k][UPITCH]  (m contiguous)
-    double* Bl = lds_raw + KP * UPITCH;  // [64 k][UPITCH]  (n contiguous)
-    const int64_t m0 = static_cast<int64_t>(blockIdx.y) * 64, n0 = static_cast<int64_t>(blockIdx.x) * 64;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = tid >> 2, lseg = tid & 3;  // loader: k-row of the tile, 16-double segment
-    f64x4 acc[4];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int64_t k0 = 0; k0 < K; k0 += 64) {
-        double va[16], vb[16];
-        const int64_t k = k0 + lrow;
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t m = m0 + lseg * 16 + e, n = n0 + lseg * 16 + e;
-            va[e] = (k < K && m < M) ? A[k * M + m] : 0.0;
-            vb[e] = (k < K && n < N) ? B[k * N + n] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int e = 0; e < 16; ++e) { Al[lrow * UPITCH + lseg * 16 + e] = va[e]; Bl[lrow * UPITCH + lseg * 16 + e] = vb[e]; }
-        __syncthreads();
-#pragma unroll
-        for (int ks = 0; ks < 64 / 4; ++ks) {
-            const int c = ks * 4 + (lane >> 4);
-            const double a = Al[c * UPITCH + wave * 16 + (lane & 15)];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Bl[c * UPITCH + b * 16 + (lane & 15)], acc[b], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int64_t m = m0 + wave * 16 + (lane >> 4) + 4 * r, n = n0 + b * 16 + (lane & 15);
-            if (m < M && n < N) C[m * N + n] = acc[b][r];
-        }
 }
 
 // End of a sweep, on the device: a sweep without a rotation is convergence.  state = {rotated, done, sweeps}.
@@ -732,6 +604,8 @@ __global__ __launch_bounds__(256) void eigh_small_kernel(const float* G, int l, 
 
 }  // namespace
 
+extern "C" {
+
 namespace {
 struct BlockPlan { int nblocks, players, pairs, gsplit, usplit; int64_t gchunk, uchunk; };
 BlockPlan block_plan(int64_t d) {
@@ -751,24 +625,6 @@ BlockPlan block_plan(int64_t d) {
 }
 constexpr int UPDATE_LDS = 2 * KP * UPITCH * static_cast<int>(sizeof(double));
 constexpr int64_t BLOCKED_MIN_D = 256;
-constexpr int64_t MIXED_MIN_D = 1024;   // mixed-precision driver from here on (KF_EIGH_MIXED=0 / 1 overrides)
-
-// One sweep of the blocked solver (in-block pairs, then the tournament of block pairs) enqueued on `st`.
-template <class T>
-void enqueue_blocked_sweep(const BlockPlan& p, T* Wt, T* Vt, T* partial, T* Ubuf, int* pair_flag, int64_t d, T tol, const double* frob2_dev,
-                           double null_scale, int* state, hipStream_t st) {
-    const int* done = state + 1;
-    for (int r = -1; r < p.players - 1; ++r) {
-        const int pairing = r < 0 ? 0 : r;
-        hipLaunchKernelGGL(eigh_gram_kernel<T>, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players, pairing,
-                           p.gsplit, p.gchunk, done);
-        hipLaunchKernelGGL(eigh_solve_kernel<T>, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1, tol,
-                           frob2_dev, null_scale, state, done);
-        hipLaunchKernelGGL(eigh_update_kernel<T>, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d, p.nblocks,
-                           p.players, pairing, p.uchunk, done);
-    }
-    hipLaunchKernelGGL(eigh_sweep_end_kernel, dim3(1), dim3(1), 0, st, state);
-}
 
 int configure_eigh() {
     static std::once_flag flag;
@@ -778,19 +634,13 @@ int configure_eigh() {
         const size_t small_bytes = sizeof(double) * (2 * static_cast<size_t>(SMALL_MAX) * ld_max + SMALL_MAX) + sizeof(int) * SMALL_MAX + 16;
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(small_bytes)) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_update_kernel<double>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                UPDATE_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_update_kernel<float>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                UPDATE_LDS) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(dgemm_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+            hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 UPDATE_LDS) != hipSuccess)
             status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
 }
 }  // namespace
-
-extern "C" {
 
 int64_t kf_eigh_workspace_bytes(int64_t d) {
     // Wt, Vt (d*d doubles each), lam (d doubles), rank (d ints), flags; for the blocked solver the per-pair Gram
@@ -800,7 +650,6 @@ int64_t kf_eigh_workspace_bytes(int64_t d) {
         const BlockPlan p = block_plan(d);
         bytes += static_cast<int64_t>(sizeof(double)) * KP * KP * p.pairs * (p.gsplit + 1) + static_cast<int64_t>(sizeof(int)) * (p.pairs + 16) + 512;
     }
-    if (d >= MIXED_MIN_D) bytes += static_cast<int64_t>(sizeof(double)) * 3 * d * d + 512;  // S, X (and the fp32 pair), V scratch
     return bytes;
 }
 
@@ -842,69 +691,32 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
         double* partial = frob2_dev + 8;
         double* Ubuf = partial + static_cast<int64_t>(KP) * KP * p.pairs * p.gsplit;
         int* pair_flag = reinterpret_cast<int*>(Ubuf + static_cast<int64_t>(KP) * KP * p.pairs);
+        // Convergence is decided ON THE DEVICE (eigh_sweep_end_kernel); the host enqueues sweeps in batches and reads the
+        // state back once per batch -- the kernels of sweeps enqueued past convergence exit at their first instruction.
         int* state = flag;  // {rotated, done, sweeps}: three of the 16 spare ints behind `rank`
-        int host_state[3] = {0, 0, 0};
-        // Runs sweeps of element type T until the device-side convergence flag is set.  Convergence is decided ON THE DEVICE
-        // (eigh_sweep_end_kernel); the host enqueues sweeps in batches and reads the state back once per batch -- the kernels
-        // of sweeps enqueued past convergence exit at their first instruction.
-        auto run = [&](auto* W, auto* V, auto tolerance, double nscale, int limit, int first_batch) -> int {
-            typedef typename std::remove_pointer<decltype(W)>::type T;
-            if (hipMemsetAsync(state, 0, 3 * sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-            host_state[0] = host_state[1] = host_state[2] = 0;
-            int enqueued = 0;
-            while (enqueued < limit && !host_state[1]) {
-                const int batch = enqueued == 0 ? first_batch : 4;
-                for (int b = 0; b < batch && enqueued < limit; ++b, ++enqueued)
-                    enqueue_blocked_sweep<T>(p, W, V, reinterpret_cast<T*>(partial), reinterpret_cast<T*>(Ubuf), pair_flag, d,
-                                             static_cast<T>(tolerance), frob2_dev, nscale, state, st);
-                if (hipMemcpyAsync(host_state, state, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-                if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-                if (verbose) fprintf(stderr, "[kf_eigh] d=%lld blocked fp%d: %d sweeps run, done=%d\n", static_cast<long long>(d),
-                                     static_cast<int>(8 * sizeof(T)), host_state[2], host_state[1]);
+        if (hipMemsetAsync(state, 0, 3 * sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        const int* done = state + 1;
+        int enqueued = 0, host_state[3] = {0, 0, 0};
+        while (enqueued < max_sweeps && !host_state[1]) {
+            const int batch = enqueued < 8 ? 8 : 4;  // nothing converges in under 8 sweeps at these sizes
+            for (int b = 0; b < batch && enqueued < max_sweeps; ++b, ++enqueued) {
+                // pass -1: the column pairs inside every block (pairing of round 0); then the tournament of block pairs
+                for (int r = -1; r < p.players - 1; ++r) {
+                    const int pairing = r < 0 ? 0 : r;
+                    hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players,
+                                       pairing, p.gsplit, p.gchunk, done);
+                    hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1,
+                                       tol, frob2_dev, null_scale, state, done);
+                    hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
+                                       p.nblocks, p.players, pairing, p.uchunk, done);
+                }
+                hipLaunchKernelGGL(eigh_sweep_end_kernel, dim3(1), dim3(1), 0, st, state);
             }
-            return KF_OK;
-        };
-        const char* mixed_env = getenv("KF_EIGH_MIXED");
-        const bool mixed = mixed_env ? atoi(mixed_env) != 0 : d >= MIXED_MIN_D;
-        if (mixed && d >= MIXED_MIN_D) {
-            // ---- mixed precision: the streams of W and V bound this solver, so most sweeps are run on fp32 copies (half the
-            // bytes, fp32 matrix cores), and fp64 only refines:
-            //   1. fp32 Jacobi on (float) S to fp32 convergence -> V32, orthonormal and diagonalising to ~1e-6;
-            //   2. V = V32 in fp64, re-orthonormalised by two Newton-Schulz steps V <- (1.5 I - 0.5 V V^T) V (quadratic: 1e-6 ->
-            //      1e-12 -> rounding), W = V S -- seven d^3 products on the fp64 matrix cores;
-            //   3. the fp64 sweeps start from an almost diagonal V^T S^2 V and converge quadratically (2-4 sweeps instead of 20-35).
-            // Every accuracy property is that of the fp64 phase; the warm start only changes where it begins.
-            double* S = reinterpret_cast<double*>((reinterpret_cast<uintptr_t>(pair_flag + p.pairs + 16) + 255) & ~static_cast<uintptr_t>(255));
-            double* X = S + d * d;
-            double* Vs = X + d * d;
-            float* W32 = reinterpret_cast<float*>(X);
-            float* V32 = W32 + d * d;
-            if (hipMemcpyAsync(S, Wt, sizeof(double) * d * d, hipMemcpyDeviceToDevice, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-            hipLaunchKernelGGL(eigh_init32_kernel, dim3(g), dim3(256), 0, st, W32, V32, S, d);
-            const double eps32 = 1.1920928955078125e-07;
-            int rc = run(W32, V32, 4.0 * eps32 * sqrt(static_cast<double>(d)), eps32 * eps32 * static_cast<double>(d), 40, 8);
-            if (rc != KF_OK) return rc;
-            const int sweeps32 = host_state[2];
-            hipLaunchKernelGGL(widen_kernel, dim3(g), dim3(256), 0, st, Vt, V32, d * d);
-            const unsigned tiles = static_cast<unsigned>((d + 63) / 64);
-            double* cur = Vt;
-            double* other = Vs;
-            for (int it = 0; it < 2; ++it) {
-                hipLaunchKernelGGL(dgemm_nt_kernel, dim3(tiles, tiles), dim3(256), 0, st, X, cur, cur, d, d, d, -0.5, 1.5);
-                hipLaunchKernelGGL(dgemm_tn_kernel, dim3(tiles, tiles), dim3(256), UPDATE_LDS, st, other, X, cur, d, d, d);
-                std::swap(cur, other);
-            }
-            // two swaps: `cur` is Vt again.  W^T = V^T S (S symmetric: B = S in the A B^T form)
-            hipLaunchKernelGGL(dgemm_nt_kernel, dim3(tiles, tiles), dim3(256), 0, st, Wt, cur, S, d, d, d, 1.0, 0.0);
-            rc = run(Wt, Vt, tol, null_scale, max_sweeps, 3);
-            if (rc != KF_OK) return rc;
-            sweeps = sweeps32 + host_state[2];
-            if (verbose) fprintf(stderr, "[kf_eigh] d=%lld mixed: %d fp32 + %d fp64 sweeps\n", static_cast<long long>(d), sweeps32, host_state[2]);
-        } else {
-            const int rc = run(Wt, Vt, tol, null_scale, max_sweeps, 8);  // nothing converges in under 8 sweeps at these sizes
-            if (rc != KF_OK) return rc;
-            sweeps = host_state[2];
+            if (hipMemcpyAsync(host_state, state, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            if (verbose) fprintf(stderr, "[kf_eigh] d=%lld blocked: %d sweeps run, done=%d\n", static_cast<long long>(d), host_state[2], host_state[1]);
         }
+        sweeps = host_state[2];
         if (host_state[1]) status = KF_OK;
     } else if (d > 1) {
         double frob2 = 0.0;

@@ -59,9 +59,13 @@ class ScoreSink:
         return self._flat
 
 
-# Low-rank query gradients are expanded to dense [q, O, I'] blocks just ahead of the score GEMM, this many bytes
-# (fp32) at a time; if ALL held queries of a layer fit, the expansion is done once per train pass and cached.
-LOW_RANK_EXPANSION_BYTES = 4 << 30
+# Low-rank query gradients of layers applied to SEQUENCES (several rows per sample) are expanded to dense [q, O, I'] blocks
+# just ahead of the score GEMM, this many bytes (fp32) at a time; if ALL held queries of a layer fit, the expansion is done once
+# per train pass and cached.  (For R rows per sample the factored contraction costs 2 R k (O + I') flops per pair against
+# 2 O I' for the dense one -- with R = 512 tokens and k = 64 that is ten times MORE -- so for sequences low rank buys storage,
+# and the dense block is the cheaper way to spend flops; the block is made as large as HBM allows, since every block re-forms
+# the train batch's per-sample gradients.)  Layers with ONE row per sample use the factored contraction, below.
+LOW_RANK_EXPANSION_BYTES = 32 << 30
 
 
 def unpadded_queries(module, preconditioned):
@@ -139,6 +143,30 @@ class TiledQueries:
 
 class PairwiseScoreTracker(BaseTracker):
     _expanded = None  # (left factor, dense tensor): per-pass cache of expanded low-rank queries
+
+    def _score_low_rank_rows(self, left: torch.Tensor, right: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool,
+                             scores: torch.Tensor, offset: int, scale: float) -> None:
+        """One row per sample: ``scores[q, n] += sum_k (g_n . L_q[:, k]) (R_q[k, :] . a'_n)`` -- the reference's
+        ``"qik,qko,bi,bo->qb"`` (module/linear.py:83-99) contracted WITHOUT expanding ``P_q = L_q R_q``: two skinny batched
+        GEMMs and a k-long row dot, ``2 k (O + I')`` flops per pair instead of ``2 O I'``."""
+        q, o, k = left.shape
+        ip = right.shape[2]
+        b = g.shape[0]
+        gq, aq = g.reshape(b, o).float().contiguous(), a.reshape(b, -1).float()
+        if ones:
+            aq = torch.cat([aq, aq.new_ones(b, 1)], dim=-1)
+        aq = aq.contiguous()
+        if self._low_rank_f32 is None or self._low_rank_f32[0] is not left:
+            self._low_rank_f32 = (left, left.float().contiguous(), right.float().contiguous())
+        _, lf, rf = self._low_rank_f32
+        dev = g.device
+        u = ops._bmm((q, b, k), ops.view(gq, 0, o, 1, b, o), ops.view(lf, o * k, 1, k, k, o), q, dev)          # [q, b, k] = g L_q
+        v = ops._bmm((q, b, k), ops.view(aq, 0, ip, 1, b, ip), ops.view(rf, k * ip, ip, 1, k, ip), q, dev)      # [q, b, k] = a' R_q^T
+        block = torch.empty(q * b, dtype=torch.float32, device=dev)
+        ops.rowwise_dot(block, u.reshape(q * b, k), v.reshape(q * b, k), scale=scale, accumulate=False)
+        scores[:, offset:offset + b].add_(block.view(q, b))
+
+    _low_rank_f32 = None  # (left as held, left fp32, right fp32): per-pass cache for the factored contraction
 
     def _query_blocks(self, preconditioned):
         """Yields ``(first_row, dense [q_c, O, I'])`` covering the held queries."""
@@ -300,6 +328,9 @@ class PairwiseScoreTracker(BaseTracker):
                     a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
                                       append_ones=ones).reshape(n, r, -1)
                     ones = False
+                if isinstance(preconditioned, list) and g.shape[1] == 1:
+                    self._score_low_rank_rows(preconditioned[0], preconditioned[1], g, a, ones, scores, offset, module.gradient_scale)
+                    return
                 fast = self._fast_layout(preconditioned, g, a, ones)
                 if fast is not None:
                     tiled, a_in, ones_in = fast
@@ -368,6 +399,7 @@ class PairwiseScoreTracker(BaseTracker):
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.module.score_sink = None
         self._expanded = None
+        self._low_rank_f32 = None
         self.clear_all_cache()
 
     def release_memory(self) -> None:

@@ -9,20 +9,16 @@ if len(sys.argv) > 1:
     sizes = [(d, n) for d, n in sizes if str(d) in sys.argv[1:]] if sys.argv[1] != "multi" else []
 for d, n in sizes:
     g = torch.Generator().manual_seed(d)
-    x = (torch.randn(n, d, generator=g) * torch.logspace(0, -3, d)).to(dev)
-    cov = x.t() @ x
+    x = torch.randn(n, d, generator=g) * torch.logspace(0, -3, d)
+    cov = (x.t() @ x).to(dev)
+    ops.eigh(cov, float(n)); torch.cuda.synchronize()
+    t0 = time.perf_counter(); evals, evecs, sweeps = ops.eigh(cov, float(n)); torch.cuda.synchronize(); dt = time.perf_counter() - t0
     s = 0.5 * (cov.double() + cov.double().t()) / n
-    want = torch.linalg.eigvalsh(s.cpu()) if d <= 4096 else None
-    for mixed in ("0", "1"):  # KF_EIGH_MIXED: fp64 throughout / fp32 warm start + fp64 polish (d >= 1024)
-        os.environ["KF_EIGH_MIXED"] = mixed
-        ops.eigh(cov, float(n)); torch.cuda.synchronize()
-        t0 = time.perf_counter(); evals, evecs, sweeps = ops.eigh(cov, float(n)); torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        ortho = float((evecs.t() @ evecs - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())
-        recon = float(((evecs * evals) @ evecs.t() - s).norm() / s.norm())
-        verr = float((evals.cpu() - want).abs().max() / want.abs().max()) if want is not None else float("nan")
-        print(f"d={d} mixed={mixed}: {dt*1e3:.0f} ms, {sweeps} sweeps, ortho {ortho:.2e}, recon {recon:.2e}, evals {verr:.2e}, "
-              f"ascending {bool((evals[1:] >= evals[:-1]).all())}", flush=True)
-    os.environ.pop("KF_EIGH_MIXED")
+    ortho = float((evecs.t() @ evecs - torch.eye(d, device=dev, dtype=torch.float64)).abs().max())
+    recon = float(((evecs * evals) @ evecs.t() - s).norm() / s.norm())
+    want = torch.linalg.eigvalsh(s.cpu())
+    verr = float((evals.cpu() - want).abs().max() / want.abs().max())
+    print(f"d={d}: {dt*1e3:.0f} ms, {sweeps} sweeps, ortho {ortho:.2e}, recon {recon:.2e}, evals {verr:.2e}, ascending {bool((evals[1:] >= evals[:-1]).all())}")
 
 # ---- the eigen stage's own shape: MULTI matrices of one size spread over LANES host threads / HIP streams -------------
 # python tools/eigh_bench.py multi <d> <count> [lanes]   e.g. multi 3073 16 8  (a BERT / GPT-2 eigen stage has 24 of 3072-3073)
