@@ -303,7 +303,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(HalfGemmArgs a) {
 // registers over this workgroup's sample range, one fp32 atomic per output element at the end.
 struct HalfLambdaArgs {
     HalfGemmArgs g;      // operands / shapes (C = Lambda fp32, ldc); batch handled by the z loop below
-    int batch, zchunk;
+    int batch, zchunk, zblocks;
     float scale2;
 };
 
@@ -311,8 +311,18 @@ __global__ __launch_bounds__(NTHREADS) void lambda_bf16_kernel(HalfLambdaArgs la
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     const HalfGemmArgs& a = la.g;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
-    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
-    const int z_begin = blockIdx.z * la.zchunk, z_end = min(la.batch, z_begin + la.zchunk);
+    // XCD-aware 1-D grid (workgroup L runs on XCD L % 8): items are (sample range, tile), sample range major, cut into 8
+    // contiguous runs -- the tiles of a sample range re-read the same rotated factors Gt[z] / At[z], so they run on ONE XCD and
+    // share its L2 (with the round-2 3-D grid consecutive tiles went to different XCDs and every XCD fetched every sample:
+    // 2.4x the algorithmic bytes, profiles/r02_pmc_resnet9.json)
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(la.zblocks) * tiles, per_xcd = (items + 7) / 8;
+    const int block = blockIdx.x, xcd = block & 7, jx = block >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + jx;
+    if (jx >= per_xcd || item >= items) return;
+    const int zb = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int n0 = (tile % a.tiles_n) * 128, m0 = (tile / a.tiles_n) * 128;
+    const int z_begin = zb * la.zchunk, z_end = min(la.batch, z_begin + la.zchunk);
     f32x16 sq[2][2];
     zero_acc(sq);
     for (int z = z_begin; z < z_end; ++z) {

@@ -979,10 +979,11 @@ int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gtv, const voi
         int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>(b, cdiv(1024, tiles)));
         la.zchunk = static_cast<int>(cdiv(b, zsplit));
         zsplit = cdiv(b, la.zchunk);
-        if (zsplit > 65535) return KF_ERR_INVALID_ARGUMENT;
+        la.zblocks = static_cast<int>(zsplit);
         la.batch = static_cast<int>(b); la.scale2 = scale * scale;
-        hipLaunchKernelGGL(lambda_bf16_kernel, dim3(static_cast<unsigned>(h.tiles_n), static_cast<unsigned>(h.tiles_m), static_cast<unsigned>(zsplit)),
-                           dim3(NTHREADS), HSMEM_BYTES, st, la);
+        const int64_t blocks = 8 * cdiv(zsplit * tiles, 8);
+        if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(lambda_bf16_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), HSMEM_BYTES, st, la);
         return launch_status();
     }
     const float* Gt = reinterpret_cast<const float*>(Gtv);

@@ -116,14 +116,14 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
     const unsigned char* frag_b = sm + B_OFFSET + (wn * 64 + lr) * 128;
 
     // piece (0 A0, 1 A1, 2 B0, 3 B1) of k-tile t = requests 2 piece, 2 piece + 1 -> buffer t & 1
-    auto issue_piece = [&](int piece, int t) {
-        const auto off = piece < 2 ? walk_a(t) : walk_b(t);
+    auto issue_at = [&](int piece, int t, int64_t off) {
 #pragma unroll
         for (int r = 2 * piece; r < 2 * piece + 2; ++r) {
             unsigned char* dst = sm + (t & 1) * STAGE_BYTES + (r < 4 ? 0 : B_OFFSET) + request_row0(r, wave) * 128;
             glds16(src.p[r] + off, dst);
         }
     };
+    auto issue_piece = [&](int piece, int t) { issue_at(piece, t, piece < 2 ? walk_a(t) : walk_b(t)); };
 
     bf16x8 a[2][4], b[2][4];
     auto read_a = [&](int half, int buf) {
@@ -162,16 +162,19 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
 #define KF_PP_TILE(T, MORE1, MORE2)                                                                                    \
     do {                                                                                                               \
         const int t_ = (T), buf_ = t_ & 1;                                                                             \
+        int64_t oa_ = 0, ob_ = 0;   /* walks first: an offset read from an LDS table is then the oldest LDS request */ \
+        if (MORE1) { oa_ = walk_a(t_ + 1); ob_ = walk_b(t_ + 1); }                                                     \
         read_a(0, buf_);                                                                                               \
         read_b(buf_);                                                                                                  \
-        if (MORE1) { issue_piece(3, t_ + 1); issue_piece(1, t_ + 1); wait_vmcnt<8>(); }                                \
+        if (MORE1) { issue_at(3, t_ + 1, ob_); issue_at(1, t_ + 1, oa_); wait_vmcnt<8>(); }                            \
         else wait_vmcnt<0>();                                                                                          \
         wait_lds_reads();                                                                                              \
         barrier();                                                                                                     \
         KF_PP_MFMA(0);                                                                                                 \
         barrier();                                                                                                     \
+        if (MORE2) { oa_ = walk_a(t_ + 2); ob_ = walk_b(t_ + 2); }                                                     \
         read_a(1, buf_);                                                                                               \
-        if (MORE2) { issue_piece(0, t_ + 2); issue_piece(2, t_ + 2); wait_vmcnt<6>(); }                                \
+        if (MORE2) { issue_at(0, t_ + 2, oa_); issue_at(2, t_ + 2, ob_); wait_vmcnt<6>(); }                            \
         else if (MORE1) wait_vmcnt<2>();                                                                               \
         wait_lds_reads();                                                                                              \
         barrier();                                                                                                     \

@@ -470,7 +470,21 @@ struct PsgV2Args {
 
 constexpr int PV2_OPERAND_BYTES = 128 * 128;
 constexpr int PV2_STAGE_BYTES = 2 * PV2_OPERAND_BYTES;
-constexpr int PV2_SMEM = 2 * PV2_STAGE_BYTES;
+constexpr int PV2_KTAB_STEPS = 64;                       // k-steps (of 64 positions) the implicit-im2col offset table holds
+constexpr int PV2_SMEM = 2 * PV2_STAGE_BYTES + PV2_KTAB_STEPS * 8 * 4;
+
+// Implicit-im2col offset of k-octet `oc` of k-step `ks` -- oy * s1 * Wq + ox for position p0 = 64 ks + 8 oc -- for every (ks, oc)
+// of a sample, once per workgroup, into the LDS tail: the division by the output width used to be paid per DMA request.
+template <class Args>
+__device__ __forceinline__ int* conv_offset_table(const Args& a, unsigned char* sm, int K, int nthreads) {
+    int* tab = reinterpret_cast<int*>(sm + 2 * PV2_STAGE_BYTES);
+    const int entries = min(K >> 6, PV2_KTAB_STEPS) * 8;
+    for (int e = threadIdx.x; e < entries; e += nthreads) {
+        const int p0 = (e >> 3) * 64 + (e & 7) * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2;
+        tab[e] = oy * a.s1 * a.Wq + ox;
+    }
+    return tab;
+}
 
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -514,6 +528,11 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
             src_b[t] = a.B + static_cast<int64_t>(z) * a.b_sample_stride + static_cast<int64_t>(i) * a.K + oct[t] * 8;
         }
     }
+    const int* ktab = nullptr;
+    if (a.conv && (a.K >> 6) <= PV2_KTAB_STEPS) {
+        ktab = conv_offset_table(a, sm, a.K, NTHREADS);
+        __syncthreads();
+    }
     auto stage = [&](int buf, int k0) {
         unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
 #pragma unroll
@@ -521,8 +540,10 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
         if (a.conv) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const int p0 = k0 + oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2;
-                glds16(src_b[t] + oy * a.s1 * a.Wq + ox, base + PV2_OPERAND_BYTES + t * 1024);
+                int off;
+                if (ktab) off = ktab[(k0 >> 6) * 8 + oct[t]];
+                else { const int p0 = k0 + oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2; off = oy * a.s1 * a.Wq + ox; }
+                glds16(src_b[t] + off, base + PV2_OPERAND_BYTES + t * 1024);
             }
         } else {
 #pragma unroll
@@ -625,15 +646,18 @@ __device__ __forceinline__ bool psg_decode(const PsgV2Args& a, int64_t item, int
     return true;
 }
 
-__device__ __forceinline__ void psg_stage(const PsgV2Args& a, const PsgItem& it, unsigned char* sm, int buf, int k0, int wave) {
+__device__ __forceinline__ void psg_stage(const PsgV2Args& a, const PsgItem& it, unsigned char* sm, int buf, int k0, int wave,
+                                          const int* ktab) {
     unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
 #pragma unroll
     for (int t = 0; t < 4; ++t) glds16(it.src_a[t] + k0, base + t * 1024);
     if (a.conv) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int p0 = k0 + it.oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2;
-            glds16(it.src_b[t] + oy * a.s1 * a.Wq + ox, base + PV2_OPERAND_BYTES + t * 1024);
+            int off;
+            if (ktab) off = ktab[(k0 >> 6) * 8 + it.oct[t]];
+            else { const int p0 = k0 + it.oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2; off = oy * a.s1 * a.Wq + ox; }
+            glds16(it.src_b[t] + off, base + PV2_OPERAND_BYTES + t * 1024);
         }
     } else {
 #pragma unroll
@@ -657,7 +681,12 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
     bool have = item < last;
     if (!have) return;
     const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
-    psg_stage(a, cur, sm, 0, 0, wave);
+    const int* ktab = nullptr;
+    if (a.conv && (a.K >> 6) <= PV2_KTAB_STEPS) {
+        ktab = conv_offset_table(a, sm, a.K, NTHREADS);
+        __syncthreads();
+    }
+    psg_stage(a, cur, sm, 0, 0, wave, ktab);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     int buf = 0;
@@ -668,8 +697,8 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
         f32x16 acc[2][2];
         zero_acc(acc);
         for (int k0 = 0; k0 < a.K; k0 += 64) {
-            if (k0 + 64 < a.K) psg_stage(a, cur, sm, buf ^ 1, k0 + 64, wave);
-            else if (have_next) psg_stage(a, nxt, sm, buf ^ 1, 0, wave);   // the next item's first k-step rides behind this one
+            if (k0 + 64 < a.K) psg_stage(a, cur, sm, buf ^ 1, k0 + 64, wave, ktab);
+            else if (have_next) psg_stage(a, nxt, sm, buf ^ 1, 0, wave, ktab);   // the next item's first k-step rides behind this one
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
             wave_kstep_64x64(acc, sa, sb, hi, sw);
@@ -883,14 +912,20 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
         src_b[g] = row_source(min(n0 + row, a.N - 1));
     }
     const int ksteps = a.K >> 6;
+    const int* ktab = nullptr;   // implicit-im2col offsets per (k-step, octet): one division per table entry, not per request
+    if (a.conv && ksteps <= PV2_KTAB_STEPS) {
+        ktab = conv_offset_table(a, sm, a.K, NTHREADS);
+        __syncthreads();
+    }
     auto stage = [&](int buf, int step) {  // step = (z - z_begin) * ksteps + kstep
-        const int z = z_begin + step / ksteps, k0 = (step % ksteps) * 64;
-        const int64_t zoff = static_cast<int64_t>(z) * a.sample_stride;
+        const int zq = step / ksteps, ks = step - zq * ksteps, k0 = ks * 64;
+        const int64_t zoff = static_cast<int64_t>(z_begin + zq) * a.sample_stride;
         unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             int koff = k0 + oct[g] * 8;
-            if (a.conv) { const int oy = koff / a.O2, ox = koff - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
+            if (ktab) koff = ktab[ks * 8 + oct[g]];
+            else if (a.conv) { const int oy = koff / a.O2, ox = koff - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
             glds16(src_a[g] + zoff + koff, base + g * 1024);
             glds16(src_b[g] + zoff + koff, base + PV2_OPERAND_BYTES + g * 1024);
         }
@@ -935,6 +970,9 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
 // loop is one (sample, k-step), walked without a break; the 8 DMA requests of a lane share one k-octet, so the implicit-im2col
 // offset (one division by the output width) is computed once per k-tile and lane.  A 128 x 128 / 4-wave tile issues twice
 // the LDS-DMA requests per MFMA of this one, which is what bound the v2 kernel (485 TFLOP/s with its epilogue switched off).
+constexpr int COV_KTAB_STEPS = 128;                       // k-steps per sample the offset table holds (4 KB)
+constexpr int COV_V3_SMEM = pp::SMEM_BYTES + COV_KTAB_STEPS * 8 * 4;
+
 __global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
@@ -969,11 +1007,20 @@ __global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
     }
     const int ksteps = a.K >> 6;
     const int64_t base = static_cast<int64_t>(z_begin) * a.sample_stride;
+    // per-(k-step, octet) offsets inside a sample, computed ONCE per workgroup into the LDS tail (the implicit-im2col offset
+    // needs a division by the output width; done per request it made the L segments longer than the M segments)
+    int* ktab = reinterpret_cast<int*>(sm + pp::SMEM_BYTES);   // ksteps <= COV_KTAB_STEPS (the launcher's condition for this kernel)
+    for (int e = tid; e < ksteps * 8; e += pp::THREADS) {
+        const int p0 = (e >> 3) * 64 + (e & 7) * 8;
+        int koff = (e >> 3) * 64;   // plain rows: the octet is already in the source pointer
+        if (a.conv) { const int oy = p0 / a.O2, ox = p0 - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
+        ktab[e] = koff;
+    }
+    __syncthreads();
+    const int kshift = (ksteps & (ksteps - 1)) == 0 ? __builtin_ctz(ksteps) : -1;
     auto walk = [&](int kt) -> int64_t {   // k-tile kt of this item = sample z_begin + kt / ksteps, k-step kt % ksteps
-        const int zq = kt / ksteps, k0 = (kt - zq * ksteps) * 64;
-        int koff = k0;
-        if (a.conv) { const int p0 = k0 + oct * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2; koff = oy * a.s1 * a.Wq + ox; }
-        return base + static_cast<int64_t>(zq) * a.sample_stride + koff;
+        const int zq = kshift >= 0 ? kt >> kshift : kt / ksteps, ks = kt - zq * ksteps;
+        return base + static_cast<int64_t>(zq) * a.sample_stride + ktab[ks * 8 + oct];
     };
     f32x16 acc[4][2];
 #pragma unroll
@@ -1030,6 +1077,7 @@ inline int cov_engine(int64_t n_rows, int64_t steps) {  // 2 = 128-row tiles / 4
     return ((t3 * (t3 + 1) / 2) * 4 * 100 <= (t2 * (t2 + 1) / 2) * 125 && steps >= 512) ? 3 : 2;
 }
 
+
 int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.tiles = static_cast<int>(cdiv(c.N, 256));
     c.np = c.tiles * 256;
@@ -1042,14 +1090,14 @@ int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.plain_store = zblocks == 1;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
     if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-    hipLaunchKernelGGL(cov_gemm_v3_kernel, grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, c);
+    hipLaunchKernelGGL(cov_gemm_v3_kernel, grid, dim3(pp::THREADS), COV_V3_SMEM, st, c);
     f.stage = c.stage; f.np = c.np; f.tile_shift = 8;
     hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();
 }
 
 int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
-    if (cov_engine(c.N, static_cast<int64_t>(c.batch) * (c.K >> 6)) == 3) return launch_cov_v3(c, f, st);
+    if ((c.K >> 6) <= COV_KTAB_STEPS && cov_engine(c.N, static_cast<int64_t>(c.batch) * (c.K >> 6)) == 3) return launch_cov_v3(c, f, st);
     c.tiles = static_cast<int>(cdiv(c.N, 128));
     c.np = c.tiles * 128;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);
@@ -1086,7 +1134,7 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
