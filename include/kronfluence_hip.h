@@ -86,8 +86,9 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
  *
  * kf_syrk_rows_bf16: C[d,d] += alpha * X'^T X' for the hooked input X [b, T, d_in] (bf16 contiguous) of a Linear layer on
  * sequences -- the same mathematics as kf_syrk_accum (module/linear.py:30-46 + tracker/factor.py:58) with the rows first
- * transposed to [b, d', T] in the workspace, where the 0/1 attention mask (KF_I64 / KF_I32 / KF_U8, nullable, [b*T]) zeroes
- * masked rows including their bias one (linear.py:39-43) and the ones row of the bias column is generated.  Needs T % 64 == 0,
+ * transposed to [b, d', T] in the workspace, where every row and its bias one are multiplied by the integer attention mask
+ * (KF_I64 / KF_I32 / KF_U8, nullable, [b*T]; linear.py:39-43: 0 zeroes the row, 1 keeps it, other weights round the product to
+ * bf16 as the reference's in-place mul_ does) and the ones row of the bias column is generated.  Needs T % 64 == 0,
  * d_in % 8 == 0, b <= 65535; the row counter is the caller's business.
  *
  * kf_conv2d_cov_accum: C[I',I'] += alpha * sum_{n,p} patches[n,p,:]^T patches[n,p,:] with IMPLICIT im2col (replaces

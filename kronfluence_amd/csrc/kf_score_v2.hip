@@ -1070,13 +1070,12 @@ inline int cov_engine(int64_t n_rows, int64_t steps) {  // 2 = 128-row tiles / 4
     if (engine_generation() == 2) return 2;
     const int64_t t2 = cdiv(n_rows, 128), t3 = cdiv(n_rows, 256);
     // MFMA work in 128 x 128 units: the 256-row tiling pads more and computes whole diagonal tiles.  Measured
-    // (profiles/r03_cov_bench.log): its loop runs 1.2-1.5x the rate of the 4-wave kernel when the contraction is long (1600
-    // rows, 4000 k-steps: 1.59 -> 1.32 ms; 2304 rows, 1000 k-steps: 0.63 -> 0.59 ms), but loses when the extra work exceeds a
-    // quarter (1152 rows: +33 %) or the contraction is short (transformer batches of 128 k-steps: the 64 K staging atomics of
-    // a 256 x 256 tile weigh more than its k-loop)
-    return ((t3 * (t3 + 1) / 2) * 4 * 100 <= (t2 * (t2 + 1) / 2) * 125 && steps >= 512) ? 3 : 2;
+    // (profiles/r03_cov_bench.log): its loop runs 1.3-1.5x the rate of the 4-wave kernel when the contraction is long (1600
+    // rows, 4000 k-steps: 1.56 -> 1.20 ms; 1152 rows: 0.70 -> 0.65 ms; 2304 rows, 1000 k-steps: 0.61 -> 0.52 ms), but loses when
+    // the contraction is short (transformer batches of 128 k-steps: the 64 K staging atomics of a 256 x 256 tile weigh more
+    // than its k-loop) or the extra MFMA work exceeds a third
+    return ((t3 * (t3 + 1) / 2) * 4 * 100 <= (t2 * (t2 + 1) / 2) * 134 && steps >= 512) ? 3 : 2;
 }
-
 
 int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.tiles = static_cast<int>(cdiv(c.N, 256));
