@@ -475,6 +475,43 @@ def test_score_gemm_long_k_loops(ops, q, b):
         assert rel(scores, want) <= 1e-5, rel(scores, want)
 
 
+def test_wave_role_split_loop_race_screen(ops):
+    """The round-3 main loop (csrc/kf_pingpong.h) orders its LDS-DMA requests against fragment reads with counted ``vmcnt`` and raw
+    barriers only: a mistake there shows up as RARE wrong tiles.  Screen: the 256 x 256 score GEMM, the bf16-output rotation and
+    the 256-row covariance kernel launched 60 times each on the same operands while another stream keeps HBM busy; every
+    result must match the first launch to fp32 summation-order noise (a stale 64-deep k-tile is >= 1e-4 of the result)."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    q, b, r, o, i = 1000, 1000, 16, 128, 1152
+    p = TiledQueries(_rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV), 0)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    x = _rand(60000, 1152, dtype=torch.bfloat16, seed=3).to(DEV)
+    qt = _rand(1152, 1152, seed=4).to(torch.bfloat16).to(DEV)
+    conv = nn.Conv2d(64, 32, 5, stride=2, padding=2, bias=False)   # I' = 1600: the 256-row covariance kernel
+    xc = _rand(300, 64, 32, 32, dtype=torch.bfloat16, seed=5).to(DEV)
+    geometry = ops.conv2d_cov_geometry(xc, conv)
+    assert geometry is not None
+    noise = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    first = {}
+    for launch in range(60):
+        with torch.cuda.stream(side):  # uneven memory load next to the kernels under test
+            if launch % 3 != 2:
+                noise[: (launch % 5 + 1) << 25].add_(1)
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(scores, 0, p, g, a, False)
+        rotated = ops.rotate_bf16(x, qt).float()
+        cov, cnt = torch.zeros(1600, 1600, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        ops.conv2d_cov_accum(cov, cnt, xc, conv, geometry)
+        for key, value in (("score", scores), ("rotate", rotated), ("cov", cov)):
+            if launch == 0:
+                first[key] = value.clone()
+            else:
+                worst = float((value - first[key]).abs().max() / first[key].abs().max())
+                assert worst <= (0.0 if key == "rotate" else 1e-5), (key, launch, worst)
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("n,d,m,bias", [(40000, 1152, 1152, False), (33000, 1600, 1608, True), (70001, 256, 2304, False)])
 def test_rotate_bf16_tall_products(ops, n, d, m, bias):
     """The rotations ``X Q`` of the Lambda stage at sizes that take the 256 x 256-tile LDS-DMA kernel (>= 512 tiles): ragged last
