@@ -665,6 +665,10 @@ __device__ __forceinline__ void psg_stage(const PsgV2Args& a, const PsgItem& it,
     }
 }
 
+// ROWS: the result is written as plain rows ordered (m, sample) -- the A operand of the dense-form Lambda GEMM
+// (kf_lambda_conv2d_accum) -- instead of k-tile-major for the score GEMM.  Its own instantiation so that the two uses have
+// their own kernel names in a profile.
+template <bool ROWS>
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -724,8 +728,8 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
             const int m = cur.m0 + ml, n = cur.n0 + ch * 8;
             if (m < a.M && n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
                 const int64_t d = static_cast<int64_t>(m) * a.N + n;
-                const int64_t idx = a.out_rows ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
-                                               : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63);
+                const int64_t idx = ROWS ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
+                                         : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63);
                 *reinterpret_cast<u32x4*>(a.out + idx) = *reinterpret_cast<const u32x4*>(ep + ml * 256 + ch * 16);
             }
         }
@@ -1131,7 +1135,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
@@ -1175,7 +1180,8 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
     if (engine_generation() == 3) {
         // persistent: two resident workgroups per CU (64 KB of LDS each), 512 in all, each walking its XCD's item range
         const int64_t grid = std::min<int64_t>(blocks, 512);
-        hipLaunchKernelGGL(psg_gemm_v3_kernel, dim3(static_cast<unsigned>(grid)), dim3(NTHREADS), PV2_SMEM, st, p);
+        if (p.out_rows) hipLaunchKernelGGL(psg_gemm_v3_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(NTHREADS), PV2_SMEM, st, p);
+        else hipLaunchKernelGGL(psg_gemm_v3_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(NTHREADS), PV2_SMEM, st, p);
         return launch_status();
     }
     hipLaunchKernelGGL(psg_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), PV2_SMEM, st, p);

@@ -66,6 +66,7 @@ class ScoreSink:
 # and the dense block is the cheaper way to spend flops; the block is made as large as HBM allows, since every block re-forms
 # the train batch's per-sample gradients.)  Layers with ONE row per sample use the factored contraction, below.
 LOW_RANK_EXPANSION_BYTES = 32 << 30
+LOW_RANK_CACHE_BYTES = 1 << 30  # per layer: only small expansions are kept for the whole train pass (storage is what low rank buys)
 
 
 def unpadded_queries(module, preconditioned):
@@ -183,7 +184,7 @@ class PairwiseScoreTracker(BaseTracker):
         score_dtype = left.dtype if left.dtype == torch.bfloat16 else torch.float32
         q, o, ip = left.shape[0], left.shape[1], right.shape[2]
         per_query = o * ip * 4
-        if q * per_query <= LOW_RANK_EXPANSION_BYTES:
+        if q * per_query <= LOW_RANK_CACHE_BYTES:
             if self._expanded is None or self._expanded[0] is not left:
                 self._expanded = (left, dense_queries(preconditioned, score_dtype))
             yield 0, self._expanded[1]

@@ -8,7 +8,7 @@ import os
 import sys
 from collections import defaultdict
 
-OURS = ("score_gemm_v2", "psg_gemm_v2", "cov_gemm_v2", "cov_finalize", "conv_pad_phases", "transpose_rows", "gemm_bf16_kernel",
+OURS = ("score_gemm_v", "psg_gemm_v", "cov_gemm_v", "rotate_gemm_v", "cov_finalize", "conv_pad_phases", "transpose_rows", "gemm_bf16_kernel",
         "lambda_bf16", "score_r1", "syrk_kernel", "eigh_")
 
 

@@ -45,14 +45,15 @@ def short(name: str) -> str:
     return name.split("(")[0].strip()
 
 
-def score_call_bytes(kernels: dict) -> float:
-    """HBM bytes of all kf_pairwise_score* calls.  The pad / transpose kernels also serve the covariance entry points when the
-    profiled command ran the factor fit: a score call launches exactly one psg_gemm_v2_kernel with one conv_pad_phases_kernel
-    (convolution) or two transpose_rows_kernel (sequence rows), so only that share of their launches is counted."""
-    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG))
+def score_call_bytes(kernels: dict, calls: int) -> float:
+    """HBM bytes of all kf_pairwise_score* calls.  A score call launches exactly one per-sample-gradient kernel
+    (``psg_gemm_v3_kernel<false>`` / ``psg_gemm_v2_kernel``; the ``<true>`` instantiation belongs to the dense-form Lambda) with
+    one conv_pad_phases_kernel (convolution) or two transpose_rows_kernel (sequence rows) -- kernels that also serve the
+    covariance / Lambda entry points when the profiled command ran the factor fit, so only that share of their launches counts."""
+    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG) and "<true>" not in n)
     total = 0.0
     for n, e in kernels.items():
-        if not n.startswith(SCORE_KERNELS):
+        if not n.startswith(SCORE_KERNELS) or (n.startswith(PSG) and "<true>" in n):
             continue
         share = 1.0
         if n.startswith("conv_pad_phases_kernel"):
@@ -68,7 +69,7 @@ def main() -> None:
         with open(sys.argv[2], encoding="utf-8") as handle:
             summary = json.load(handle)
         calls = summary["kf_pairwise_score_calls_profiled"]
-        summary["kf_pairwise_score_bytes_per_launch"] = score_call_bytes(summary["kernels"]) / calls if calls else None
+        summary["kf_pairwise_score_bytes_per_launch"] = score_call_bytes(summary["kernels"], calls) / calls if calls else None
         with open(sys.argv[2], "w", encoding="utf-8") as handle:
             json.dump(summary, handle, indent=1)
         print(summary["kf_pairwise_score_bytes_per_launch"])
@@ -97,7 +98,7 @@ def main() -> None:
         kernels[name] = entry
     # one kf_pairwise_score* call = its pad / transpose / gradient kernels + one score GEMM (or one score_r1 launch)
     calls = sum(e["launches"] for n, e in kernels.items() if n.startswith(SCORE_GEMM) or n.startswith("score_r1_kernel"))
-    total = score_call_bytes(kernels)
+    total = score_call_bytes(kernels, calls)
     dominant = max((e for n, e in kernels.items() if n.startswith(SCORE_GEMM)), key=lambda e: e["launches"], default=None)
     cov = max((e for n, e in kernels.items() if n.startswith(COV_GEMM)), key=lambda e: e["launches"], default=None)
     summary = {
