@@ -17,18 +17,21 @@ Workloads (synthetic random-weight models of the BASELINE.json layer shapes, SUR
              CIFAR-10 ResNet-9 (Conv2d tracked), 50 000 train x 1 000 query, bf16 autocast, bf16 query gradients
   mnist_mlp  configs[0]: 784-1024-1024-1024-10 MLP, 1 000 train x 100 query, fp32, damping 1e-8
   bert_base  configs[2]: 12-layer BERT-base-shaped encoder + pooler + 2-way head (74 tracked Linears, D = 85.6 M),
-             T = 128 with random-length padding masks, 872 queries, fp32 factors / bf16 gradients; the train set is
-             scaled (default 8 192 of 67 349 sequences; ``--n-train`` overrides)
-  gpt2_small configs[3]: GPT-2-small-shaped decoder (48 tracked block Linears with bias, T = 512, D = 85.0 M), bf16;
-             scaled to 2 048 train x 1 024 query sequences by default
+             T = 128 with random-length padding masks, 872 queries, fp32 factors / bf16 gradients (``--workload bert_base``
+             alone defaults to 8 192 of the 67 349 train sequences; ``--n-train`` overrides)
+  gpt2_small configs[3]: GPT-2-small-shaped decoder (48 tracked block Linears with bias, T = 512, D = 85.0 M), bf16 incl. the
+             covariances (the reference's all-low-precision preset); 2 048 train x 1 024 query sequences by default
 
-With N = 1 and the default workload the same JSON line also carries ``targets.mnist_mlp`` (the north-star target:
-GPU pairs/s, CPU-oracle pairs/s on the SAME full workload, their ratio and the GPU-vs-oracle score error at damping
-1e-8) and ``other_configs`` (bert_base and gpt2_small at bounded sizes, one timed step each) measured in the same run.
+With the default workload the same JSON line also carries ``targets.mnist_mlp`` (N = 1; the north-star target: GPU pairs/s,
+CPU-oracle pairs/s on the SAME full workload, their ratio and the GPU-vs-oracle score error at damping 1e-8) and
+``other_configs``, one timed step each, measured in the same run: N = 1 -- bert_base at its FULL 67 349 x 872 and gpt2_small at
+16 384 x 1 024 (factors fitted on a bounded prefix, ``factor_fit.n_fit``); N > 1 -- gpt2_small, the config the north-star
+scaling target is stated on, sharded like the headline.  ``python bench.py --gpus N`` typed without a launcher re-executes itself
+under ``torch.distributed.run`` (one rank per GPU, RCCL) and the line then carries ``exchanges``.
 
-``roofline`` times the dominant kernel calls (the pairwise-score contraction ``kf_pairwise_score``) with HIP events on
-the launch stream inside the timed region; ``roofline_cov`` / ``roofline_lambda`` do the same for ``kf_syrk_accum`` and
-``kf_lambda_accum`` during the factor fit; ``cpu_baseline`` times the CPU oracle (``oracle/ekfac_ref.py``) on a bounded
+``roofline`` times the dominant kernel calls (the pairwise-score contraction ``kf_pairwise_score*``) with HIP events on
+the launch stream inside the timed region; ``roofline_cov`` / ``roofline_lambda`` / ``roofline_lambda_update`` do the same for the
+covariance calls, the Lambda kernels and the whole Lambda update of a hook during the factor fit; ``cpu_baseline`` times the CPU oracle (``oracle/ekfac_ref.py``) on a bounded
 sample of the same workload on this box's host cores (rank 0, N = 1 only).
 """
 
