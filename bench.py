@@ -545,6 +545,15 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     elapsed = time.perf_counter() - t0
     new_segments = torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0
     gc.enable()
+    if os.environ.get("KF_BENCH_PROFILE") and rank == 0:
+        # diagnostics only (outside the timed region): one more step under the torch profiler, per-kernel device totals to a file
+        from torch.profiler import ProfilerActivity, profile
+        count = int(os.environ.get("KF_BENCH_PROFILE_TRAIN", n_train))
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            step(min(count, n_train))
+            torch.cuda.synchronize()
+        with open(os.environ["KF_BENCH_PROFILE"], "w") as fh:
+            fh.write(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=90))
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -606,136 +606,202 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
 // k-step of an item is being multiplied, the first k-step of the next item is already on its way, and it lands during the
 // bf16 epilogue.  In the v2 kernel every item (1-16 k-steps: K = R = 64 .. 1024) paid a full DMA round trip before its first
 // MFMA and there was one workgroup launch per item.  The epilogue stages its bf16 tile in the stage buffer that was consumed
-// last (128 rows x 256 B = 32 KB exactly), so LDS stays at 64 KB and two workgroups share a CU as before.
+// last (128 rows x 256 B = 32 KB exactly), so two workgroups share a CU as before.
+//
+// An item is only 16-64 MFMAs per wave, so what the wave executes AROUND them decides the rate (the first persistent version
+// issued ~1 800 vector instructions per item -- per-row divisions of the implicit-im2col decode, 64 two-byte LDS stores,
+// 64-bit index arithmetic -- and its matrix pipe was busy 11 % of the time).  Now:
+//   * everything about a DMA source that does not depend on the sample lives in an LDS table built once per workgroup
+//     (`rowtab`: implicit-im2col row -> element offset into the phase copies), next to the per-k-step position table; an item's
+//     decode is two scalar divisions, 8 table lookups and 8 adds, its sample base is wave-uniform (SGPR pair);
+//   * the accumulators are TRANSPOSED (MFMA rows run along i, the contiguous direction of the result), so a lane owns four
+//     consecutive bf16 of a result row: 16 packed 8-byte LDS stores per lane instead of 64 two-byte ones;
+//   * the first k-step accumulates onto an inline zero instead of 64 cleared registers, and the 16-byte global stores of an
+//     item step by one 64-bit stride.
 // ------------------------------------------------------------------------------------------------
+constexpr int PV2_ROWTAB_MAX = 3072;   // implicit-im2col rows the row table holds: 2 x (66 + 12) KB of LDS = two workgroups per CU
+constexpr int PV3_SMEM_MAX = PV2_SMEM + PV2_ROWTAB_MAX * 4;
+
+// sample-independent part of the DMA source of implicit-im2col row i = shift * C + c: element offset into the phase copies
+__device__ __forceinline__ int conv_row_offset(const PsgV2Args& a, int i) {
+    const int shift = i / a.C, c = i - shift * a.C;
+    const int ky = shift / a.k2, kx = shift - ky * a.k2;
+    const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
+    return static_cast<int>(phase * a.phase_stride) + c * a.plane + ky * a.d1 * a.Wq + coff;
+}
+
 struct PsgItem {
-    const uint16_t* src_a[4];
-    const uint16_t* src_b[4];
-    int oct[4];
+    const uint16_t* pa;   // sample bases (wave-uniform)
+    const uint16_t* pb;
+    int off_a[4], off_b[4];
     int m0, n0, z;
 };
 
-__device__ __forceinline__ bool psg_decode(const PsgV2Args& a, int64_t item, int64_t items, int wave, int lane, PsgItem& it) {
-    constexpr int PSG_ZB = 8;
-    const int tiles = a.tiles_m * a.tiles_n;
-    if (item >= items) return false;
-    const int64_t zb = item / (static_cast<int64_t>(tiles) * PSG_ZB);
-    const int rem = static_cast<int>(item - zb * tiles * PSG_ZB);
-    const int tile = rem / PSG_ZB;
-    it.z = static_cast<int>(zb) * PSG_ZB + rem % PSG_ZB;
-    if (it.z >= a.batch) return false;   // padding sample of the last block of 8: the caller moves on to its next item
-    it.m0 = (tile / a.tiles_n) * 128;
-    it.n0 = (tile % a.tiles_n) * 128;
+// One 64-deep k-step with the operands swapped: accumulator rows run along the B image (i), columns along the A image (m).
+// ZERO: the first k-step of an item accumulates onto an inline 0.
+template <bool ZERO>
+__device__ __forceinline__ void wave_kstep_transposed(f32x16 (&acc)[2][2], const unsigned char* sa, const unsigned char* sb, int hi, int sw) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const int row = (wave * 4 + t) * 8 + (lane >> 3);
-        it.oct[t] = (lane & 7) ^ lds_swz(row);
-        const int m = min(it.m0 + row, a.M - 1);
-        it.src_a[t] = a.A + static_cast<int64_t>(it.z) * a.a_sample_stride + static_cast<int64_t>(m) * a.K + it.oct[t] * 8;
-        const int i = min(it.n0 + row, a.N - 1);
-        if (a.conv) {
-            const int shift = i / a.C, c = i - shift * a.C;
-            const int ky = shift / a.k2, kx = shift - ky * a.k2;
-            const int col = kx * a.d2, phase = col % a.s2, coff = col / a.s2;
-            it.src_b[t] = a.B + phase * a.phase_stride + static_cast<int64_t>(it.z) * a.b_sample_stride +
-                          static_cast<int64_t>(c) * a.plane + ky * a.d1 * a.Wq + coff;
+    for (int kk = 0; kk < 4; ++kk) {
+        const int co = ((kk * 2 + hi) ^ sw) * 16;
+        const bf16x8 a0 = *reinterpret_cast<const bf16x8*>(sa + co);
+        const bf16x8 a1 = *reinterpret_cast<const bf16x8*>(sa + 32 * 128 + co);
+        const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(sb + co);
+        const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(sb + 32 * 128 + co);
+        if (ZERO && kk == 0) {
+            const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, zero, 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, zero, 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, zero, 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, zero, 0, 0, 0);
         } else {
-            it.src_b[t] = a.B + static_cast<int64_t>(it.z) * a.b_sample_stride + static_cast<int64_t>(i) * a.K + it.oct[t] * 8;
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b0, a1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b1, a1, acc[1][1], 0, 0, 0);
         }
     }
-    return true;
 }
 
-__device__ __forceinline__ void psg_stage(const PsgV2Args& a, const PsgItem& it, unsigned char* sm, int buf, int k0, int wave,
-                                          const int* ktab) {
-    unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) glds16(it.src_a[t] + k0, base + t * 1024);
-    if (a.conv) {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            int off;
-            if (ktab) off = ktab[(k0 >> 6) * 8 + it.oct[t]];
-            else { const int p0 = k0 + it.oct[t] * 8, oy = p0 / a.O2, ox = p0 - oy * a.O2; off = oy * a.s1 * a.Wq + ox; }
-            glds16(it.src_b[t] + off, base + PV2_OPERAND_BYTES + t * 1024);
-        }
-    } else {
-#pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(it.src_b[t] + k0, base + PV2_OPERAND_BYTES + t * 1024);
-    }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 v = __builtin_convertvector(f32x2{lo, hi}, bf16x2);
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // ROWS: the result is written as plain rows ordered (m, sample) -- the A operand of the dense-form Lambda GEMM
 // (kf_lambda_conv2d_accum) -- instead of k-tile-major for the score GEMM.  Its own instantiation so that the two uses have
 // their own kernel names in a profile.
+//
+// Work order: groups of (block of 8 consecutive samples, tile), block-major; XCD x owns a contiguous range of groups, its
+// workgroup j serves sample j % 8 of the groups j / 8, j / 8 + gridDim / 64, ...  The workgroups running together on an XCD
+// then cover a few samples x all their tiles -- the samples' inputs stay in that XCD's L2 across their tiles -- and the 8
+// samples of one tile write ADJACENT 128-byte pieces of the k-tile-major gradient buffer.
 template <bool ROWS>
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     constexpr int PSG_ZB = 8;
     const int tiles = a.tiles_m * a.tiles_n;
-    const int64_t zblocks = (a.batch + PSG_ZB - 1) / PSG_ZB;
-    const int64_t items = zblocks * PSG_ZB * tiles, per_xcd = (items + 7) / 8;
-    // workgroup L serves XCD L % 8: items xcd * per_xcd + j for j = L / 8, L / 8 + gridDim / 8, ...
-    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
-    const int64_t first = static_cast<int64_t>(xcd) * per_xcd, last = min(items, first + per_xcd);
-    int64_t item = first + (blockIdx.x >> 3);
-    PsgItem cur, nxt;
-    while (item < last && !psg_decode(a, item, items, wave, lane, cur)) item += stride;   // (workgroup-uniform)
-    bool have = item < last;
-    if (!have) return;
-    const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
-    const int* ktab = nullptr;
-    if (a.conv && (a.K >> 6) <= PV2_KTAB_STEPS) {
-        ktab = conv_offset_table(a, sm, a.K, NTHREADS);
+    const int groups = ((a.batch + PSG_ZB - 1) / PSG_ZB) * tiles, per_xcd = (groups + 7) / 8;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3, zsub = j & 7, gstride = gridDim.x >> 6;
+    const int last = min(groups, (xcd + 1) * per_xcd);
+    int group = xcd * per_xcd + (j >> 3);
+
+    int* ktab = reinterpret_cast<int*>(sm + 2 * PV2_STAGE_BYTES);
+    int* rowtab = ktab + PV2_KTAB_STEPS * 8;
+    const bool k_table = a.conv && (a.K >> 6) <= PV2_KTAB_STEPS, row_table = a.conv && a.N <= PV2_ROWTAB_MAX;
+    if (a.conv) {
+        if (k_table) conv_offset_table(a, sm, a.K, NTHREADS);
+        if (row_table)
+            for (int i = tid; i < a.N; i += NTHREADS) rowtab[i] = conv_row_offset(a, i);
         __syncthreads();
     }
-    psg_stage(a, cur, sm, 0, 0, wave, ktab);
+    // this thread's four DMA rows of an operand tile and the k-octet it fetches of each (item independent)
+    int row[4], oct8[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        row[t] = (wave * 4 + t) * 8 + (lane >> 3);
+        oct8[t] = ((lane & 7) ^ lds_swz(row[t])) * 8;
+    }
+    auto decode = [&](int g, PsgItem& it) -> bool {   // (wave-uniform result)
+        if (g >= last) return false;
+        const int zb = g / tiles, tile = g - zb * tiles;
+        it.z = zb * PSG_ZB + zsub;
+        if (it.z >= a.batch) return false;   // padding sample of the last block of 8: nothing follows for this workgroup
+        const int tm = tile / a.tiles_n;
+        it.m0 = tm * 128;
+        it.n0 = (tile - tm * a.tiles_n) * 128;
+        it.pa = a.A + static_cast<int64_t>(it.z) * a.a_sample_stride;
+        it.pb = a.B + static_cast<int64_t>(it.z) * a.b_sample_stride;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            it.off_a[t] = min(it.m0 + row[t], a.M - 1) * a.K + oct8[t];
+            const int i = min(it.n0 + row[t], a.N - 1);
+            it.off_b[t] = !a.conv ? i * a.K + oct8[t] : row_table ? rowtab[i] : conv_row_offset(a, i);
+        }
+        return true;
+    };
+    auto stage = [&](const PsgItem& it, int buf, int k0) {
+        unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) glds16(it.pa + (it.off_a[t] + k0), base + t * 1024);
+        if (a.conv) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                int off;
+                if (k_table) off = ktab[(k0 >> 3) + (oct8[t] >> 3)];
+                else { const int p0 = k0 + oct8[t], oy = p0 / a.O2, ox = p0 - oy * a.O2; off = oy * a.s1 * a.Wq + ox; }
+                glds16(it.pb + (it.off_b[t] + off), base + PV2_OPERAND_BYTES + t * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) glds16(it.pb + (it.off_b[t] + k0), base + PV2_OPERAND_BYTES + t * 1024);
+        }
+    };
+
+    PsgItem cur, nxt;
+    bool have = decode(group, cur);
+    if (!have) return;
+    const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
+    // epilogue constants: the lane's LDS positions (transposed accumulators) and its 16-byte piece of a result row
+    const int er = tid >> 4, ech = tid & 15;   // row (+ 16 per pass) and 16-byte chunk this thread copies out
+    const int64_t out_step = ROWS ? static_cast<int64_t>(16) * a.batch * a.N : static_cast<int64_t>(a.N >> 2) * a.out_tile_stride;
+    stage(cur, 0, 0);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
     int buf = 0;
     while (have) {
-        int64_t next_item = item + stride;
-        while (next_item < last && !psg_decode(a, next_item, items, wave, lane, nxt)) next_item += stride;
-        const bool have_next = next_item < last;
+        group += gstride;
+        const bool have_next = decode(group, nxt);
         f32x16 acc[2][2];
-        zero_acc(acc);
         for (int k0 = 0; k0 < a.K; k0 += 64) {
-            if (k0 + 64 < a.K) psg_stage(a, cur, sm, buf ^ 1, k0 + 64, wave, ktab);
-            else if (have_next) psg_stage(a, nxt, sm, buf ^ 1, 0, wave, ktab);   // the next item's first k-step rides behind this one
+            if (k0 + 64 < a.K) stage(cur, buf ^ 1, k0 + 64);
+            else if (have_next) stage(nxt, buf ^ 1, 0);   // the next item's first k-step rides behind this one
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
-            wave_kstep_64x64(acc, sa, sb, hi, sw);
+            if (k0 == 0) wave_kstep_transposed<true>(acc, sa, sb, hi, sw);
+            else wave_kstep_transposed<false>(acc, sa, sb, hi, sw);
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             buf ^= 1;
         }
-        // `buf` now holds the next item's first k-step (landed); `buf ^ 1` was consumed last and stages the bf16 tile
+        // `buf` now holds the next item's first k-step (landed); `buf ^ 1` was consumed last and stages the bf16 tile:
+        // row m (256 B), 16-byte chunk c of it at chunk position c ^ (m & 15)
         unsigned char* ep = sm + (buf ^ 1) * PV2_STAGE_BYTES;
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-            for (int tj = 0; tj < 2; ++tj)
+            for (int tj = 0; tj < 2; ++tj) {
+                const int ml = wm * 64 + tj * 32 + lr;
+                unsigned char* dst = ep + ml * 256 + hi * 8;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = acc_row(wm, ti, r, lane), nl = acc_col(wn, tj, lane);
-                    *reinterpret_cast<__bf16*>(ep + ml * 256 + nl * 2) = static_cast<__bf16>(acc[ti][tj][r]);
+                for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3: columns i = 8 q + 4 hi + (0 .. 3) of the block
+                    const int c = wn * 8 + ti * 4 + q;
+                    uint2 w;
+                    w.x = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
+                    w.y = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
+                    *reinterpret_cast<uint2*>(dst + ((c ^ (ml & 15)) << 4)) = w;
                 }
+            }
         __syncthreads();
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int id = tid + 256 * it, ml = id >> 4, ch = id & 15;
-            const int m = cur.m0 + ml, n = cur.n0 + ch * 8;
-            if (m < a.M && n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
+        {
+            const int m = cur.m0 + er, n = cur.n0 + ech * 8;
+            if (n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
                 const int64_t d = static_cast<int64_t>(m) * a.N + n;
-                const int64_t idx = ROWS ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
-                                         : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63);
-                *reinterpret_cast<u32x4*>(a.out + idx) = *reinterpret_cast<const u32x4*>(ep + ml * 256 + ch * 16);
+                // 16 rows further: d grows by 16 N, a multiple of 64 -> the same place in a k-tile, N / 4 k-tiles on
+                uint16_t* dst = a.out + (ROWS ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
+                                              : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63));
+                const unsigned char* src = ep + er * 256 + ((ech ^ (er & 15)) << 4);
+#pragma unroll
+                for (int it = 0; it < 8; ++it)
+                    if (m + 16 * it < a.M)
+                        *reinterpret_cast<u32x4*>(dst + it * out_step) = *reinterpret_cast<const u32x4*>(src + it * 4096);
             }
         }
         __syncthreads();   // the staging buffer is free again before the next k-step's DMA is issued into it
         cur = nxt;
-        item = next_item;
         have = have_next;
     }
 }
@@ -1085,10 +1151,16 @@ int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.tiles = static_cast<int>(cdiv(c.N, 256));
     c.np = c.tiles * 256;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);
-    // one workgroup per CU (128 KB of LDS): about two rounds of items, each at least 16 k-tiles long
-    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(512, pairs), steps / 16}));
-    c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
-    const int64_t zblocks = cdiv(c.batch, c.zchunk);
+    // One workgroup per CU (128 KB of LDS), so the items run in rounds of 256: split the samples so that the LAST round is
+    // (nearly) full too -- 45 tile pairs x 12 sample blocks = 540 items ran as three rounds, the third 11 % full; 45 x 11 = 495
+    // are two.  Among 1-4 rounds take the cheapest by (k-tiles per item + a prologue / staging-atomics charge of ~12 k-tiles).
+    int64_t zblocks = 1, best = INT64_MAX;
+    for (int rounds = 1; rounds <= 4; ++rounds) {
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), rounds * 256 / pairs, steps / 16}));
+        const int64_t chunk = cdiv(c.batch, want), blocks = cdiv(c.batch, chunk);
+        const int64_t cost = cdiv(blocks * pairs, 256) * (chunk * (c.K >> 6) + 12);
+        if (cost < best) { best = cost; zblocks = blocks; c.zchunk = static_cast<int>(chunk); }
+    }
     c.zblocks = static_cast<int>(zblocks);
     c.plain_store = zblocks == 1;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
@@ -1135,8 +1207,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
@@ -1177,11 +1249,17 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
     p.tiles_m = static_cast<int>(cdiv(p.M, 128)); p.tiles_n = static_cast<int>(cdiv(p.N, 128));
     const int64_t blocks = 8 * cdiv(cdiv(p.batch, 8) * 8 * p.tiles_m * p.tiles_n, 8);  // PSG_ZB = 8 samples per block
     if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
-    if (engine_generation() == 3) {
-        // persistent: two resident workgroups per CU (64 KB of LDS each), 512 in all, each walking its XCD's item range
-        const int64_t grid = std::min<int64_t>(blocks, 512);
-        if (p.out_rows) hipLaunchKernelGGL(psg_gemm_v3_kernel<true>, dim3(static_cast<unsigned>(grid)), dim3(NTHREADS), PV2_SMEM, st, p);
-        else hipLaunchKernelGGL(psg_gemm_v3_kernel<false>, dim3(static_cast<unsigned>(grid)), dim3(NTHREADS), PV2_SMEM, st, p);
+    // the persistent kernel keeps per-lane source offsets in 32 bits (the sample base is a 64-bit scalar)
+    const int64_t span_a = static_cast<int64_t>(p.M) * p.K + 64;
+    const int64_t span_b = p.conv ? static_cast<int64_t>(p.s2) * p.phase_stride + p.plane : static_cast<int64_t>(p.N) * p.K + 64;
+    if (engine_generation() == 3 && span_a < (1LL << 31) && span_b < (1LL << 31)) {
+        // persistent: two resident workgroups per CU (64 KB of LDS each + tables), 512 in all = 64 per XCD, each walking its
+        // XCD's range of (8-sample block, tile) groups; fewer when there are fewer than 8 groups per XCD
+        const int64_t groups = cdiv(p.batch, 8) * p.tiles_m * p.tiles_n;
+        const unsigned grid = 64u * static_cast<unsigned>(std::min<int64_t>(8, cdiv(groups, 8)));
+        const size_t smem = PV2_SMEM + ((p.conv && p.N <= PV2_ROWTAB_MAX) ? static_cast<size_t>((p.N + 3) / 4 * 16) : 0);
+        if (p.out_rows) hipLaunchKernelGGL(psg_gemm_v3_kernel<true>, dim3(grid), dim3(NTHREADS), smem, st, p);
+        else hipLaunchKernelGGL(psg_gemm_v3_kernel<false>, dim3(grid), dim3(NTHREADS), smem, st, p);
         return launch_status();
     }
     hipLaunchKernelGGL(psg_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), PV2_SMEM, st, p);

@@ -118,6 +118,25 @@ def main():
             line += f" engine{gen} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s |"
         d = float((outs[3] - outs[2]).norm() / outs[2].norm())
         print(f"{line} rel diff {d:.1e}{'' if d < 1e-4 else '   <-- MISMATCH'}", flush=True)
+    print("== transformer score entry point (kf_pairwise_score_rows: transposes + per-sample gradients + score GEMM)")
+    for name, q, b, t_len, o, i in [("bert 768x769 T=128 b=512", 872, 512, 128, 768, 768), ("bert 3072x769 T=128 b=512", 872, 512, 128, 3072, 768),
+                                    ("gpt2 768x769 T=512 b=128", 1024, 128, 512, 768, 768), ("gpt2 768x3073 T=512 b=128", 1024, 128, 512, 768, 3072)]:
+        ipp = (i + 1 + 7) // 8 * 8
+        g = torch.randn(b, t_len, o, device=DEV).bfloat16()
+        a = torch.randn(b, t_len, i, device=DEV).bfloat16()
+        tiled = TiledQueries(torch.randn(q, o, ipp, device=DEV).bfloat16(), 0)
+        flops = 2.0 * q * b * o * (i + 1) + 2.0 * b * t_len * o * (i + 1)
+        line, outs = f"  {name:28s}", {}
+        for gen in (2, 3):
+            engine(gen)
+            s = torch.zeros(q, b, device=DEV)
+            t = timed(lambda: ops.pairwise_score_rows(s, 0, tiled, g, a, True), 5)
+            s.zero_()
+            ops.pairwise_score_rows(s, 0, tiled, g, a, True)
+            outs[gen] = s
+            line += f" engine{gen} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s |"
+        d = float((outs[3] - outs[2]).norm() / outs[2].norm())
+        print(f"{line} rel diff {d:.1e}{'' if d < 1e-4 else '   <-- MISMATCH'}", flush=True)
     engine(3)
 
     print("== Lambda of a conv layer: factored form (im2col + 2 rotations + kf_lambda_accum) vs dense form (kf_lambda_conv2d_accum)")
