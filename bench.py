@@ -549,11 +549,25 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         # diagnostics only (outside the timed region): one more step under the torch profiler, per-kernel device totals to a file
         from torch.profiler import ProfilerActivity, profile
         count = int(os.environ.get("KF_BENCH_PROFILE_TRAIN", n_train))
-        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+        stacks = os.environ.get("KF_BENCH_PROFILE_STACKS") == "1"
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=stacks, record_shapes=stacks) as prof:
             step(min(count, n_train))
             torch.cuda.synchronize()
         with open(os.environ["KF_BENCH_PROFILE"], "w") as fh:
             fh.write(prof.key_averages().table(sort_by="cuda_time_total", row_limit=70, max_name_column_width=90))
+            if stacks:  # who copies: the copy-like operators by input shape and by Python call site
+                copies = ("aten::copy_", "aten::clone", "aten::contiguous", "aten::_to_copy", "aten::pad", "aten::cat")
+                rows = [e for e in prof.key_averages(group_by_input_shape=True) if e.key in copies]
+                rows.sort(key=lambda e: -e.device_time_total)
+                fh.write("\n\n== copy-like operators by input shape (device us, calls)\n")
+                for e in rows[:40]:
+                    fh.write(f"{e.key:18s} {e.device_time_total:10.0f} {e.count:6d}  {e.input_shapes}\n")
+                rows = [e for e in prof.key_averages(group_by_stack_n=12) if e.key in copies]
+                rows.sort(key=lambda e: -e.device_time_total)
+                fh.write("\n== copy-like operators by call site (device us, calls)\n")
+                for e in rows[:25]:
+                    frames = [f for f in e.stack if "site-packages/torch" not in f and "<built-in" not in f][:5]
+                    fh.write(f"{e.key:18s} {e.device_time_total:10.0f} {e.count:6d}\n    " + "\n    ".join(frames) + "\n")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -20,6 +20,12 @@ namespace kf {
 int score_gemm_tiled(float* scores, int64_t ld, const void* P, const void* psg, int64_t Q, int64_t b, int64_t D, float scale, void* stream);
 int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                    float alpha, const float* row_add, int row_add_n, void* stream);
+// kf_precondition's bf16 path on the round-3 engines (kf_score_v2.hip)
+int64_t precondition_v3_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t W);
+bool precondition_v3_eligible(int64_t q, int64_t R, int64_t O, int64_t I, int64_t W);
+int precondition_v3(void* Pout, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg,
+                    const float* Qa, int64_t Ip, const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16,
+                    const void* QaT_bf16, int64_t W, void* workspace, void* stream);
 }
 
 namespace {
@@ -1026,7 +1032,8 @@ int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t
     // Gt, At, T and (for low-precision outputs) the fp32 staging copy of the rotated gradient; I' rounded up to the
     // padded width the bf16 path may use
     const int64_t Ipp = (Ip + 7) / 8 * 8;
-    return static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ipp + 2 * q * O * Ipp) + 1024;
+    const int64_t staged = static_cast<int64_t>(sizeof(float)) * (q * R * O + q * R * Ipp + 2 * q * O * Ipp) + 1024;
+    return std::max(staged, precondition_v3_workspace_bytes(q, R, O, Ipp));
 }
 
 int kf_precondition(void* Pout, int out_dtype, int64_t ldp, const void* G, const void* A, int in_dtype, int64_t q, int64_t R, int64_t O,
@@ -1050,6 +1057,8 @@ int kf_precondition(void* Pout, int out_dtype, int64_t ldp, const void* G, const
                      ((reinterpret_cast<uintptr_t>(Qa_bf16) | reinterpret_cast<uintptr_t>(QgT_bf16) | reinterpret_cast<uintptr_t>(QaT_bf16) |
                        reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Pout)) & 15) == 0;
     int rc;
+    if (low && ldq == (Ip + 7) / 8 * 8 && precondition_v3_eligible(q, R, O, I, ldq))
+        return precondition_v3(Pout, G, A, q, R, O, I, append_ones, Qg, Qa, Ip, inv_lambda, scale, Qa_bf16, QgT_bf16, QaT_bf16, ldq, workspace, stream);
     if (low) {
         const int64_t W = ldq;
         uint16_t* Gt16 = reinterpret_cast<uint16_t*>(workspace);   // [q R, O]

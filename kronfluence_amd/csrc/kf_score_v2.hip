@@ -462,6 +462,10 @@ struct PsgV2Args {
     const uint16_t* B; int64_t b_sample_stride; // plain: [batch][N][K]; conv: [phase][batch][C][Hp][Wq]
     int M, N, K;                                // K % 64 == 0
     int batch, tiles_m, tiles_n;
+    int n_begin;                                // columns [n_begin, N) are produced (n_begin % 128 == 0; the 256 x 256 kernel owns the rest)
+    // out_rows == 2 ("plain"): element (n, m, i) at (n * M + m) * N + i, times mul[m * ld_mul + i] for i < mul_n and 0 beyond --
+    // the eigenbasis gradient of a query times 1 / (lambda + damping) (kf_precondition)
+    const float* mul; int ld_mul, mul_n;
     // implicit im2col (conv != 0): row i = shift * C + c, shift = ky * k2 + kx;  k = oy * O2 + ox (O2 % 8 == 0);
     // element = Xs[(kx * d2) % s2][n][c][s1 * oy + ky * d1][ox + (kx * d2) / s2]
     int conv, C, k2, O2, s1, d1, s2, d2, Wq, plane /* Hp * Wq */;
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
     const int rem = static_cast<int>(item - zb * tiles * PSG_ZB);
     const int tile = rem / PSG_ZB, z = static_cast<int>(zb) * PSG_ZB + rem % PSG_ZB;
     if (z >= a.batch) return;
-    const int m0 = (tile / a.tiles_n) * 128, n0 = (tile % a.tiles_n) * 128;
+    const int m0 = (tile / a.tiles_n) * 128, n0 = a.n_begin + (tile % a.tiles_n) * 128;
 
     // per-lane DMA sources: 4 row groups of each operand per wave; the k-octet this lane fetches is chunk_src
     const uint16_t* src_a[4];
@@ -630,11 +634,13 @@ __device__ __forceinline__ int conv_row_offset(const PsgV2Args& a, int i) {
     return static_cast<int>(phase * a.phase_stride) + c * a.plane + ky * a.d1 * a.Wq + coff;
 }
 
-struct PsgItem {
-    const uint16_t* pa;   // sample bases (wave-uniform)
+struct PsgItem {   // (wave-uniform)
+    const uint16_t* pa;   // sample bases
     const uint16_t* pb;
-    int off_a[4], off_b[4];
     int m0, n0, z;
+};
+struct PsgLaneOffsets {   // element offsets of this lane's 4 + 4 DMA requests of an item, k-step 0
+    int a[4], b[4];
 };
 
 // One 64-deep k-step with the operands swapped: accumulator rows run along the B image (i), columns along the A image (m).
@@ -678,8 +684,9 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // workgroup j serves sample j % 8 of the groups j / 8, j / 8 + gridDim / 64, ...  The workgroups running together on an XCD
 // then cover a few samples x all their tiles -- the samples' inputs stay in that XCD's L2 across their tiles -- and the 8
 // samples of one tile write ADJACENT 128-byte pieces of the k-tile-major gradient buffer.
-template <bool ROWS>
+template <int OUT>   // 0: k-tile-major (score GEMM operand), 1: rows ordered (m, sample), 2: plain per sample, times `mul`
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
+    constexpr bool ROWS = OUT == 1, PLAIN = OUT == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
     constexpr int PSG_ZB = 8;
@@ -698,7 +705,10 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
             for (int i = tid; i < a.N; i += NTHREADS) rowtab[i] = conv_row_offset(a, i);
         __syncthreads();
     }
-    // this thread's four DMA rows of an operand tile and the k-octet it fetches of each (item independent)
+    // this thread's four DMA rows of an operand tile and the k-octet it fetches of each (item independent).
+    // (Specialising the waves by traffic -- waves 0-1 issue all 16 DMA requests of a k-step and never store, waves 2-3 issue all
+    // stores and never wait on vmcnt, so that no wave waits for its own stores at the next "DMA landed" -- was measured: 6-11 %
+    // SLOWER on every shape, profiles/r03_psg_wave_roles_negative.log.)
     int row[4], oct8[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -712,32 +722,35 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
         if (it.z >= a.batch) return false;   // padding sample of the last block of 8: nothing follows for this workgroup
         const int tm = tile / a.tiles_n;
         it.m0 = tm * 128;
-        it.n0 = (tile - tm * a.tiles_n) * 128;
+        it.n0 = a.n_begin + (tile - tm * a.tiles_n) * 128;
         it.pa = a.A + static_cast<int64_t>(it.z) * a.a_sample_stride;
         it.pb = a.B + static_cast<int64_t>(it.z) * a.b_sample_stride;
+        return true;
+    };
+    PsgLaneOffsets off;   // of the item whose DMA is being issued (the current one, from its last k-step on the next one)
+    auto lane_offsets = [&](const PsgItem& it) {
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            it.off_a[t] = min(it.m0 + row[t], a.M - 1) * a.K + oct8[t];
+            off.a[t] = min(it.m0 + row[t], a.M - 1) * a.K + oct8[t];
             const int i = min(it.n0 + row[t], a.N - 1);
-            it.off_b[t] = !a.conv ? i * a.K + oct8[t] : row_table ? rowtab[i] : conv_row_offset(a, i);
+            off.b[t] = !a.conv ? i * a.K + oct8[t] : row_table ? rowtab[i] : conv_row_offset(a, i);
         }
-        return true;
     };
     auto stage = [&](const PsgItem& it, int buf, int k0) {
         unsigned char* base = sm + buf * PV2_STAGE_BYTES + wave * 4096;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) glds16(it.pa + (it.off_a[t] + k0), base + t * 1024);
+        for (int t = 0; t < 4; ++t) glds16(it.pa + (off.a[t] + k0), base + t * 1024);
         if (a.conv) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                int off;
-                if (k_table) off = ktab[(k0 >> 3) + (oct8[t] >> 3)];
-                else { const int p0 = k0 + oct8[t], oy = p0 / a.O2, ox = p0 - oy * a.O2; off = oy * a.s1 * a.Wq + ox; }
-                glds16(it.pb + (it.off_b[t] + off), base + PV2_OPERAND_BYTES + t * 1024);
+                int o;
+                if (k_table) o = ktab[(k0 >> 3) + (oct8[t] >> 3)];
+                else { const int p0 = k0 + oct8[t], oy = p0 / a.O2, ox = p0 - oy * a.O2; o = oy * a.s1 * a.Wq + ox; }
+                glds16(it.pb + (off.b[t] + o), base + PV2_OPERAND_BYTES + t * 1024);
             }
         } else {
 #pragma unroll
-            for (int t = 0; t < 4; ++t) glds16(it.pb + (it.off_b[t] + k0), base + PV2_OPERAND_BYTES + t * 1024);
+            for (int t = 0; t < 4; ++t) glds16(it.pb + (off.b[t] + k0), base + PV2_OPERAND_BYTES + t * 1024);
         }
     };
 
@@ -747,7 +760,9 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
     const int lr = lane & 31, sw = (lr >> 1) & 7, hi = lane >> 5;
     // epilogue constants: the lane's LDS positions (transposed accumulators) and its 16-byte piece of a result row
     const int er = tid >> 4, ech = tid & 15;   // row (+ 16 per pass) and 16-byte chunk this thread copies out
-    const int64_t out_step = ROWS ? static_cast<int64_t>(16) * a.batch * a.N : static_cast<int64_t>(a.N >> 2) * a.out_tile_stride;
+    const int64_t out_step = ROWS ? static_cast<int64_t>(16) * a.batch * a.N : PLAIN ? static_cast<int64_t>(16) * a.N
+                                                                                      : static_cast<int64_t>(a.N >> 2) * a.out_tile_stride;
+    lane_offsets(cur);
     stage(cur, 0, 0);
     __builtin_amdgcn_s_waitcnt(0);
     __syncthreads();
@@ -758,7 +773,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
         f32x16 acc[2][2];
         for (int k0 = 0; k0 < a.K; k0 += 64) {
             if (k0 + 64 < a.K) stage(cur, buf ^ 1, k0 + 64);
-            else if (have_next) stage(nxt, buf ^ 1, 0);   // the next item's first k-step rides behind this one
+            else if (have_next) { lane_offsets(nxt); stage(nxt, buf ^ 1, 0); }   // the next item's first k-step rides behind this one
             const unsigned char* sa = sm + buf * PV2_STAGE_BYTES + (wm * 64 + lr) * 128;
             const unsigned char* sb = sm + buf * PV2_STAGE_BYTES + PV2_OPERAND_BYTES + (wn * 64 + lr) * 128;
             if (k0 == 0) wave_kstep_transposed<true>(acc, sa, sb, hi, sw);
@@ -792,17 +807,103 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
                 const int64_t d = static_cast<int64_t>(m) * a.N + n;
                 // 16 rows further: d grows by 16 N, a multiple of 64 -> the same place in a k-tile, N / 4 k-tiles on
                 uint16_t* dst = a.out + (ROWS ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
+                                        : PLAIN ? (static_cast<int64_t>(cur.z) * a.M + m) * a.N + n
                                               : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63));
                 const unsigned char* src = ep + er * 256 + ((ech ^ (er & 15)) << 4);
 #pragma unroll
                 for (int it = 0; it < 8; ++it)
-                    if (m + 16 * it < a.M)
-                        *reinterpret_cast<u32x4*>(dst + it * out_step) = *reinterpret_cast<const u32x4*>(src + it * 4096);
+                    if (m + 16 * it < a.M) {
+                        u32x4 w = *reinterpret_cast<const u32x4*>(src + it * 4096);
+                        if constexpr (PLAIN) {   // eight products in fp32, rounded to bf16 once more
+                            const float* mrow = a.mul + static_cast<int64_t>(m + 16 * it) * a.ld_mul + n;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float f0 = (n + 2 * e < a.mul_n) ? mrow[2 * e] : 0.0f, f1 = (n + 2 * e + 1 < a.mul_n) ? mrow[2 * e + 1] : 0.0f;
+                                w[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * f0, __uint_as_float(w[e] & 0xffff0000u) * f1);
+                            }
+                        }
+                        *reinterpret_cast<u32x4*>(dst + it * out_step) = w;
+                    }
             }
         }
         __syncthreads();   // the staging buffer is free again before the next k-step's DMA is issued into it
         cur = nxt;
         have = have_next;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Per-sample gradients with a LONG contraction (sequences: K = T >= 256) on the wave-role-split 256 x 256 loop: one workgroup
+// per (sample, 256 x 256 tile), 4 .. 16 k-tiles each -- the 128 x 128 kernel above spends a DMA round trip per k-step on these
+// (0.3 PFLOP/s at T = 512).  The operands are swapped (tile rows = i, the contiguous direction of the result; tile columns = m),
+// so a lane owns four consecutive bf16 of a result row; the whole 256 x 256 bf16 tile is transposed through the 128 KB of LDS
+// (row m: 512 B, 16-byte chunk c at position c ^ (m & 31)) and leaves in 16-byte pieces of the k-tile-major layout.
+// Covers columns [0, n_end) (n_end % 256 == 0 or n_end == N); M % 256 == 0.  A sample's tiles are consecutive items of one
+// XCD (its two operands, < 2 MB, stay in that L2).
+// ------------------------------------------------------------------------------------------------
+struct PsgPpArgs {
+    uint16_t* out; int64_t out_tile_stride;
+    const uint16_t* A; int64_t a_sample_stride;   // [batch][M][K]
+    const uint16_t* B; int64_t b_sample_stride;   // [batch][N][K]
+    int M, N, KT, batch, tiles_m, tiles_n, n_end;
+};
+
+__global__ __launch_bounds__(pp::THREADS) void psg_gemm_pp_kernel(PsgPpArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int z = static_cast<int>(item / tiles), tile = static_cast<int>(item - static_cast<int64_t>(z) * tiles);
+    const int tn = tile / a.tiles_m, tm = tile - tn * a.tiles_m;
+    const int i0 = tn * 256, m0 = tm * 256;   // tile rows: i0 .. (B operand of the gradient), tile columns: m0 .. (A operand)
+    const int K = a.KT * 64;
+    const uint16_t* rows_i = a.B + static_cast<int64_t>(z) * a.b_sample_stride;
+    const uint16_t* rows_m = a.A + static_cast<int64_t>(z) * a.a_sample_stride;
+
+    pp::Sources src;
+    pp::make_sources(src, wave, lane,
+                     [&](int row) { return rows_i + static_cast<int64_t>(min(i0 + row, a.N - 1)) * K; },
+                     [&](int row) { return rows_m + static_cast<int64_t>(m0 + row) * K; });
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    pp::mainloop(acc, sm, src, a.KT, wave, lane, [](int t) { return t * 64; }, [](int t) { return t * 64; });
+    __syncthreads();   // every wave is done with the stage buffers: the epilogue reuses them
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int ml = wn * 64 + jn * 32 + (lane & 31);
+            unsigned char* dst = sm + ml * 512 + hi * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // registers 4 q .. 4 q + 3: tile rows i = wm * 128 + i * 32 + 8 q + 4 hi + (0 .. 3)
+                const int c = wm * 16 + i * 4 + q;
+                uint2 w;
+                w.x = pack_bf16x2(acc[i][jn][4 * q], acc[i][jn][4 * q + 1]);
+                w.y = pack_bf16x2(acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]);
+                *reinterpret_cast<uint2*>(dst + ((c ^ (ml & 31)) << 4)) = w;
+            }
+        }
+    __syncthreads();
+    // 512 threads = 16 result rows x 32 chunks per pass; 16 rows further d = m N + n grows by 16 N, a multiple of 64
+    const int er = tid >> 5, ech = tid & 31, n = i0 + ech * 8;
+    if (n < a.n_end) {  // N % 8 == 0: a chunk is entirely in or out
+        const int64_t d = static_cast<int64_t>(m0 + er) * a.N + n;
+        uint16_t* dst = a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
+        const int64_t step = static_cast<int64_t>(a.N >> 2) * a.out_tile_stride;
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+            const int ml = er + 16 * it;
+            *reinterpret_cast<u32x4*>(dst + it * step) = *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ech ^ (ml & 31)) << 4));
+        }
     }
 }
 
@@ -1207,8 +1308,10 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
@@ -1246,7 +1349,22 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
 }
 
 int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
-    p.tiles_m = static_cast<int>(cdiv(p.M, 128)); p.tiles_n = static_cast<int>(cdiv(p.N, 128));
+    p.n_begin = 0;
+    if (engine_generation() == 3 && !p.conv && !p.out_rows && p.K >= 256 && p.M % 256 == 0 && p.N >= 256 && !getenv("KF_PSG_PP_OFF")) {
+        // long contraction: whole 256-column tiles on the wave-role-split loop; a remainder of at most 128 columns (the bias
+        // column and the padding of an odd I') stays with the 128 x 128 kernel below
+        const int rest = p.N % 256, n_end = rest > 128 ? p.N : p.N - rest;
+        PsgPpArgs g;
+        g.out = p.out; g.out_tile_stride = p.out_tile_stride; g.A = p.A; g.a_sample_stride = p.a_sample_stride;
+        g.B = p.B; g.b_sample_stride = p.b_sample_stride; g.M = p.M; g.N = p.N; g.KT = p.K >> 6; g.batch = p.batch;
+        g.tiles_m = p.M / 256; g.tiles_n = static_cast<int>(cdiv(n_end, 256)); g.n_end = n_end;
+        const int64_t items = static_cast<int64_t>(g.batch) * g.tiles_m * g.tiles_n;
+        if (items >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+        hipLaunchKernelGGL(psg_gemm_pp_kernel, dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pp::THREADS), pp::SMEM_BYTES, st, g);
+        if (n_end == p.N) return launch_status();
+        p.n_begin = n_end;
+    }
+    p.tiles_m = static_cast<int>(cdiv(p.M, 128)); p.tiles_n = static_cast<int>(cdiv(p.N - p.n_begin, 128));
     const int64_t blocks = 8 * cdiv(cdiv(p.batch, 8) * 8 * p.tiles_m * p.tiles_n, 8);  // PSG_ZB = 8 samples per block
     if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
     // the persistent kernel keeps per-lane source offsets in 32 bits (the sample base is a 64-bit scalar)
@@ -1258,10 +1376,12 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
         const int64_t groups = cdiv(p.batch, 8) * p.tiles_m * p.tiles_n;
         const unsigned grid = 64u * static_cast<unsigned>(std::min<int64_t>(8, cdiv(groups, 8)));
         const size_t smem = PV2_SMEM + ((p.conv && p.N <= PV2_ROWTAB_MAX) ? static_cast<size_t>((p.N + 3) / 4 * 16) : 0);
-        if (p.out_rows) hipLaunchKernelGGL(psg_gemm_v3_kernel<true>, dim3(grid), dim3(NTHREADS), smem, st, p);
-        else hipLaunchKernelGGL(psg_gemm_v3_kernel<false>, dim3(grid), dim3(NTHREADS), smem, st, p);
+        if (p.out_rows == 2) hipLaunchKernelGGL(psg_gemm_v3_kernel<2>, dim3(grid), dim3(NTHREADS), smem, st, p);
+        else if (p.out_rows) hipLaunchKernelGGL(psg_gemm_v3_kernel<1>, dim3(grid), dim3(NTHREADS), smem, st, p);
+        else hipLaunchKernelGGL(psg_gemm_v3_kernel<0>, dim3(grid), dim3(NTHREADS), smem, st, p);
         return launch_status();
     }
+    if (p.out_rows == 2) return KF_ERR_INVALID_ARGUMENT;   // the plain / scaled result exists on the persistent kernel only
     hipLaunchKernelGGL(psg_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(NTHREADS), PV2_SMEM, st, p);
     return launch_status();
 }
@@ -1299,6 +1419,109 @@ int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void*
     }
     hipLaunchKernelGGL(rotate_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), 2 * 512 * 128, as_stream(stream), r);
     return launch_status();
+}
+
+// ------------------------------------------------------------------------------------------------
+// EK-FAC preconditioning of a batch of query gradients, bf16 preset, on the round-3 engines (kf_precondition's low-precision path
+// when O, I and R are multiples of 64): four eigenbasis rotations on the 256 x 256 wave-role-split loop and the per-query
+// gradient on the persistent 128 x 128 kernel, instead of five products on the register-staged engine (its batched TN
+// products ran at 0.02-0.07 PFLOP/s: 35 % of the device time of a BERT step at 2 048 train sequences).
+//   1  GtT[q][o'][r] = sum_o  QgT[o'][o] G[(q r)][o]                      rotation, result K-contiguous per query
+//   2  AtT[q][i'][r] = sum_i  QaT[i'][i] A[(q r)][i]  (+ Qa[I][i'])       same; rows i' >= I' stay zero
+//   3  rot[q][o][i'] = (sum_r GtT[q][o][r] AtT[q][i'][r]) / (lambda + damping)[o][i']     (psg_gemm_v3_kernel<2>)
+//   4  Tt[q][j][o]   = sum_i' Qa[j][i'] rot[(q o)][i']                    contraction padded to W64 = W rounded up to 64
+//   5  P[q][m][n]    = scale sum_o Qg[m][o] Tt[(q n)][o]
+// Rounding points are those of the register-staged path (bf16 after every product, fp32 accumulation) plus one: the gradient of
+// step 3 is rounded before AND after the multiplication.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void pad_rows_bf16_kernel(uint16_t* dst, const uint16_t* src, int rows, int cols, int ld_dst) {   // dst[r][c] = src[r][c] or 0
+    const int64_t total = static_cast<int64_t>(rows) * ld_dst;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int r = static_cast<int>(e / ld_dst), c = static_cast<int>(e - static_cast<int64_t>(r) * ld_dst);
+        dst[e] = c < cols ? src[static_cast<int64_t>(r) * cols + c] : static_cast<uint16_t>(0);
+    }
+}
+__global__ void cast_f32_bf16_kernel(uint16_t* dst, const float* src, int64_t n) {
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < n; e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const uint32_t w = pack_bf16x2(src[e], 0.0f);
+        dst[e] = static_cast<uint16_t>(w & 0xffffu);
+    }
+}
+// C[m, n] = alpha sum_k A[m, k] B[n, k] (+ col_add[m]) on the 256 x 256 loop, element (m, n) at (n / c_inner) * c_outer + m * c_inner + n % c_inner
+int launch_rotate_blocked(uint16_t* C, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
+                          float alpha, const float* col_add, int col_add_m, int64_t c_inner, int64_t c_outer, hipStream_t st) {
+    if (K % 64 != 0 || N % 8 != 0 || c_inner % 8 != 0 || M >= (1LL << 31) - 256 || N >= (1LL << 31) - 256) return KF_ERR_INVALID_ARGUMENT;
+    RotateV3Args v{};
+    v.r.C = C; v.r.ldc = 0; v.r.A = A; v.r.lda = lda; v.r.B = B; v.r.ldb = ldb;
+    v.r.M = static_cast<int>(M); v.r.N = static_cast<int>(N); v.r.KT = static_cast<int>(K / 64);
+    v.r.tiles_m = static_cast<int>(cdiv(M, 256)); v.r.tiles_n = static_cast<int>(cdiv(N, 256));
+    v.r.alpha = alpha; v.r.row_add = nullptr; v.r.row_add_n = 0;
+    v.col_add = col_add; v.col_add_m = col_add_m; v.c_inner = c_inner; v.c_outer = c_outer;
+    v.n_major = 1;   // the few m-tiles (eigenvectors: L2 resident) of one n-tile run back to back: the big operand is read once
+    const int64_t blocks = 8 * cdiv(static_cast<int64_t>(v.r.tiles_m) * v.r.tiles_n, 8);
+    hipLaunchKernelGGL(rotate_gemm_v3_kernel<0>, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v);
+    return launch_status();
+}
+struct PrecondPlan { int64_t W64, gt, at, rot, qa, tt, qg, total; };
+PrecondPlan precond_plan(int64_t q, int64_t R, int64_t O, int64_t W) {
+    PrecondPlan p;
+    p.W64 = (W + 63) / 64 * 64;
+    p.gt = 0;
+    p.at = p.gt + align256(2 * q * O * R);
+    p.rot = p.at + align256(2 * q * p.W64 * R);
+    p.qa = p.rot + align256(2 * q * O * p.W64);
+    p.tt = p.qa + align256(2 * W * p.W64);
+    p.qg = p.tt + align256(2 * q * W * O);
+    p.total = p.qg + align256(2 * O * O);
+    return p;
+}
+}  // namespace
+
+int64_t precondition_v3_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t W) { return precond_plan(q, R, O, W).total; }
+
+bool precondition_v3_eligible(int64_t q, int64_t R, int64_t O, int64_t I, int64_t W) {
+    return engine_generation() == 3 && !getenv("KF_PRECOND_V3_OFF") && O % 64 == 0 && I % 64 == 0 && R % 64 == 0 && W % 8 == 0 && W >= I &&
+           q * R < (1LL << 31) - 256 && q * std::max(O, W) < (1LL << 31) - 256 && O * R + 64 < (1LL << 31) &&
+           ((W + 63) / 64 * 64) * R + 64 < (1LL << 31) && q <= 65535;
+}
+
+int precondition_v3(void* Pout, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg,
+                    const float* Qa, int64_t Ip, const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16,
+                    const void* QaT_bf16, int64_t W, void* workspace, void* stream) {
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    hipStream_t st = as_stream(stream);
+    const PrecondPlan p = precond_plan(q, R, O, W);
+    char* ws = reinterpret_cast<char*>(workspace);
+    uint16_t* gt = reinterpret_cast<uint16_t*>(ws + p.gt);
+    uint16_t* at = reinterpret_cast<uint16_t*>(ws + p.at);
+    uint16_t* rot = reinterpret_cast<uint16_t*>(ws + p.rot);
+    uint16_t* qa = reinterpret_cast<uint16_t*>(ws + p.qa);
+    uint16_t* tt = reinterpret_cast<uint16_t*>(ws + p.tt);
+    uint16_t* qg = reinterpret_cast<uint16_t*>(ws + p.qg);
+    const int64_t W64 = p.W64;
+    // rows i' in [W, W64) of AtT are never written by step 2: zero (they are operand rows of step 3)
+    if (hipMemsetAsync(at, 0, static_cast<size_t>(2 * q * W64 * R), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(W * W64, 256), 2048))), dim3(256), 0, st, qa,
+                       reinterpret_cast<const uint16_t*>(Qa_bf16), static_cast<int>(W), static_cast<int>(W), static_cast<int>(W64));
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(O * O, 256), 2048))), dim3(256), 0, st, qg, Qg, O * O);
+    int rc = launch_rotate_blocked(gt, reinterpret_cast<const uint16_t*>(QgT_bf16), O, reinterpret_cast<const uint16_t*>(G), O, O, q * R, O, 1.0f,
+                                   nullptr, 0, R, O * R, st);
+    if (rc != KF_OK) return rc;
+    rc = launch_rotate_blocked(at, reinterpret_cast<const uint16_t*>(QaT_bf16), W, reinterpret_cast<const uint16_t*>(A), I, W, q * R, I, 1.0f,
+                               append_ones ? Qa + I * Ip : nullptr, append_ones ? static_cast<int>(Ip) : 0, R, W64 * R, st);
+    if (rc != KF_OK) return rc;
+    PsgV2Args g{};
+    g.out = rot; g.out_tile_stride = 0; g.out_rows = 2;
+    g.A = gt; g.a_sample_stride = O * R; g.B = at; g.b_sample_stride = W64 * R;
+    g.M = static_cast<int>(O); g.N = static_cast<int>(W64); g.K = static_cast<int>(R); g.batch = static_cast<int>(q);
+    g.conv = 0; g.C = 1; g.k2 = 1; g.O2 = 8; g.s1 = 1; g.d1 = 1; g.s2 = 1; g.d2 = 1; g.Wq = 8; g.plane = 0; g.phase_stride = 0;
+    g.mul = inv_lambda; g.ld_mul = static_cast<int>(Ip); g.mul_n = static_cast<int>(Ip);
+    rc = launch_psg_v2(g, st);
+    if (rc != KF_OK) return rc;
+    rc = launch_rotate_blocked(tt, qa, W64, rot, W64, W, q * O, W64, 1.0f, nullptr, 0, O, W * O, st);
+    if (rc != KF_OK) return rc;
+    return launch_rotate_blocked(reinterpret_cast<uint16_t*>(Pout), qg, O, tt, O, O, q * W, O, scale, nullptr, 0, W, O * W, st);
 }
 }  // namespace kf
 
@@ -1370,7 +1593,7 @@ int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_til
                            grid, gsrc, b * O, static_cast<int>(c.O1), static_cast<int>(c.O2), static_cast<int>(c.O1p), static_cast<int>(c.O2p));
         gsrc = grid;
     }
-    PsgV2Args g;
+    PsgV2Args g{};
     g.out = psg; g.out_tile_stride = b * 64; g.out_rows = 0;
     g.A = gsrc; g.a_sample_stride = O * c.Pp;
     g.B = copies; g.b_sample_stride = c.Cp * c.Hp * c.Wq;
@@ -1414,7 +1637,7 @@ int kf_lambda_conv2d_accum(float* Lambda, int64_t ld_lambda, const void* Gt_nchw
     hipLaunchKernelGGL(conv_pad_phases_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(chunks, 256), 1 << 20))), dim3(256), 0,
                        st, pa);
     // per-sample gradients in the gradient eigenbasis, rows ordered (o, sample), patch axis (ky, kx, c)
-    PsgV2Args g;
+    PsgV2Args g{};
     g.out = psg; g.out_tile_stride = 0; g.out_rows = 1;
     g.A = reinterpret_cast<const uint16_t*>(Gt_nchw); g.a_sample_stride = O * c.Pp;
     g.B = copies; g.b_sample_stride = c.Cp * c.Hp * c.Wq;
@@ -1463,7 +1686,7 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
     t.out = at; t.x = reinterpret_cast<const uint16_t*>(A); t.C = static_cast<int>(I); t.Cp = static_cast<int>(Ip); t.ones = append_ones ? 1 : 0;
     hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(Ip, 64)), static_cast<unsigned>(b)),
                        dim3(256), 0, st, t);
-    PsgV2Args g;
+    PsgV2Args g{};
     g.out = psg; g.out_tile_stride = b * 64; g.out_rows = 0;
     g.A = gt; g.a_sample_stride = O * R; g.B = at; g.b_sample_stride = Ip * R;
     g.M = static_cast<int>(O); g.N = static_cast<int>(Ip); g.K = static_cast<int>(R); g.batch = static_cast<int>(b);

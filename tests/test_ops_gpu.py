@@ -440,7 +440,11 @@ def test_lambda_conv2d_dense_form(ops, c):
 
 
 @pytest.mark.parametrize("q,b,r,o,i,bias", [(5, 6, 64, 64, 128, True), (300, 9, 128, 136, 72, True), (40, 3, 512, 72, 768, False),
-                                             (7, 4, 64, 8, 8, True)])
+                                             (7, 4, 64, 8, 8, True),
+                                             # long contraction + O % 256 == 0: per-sample gradients on the 256 x 256 wave-role-split
+                                             # loop -- whole tiles only / a masked 144-column tile / a 16-column remainder (bias +
+                                             # padding) left to the 128 x 128 kernel; 4, 5 and 8 k-tiles
+                                             (20, 3, 256, 256, 512, False), (12, 2, 320, 512, 392, True), (9, 3, 512, 256, 264, True)])
 def test_pairwise_score_rows_v2(ops, q, b, r, o, i, bias):
     """kf_pairwise_score_rows: Linear layer on [b, R, .] rows; the bias column of ones and the zero padding of I' to a
     multiple of 8 are generated inside the call (no torch.cat); against ``"qio,b...i,b...o->qb"`` (linear.py:112-122)."""
