@@ -628,8 +628,9 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         peak = PEAK_BF16_MFMA_TFLOPS if low else PEAK_FP32_MFMA_TFLOPS
         roofline = _event_summary(score_events.get("pairwise_score", []), peak,
                                   "kf_pairwise_score*: score_r1_kernel (one row per sample) | conv_pad_phases_kernel / "
-                                  "transpose_rows_kernel + psg_gemm_v2_kernel (per-sample gradients) + "
-                                  "score_gemm_v2_kernel<TM,TN,W> (score GEMM; the dominant kernel)", elapsed)
+                                  "transpose_rows_kernel + psg_gemm_v3_kernel / psg_gemm_pp_kernel (per-sample gradients) + "
+                                  "score_gemm_v3_kernel (256 x 256; score_gemm_v2_kernel<TM,TN,W> for the 256 x 128 / 128 x 256 "
+                                  "shapes) (score GEMM; the dominant kernel)", elapsed)
         traffic = _pmc_traffic(name)
         if traffic is not None and "stale" in traffic:
             if roofline is not None:

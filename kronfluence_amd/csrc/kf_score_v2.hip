@@ -607,8 +607,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v2_kernel(PsgV2Args a) {
 // ------------------------------------------------------------------------------------------------
 // Round 3: the same per-sample-gradient tiles from PERSISTENT workgroups.  A workgroup walks a strided list of (sample,
 // tile) items of its XCD's range and keeps the two-stage LDS-DMA pipeline running ACROSS item boundaries: while the last
-// k-step of an item is being multiplied, the first k-step of the next item is already on its way, and it lands during the
-// bf16 epilogue.  In the v2 kernel every item (1-16 k-steps: K = R = 64 .. 1024) paid a full DMA round trip before its first
+// k-step of an item is being multiplied, the first k-step of the next item is already on its way.  In the v2 kernel every item (1-16 k-steps: K = R = 64 .. 1024) paid a full DMA round trip before its first
 // MFMA and there was one workgroup launch per item.  The epilogue stages its bf16 tile in the stage buffer that was consumed
 // last (128 rows x 256 B = 32 KB exactly), so two workgroups share a CU as before.
 //
@@ -684,6 +683,12 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // workgroup j serves sample j % 8 of the groups j / 8, j / 8 + gridDim / 64, ...  The workgroups running together on an XCD
 // then cover a few samples x all their tiles -- the samples' inputs stay in that XCD's L2 across their tiles -- and the 8
 // samples of one tile write ADJACENT 128-byte pieces of the k-tile-major gradient buffer.
+// (Two latency experiments on this kernel, both measured and neither adopted -- profiles/r03_psg_wave_roles_negative.log,
+// r03_psg_deferred_wait_negative.log: waves specialised into DMA issuers and storers so that no wave waits for its own stores
+// at the next "DMA landed" (6-11 % slower), and the DMA wait moved to the top of the consuming k-step with a counted vmcnt
+// over the copy-out stores, so that the next item's first k-step stays in flight through the epilogue (no change).  The
+// kernel is bound by memory-system throughput -- its 32 KB result tile per 16-64 MFMAs and the gather-like implicit-im2col
+// requests -- not by the latency of the item boundary.)
 template <int OUT>   // 0: k-tile-major (score GEMM operand), 1: rows ordered (m, sample), 2: plain per sample, times `mul`
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
     constexpr bool ROWS = OUT == 1, PLAIN = OUT == 2;
@@ -705,10 +710,7 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
             for (int i = tid; i < a.N; i += NTHREADS) rowtab[i] = conv_row_offset(a, i);
         __syncthreads();
     }
-    // this thread's four DMA rows of an operand tile and the k-octet it fetches of each (item independent).
-    // (Specialising the waves by traffic -- waves 0-1 issue all 16 DMA requests of a k-step and never store, waves 2-3 issue all
-    // stores and never wait on vmcnt, so that no wave waits for its own stores at the next "DMA landed" -- was measured: 6-11 %
-    // SLOWER on every shape, profiles/r03_psg_wave_roles_negative.log.)
+    // this thread's four DMA rows of an operand tile and the k-octet it fetches of each (item independent)
     int row[4], oct8[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -794,37 +796,34 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {   // accumulator registers 4 q .. 4 q + 3: columns i = 8 q + 4 hi + (0 .. 3) of the block
                     const int c = wn * 8 + ti * 4 + q;
-                    uint2 w;
-                    w.x = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
-                    w.y = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
-                    *reinterpret_cast<uint2*>(dst + ((c ^ (ml & 15)) << 4)) = w;
+                    const uint32_t w0 = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
+                    const uint32_t w1 = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
+                    *reinterpret_cast<uint2*>(dst + ((c ^ (ml & 15)) << 4)) = uint2{w0, w1};
                 }
             }
         __syncthreads();
         {
             const int m = cur.m0 + er, n = cur.n0 + ech * 8;
-            if (n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
-                const int64_t d = static_cast<int64_t>(m) * a.N + n;
-                // 16 rows further: d grows by 16 N, a multiple of 64 -> the same place in a k-tile, N / 4 k-tiles on
-                uint16_t* dst = a.out + (ROWS ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
-                                        : PLAIN ? (static_cast<int64_t>(cur.z) * a.M + m) * a.N + n
-                                              : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63));
-                const unsigned char* src = ep + er * 256 + ((ech ^ (er & 15)) << 4);
+            const int64_t d = static_cast<int64_t>(m) * a.N + n;
+            // 16 rows further: d grows by 16 N, a multiple of 64 -> the same place in a k-tile, N / 4 k-tiles on
+            uint16_t* dst = a.out + (ROWS ? (static_cast<int64_t>(m) * a.batch + cur.z) * a.N + n
+                                    : PLAIN ? (static_cast<int64_t>(cur.z) * a.M + m) * a.N + n
+                                          : (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63));
+            const unsigned char* src = ep + er * 256 + ((ech ^ (er & 15)) << 4);
 #pragma unroll
-                for (int it = 0; it < 8; ++it)
-                    if (m + 16 * it < a.M) {
-                        u32x4 w = *reinterpret_cast<const u32x4*>(src + it * 4096);
-                        if constexpr (PLAIN) {   // eight products in fp32, rounded to bf16 once more
-                            const float* mrow = a.mul + static_cast<int64_t>(m + 16 * it) * a.ld_mul + n;
+            for (int it = 0; it < 8; ++it)
+                if (m + 16 * it < a.M && n < a.N) {  // N % 8 == 0: a chunk is entirely in or out
+                    u32x4 w = *reinterpret_cast<const u32x4*>(src + it * 4096);
+                    if constexpr (PLAIN) {   // eight products in fp32, rounded to bf16 once more
+                        const float* mrow = a.mul + static_cast<int64_t>(m + 16 * it) * a.ld_mul + n;
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float f0 = (n + 2 * e < a.mul_n) ? mrow[2 * e] : 0.0f, f1 = (n + 2 * e + 1 < a.mul_n) ? mrow[2 * e + 1] : 0.0f;
-                                w[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * f0, __uint_as_float(w[e] & 0xffff0000u) * f1);
-                            }
+                        for (int e = 0; e < 4; ++e) {
+                            const float f0 = (n + 2 * e < a.mul_n) ? mrow[2 * e] : 0.0f, f1 = (n + 2 * e + 1 < a.mul_n) ? mrow[2 * e + 1] : 0.0f;
+                            w[e] = pack_bf16x2(__uint_as_float(w[e] << 16) * f0, __uint_as_float(w[e] & 0xffff0000u) * f1);
                         }
-                        *reinterpret_cast<u32x4*>(dst + it * out_step) = w;
                     }
-            }
+                    *reinterpret_cast<u32x4*>(dst + it * out_step) = w;
+                }
         }
         __syncthreads();   // the staging buffer is free again before the next k-step's DMA is issued into it
         cur = nxt;

@@ -24,7 +24,10 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCORE_GEMM = ("score_gemm_v2_kernel", "score_gemm_v3_kernel")
-PSG = ("psg_gemm_v2_kernel", "psg_gemm_v3_kernel")
+PSG = ("psg_gemm_v2_kernel", "psg_gemm_v3_kernel", "psg_gemm_pp_kernel")
+# instantiations of the persistent gradient kernel that serve OTHER entry points: <1, .> rows for the dense-form Lambda, <2, .> the
+# query-side preconditioner
+PSG_NOT_SCORE = ("psg_gemm_v3_kernel<1", "psg_gemm_v3_kernel<2")
 COV_GEMM = ("cov_gemm_v2_kernel", "cov_gemm_v3_kernel")
 SCORE_KERNELS = SCORE_GEMM + PSG + ("conv_pad_phases_kernel", "pad_grid_kernel", "transpose_rows_kernel", "score_r1_kernel")
 
@@ -47,13 +50,13 @@ def short(name: str) -> str:
 
 def score_call_bytes(kernels: dict, calls: int) -> float:
     """HBM bytes of all kf_pairwise_score* calls.  A score call launches exactly one per-sample-gradient kernel
-    (``psg_gemm_v3_kernel<false>`` / ``psg_gemm_v2_kernel``; the ``<true>`` instantiation belongs to the dense-form Lambda) with
+    (``psg_gemm_v3_kernel<0, .>`` / ``psg_gemm_pp_kernel`` / ``psg_gemm_v2_kernel``; see PSG_NOT_SCORE for the others) with
     one conv_pad_phases_kernel (convolution) or two transpose_rows_kernel (sequence rows) -- kernels that also serve the
     covariance / Lambda entry points when the profiled command ran the factor fit, so only that share of their launches counts."""
-    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG) and "<true>" not in n)
+    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG) and not n.startswith(PSG_NOT_SCORE) and not n.startswith("psg_gemm_pp"))
     total = 0.0
     for n, e in kernels.items():
-        if not n.startswith(SCORE_KERNELS) or (n.startswith(PSG) and "<true>" in n):
+        if not n.startswith(SCORE_KERNELS) or n.startswith(PSG_NOT_SCORE):
             continue
         share = 1.0
         if n.startswith("conv_pad_phases_kernel"):
