@@ -645,7 +645,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                                       "algorithmic bytes = one read of the rows handed over)", fit_times["covariance"])
         if roofline_cov is not None and traffic is not None and traffic.get("cov_gemm_bytes_per_launch") is not None:
             roofline_cov["traffic"] = traffic["cov_gemm_bytes_per_launch"]
-            roofline_cov["traffic_source"] = "cov_gemm_v2_kernel alone (per launch), same PMC passes as roofline.traffic"
+            roofline_cov["traffic_source"] = "the covariance GEMM kernel with the most launches alone (cov_gemm_v3_kernel / cov_gemm_v2_kernel; per launch), same PMC passes as roofline.traffic"
             roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
         result = {
             "metric": "pairwise_influence_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world,
