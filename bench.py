@@ -647,6 +647,14 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             roofline_cov["traffic"] = traffic["cov_gemm_bytes_per_launch"]
             roofline_cov["traffic_source"] = "the covariance GEMM kernel with the most launches alone (cov_gemm_v3_kernel / cov_gemm_v2_kernel; per launch), same PMC passes as roofline.traffic"
             roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
+        roofline_lambda = _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_accum (factored form: the product of "
+                                         "the rotated factors, 2 b R O I' flops) | kf_lambda_conv2d_accum (dense form of a Conv2d layer: "
+                                         "pad + psg_gemm + rotate_gemm_v3<sumsq>, 2 b R O I' + 2 b O I'^2 flops)", fit_times["lambda"])
+        if roofline_lambda is not None and traffic is not None and traffic.get("kf_lambda_bytes_per_launch") is not None:
+            roofline_lambda["traffic"] = traffic["kf_lambda_bytes_per_launch"]
+            roofline_lambda["traffic_source"] = ("lambda_bf16_kernel / lambda_kernel (factored calls) and conv_pad_phases + psg_gemm_v3<1> + "
+                                                 "rotate_gemm_v3<1> (dense calls) per call, same PMC passes as roofline.traffic")
+            roofline_lambda["mfma_util"] = traffic.get("lambda_mfma_util")
         result = {
             "metric": "pairwise_influence_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
@@ -663,9 +671,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                           if n_train < spec.get("full_n_train", 0) else {})},
             "roofline": roofline,
             "roofline_cov": roofline_cov,
-            "roofline_lambda": _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_accum (factored form: the product of "
-                                              "the rotated factors, 2 b R O I' flops) | kf_lambda_conv2d_accum (dense form of a Conv2d layer: "
-                                              "pad + psg_gemm + rotate_gemm_v3<sumsq>, 2 b R O I' + 2 b O I'^2 flops)", fit_times["lambda"]),
+            "roofline_lambda": roofline_lambda,
             # the WHOLE Lambda update of a hook (eigenbasis rotations included) against F_lambda, the cheaper of the two exact
             # formulations
             "roofline_lambda_update": _event_summary(fit_events.get("lambda_update", []), peak, "LambdaTracker backward hook: "

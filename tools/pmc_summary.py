@@ -67,12 +67,32 @@ def score_call_bytes(kernels: dict, calls: int) -> float:
     return total
 
 
+def lambda_call_bytes(kernels: dict):
+    """-> (HBM bytes per kf_lambda_accum / kf_lambda_conv2d_accum call, calls, MFMA utilisation per Lambda kernel).  A factored call is one lambda_bf16_kernel / lambda_kernel launch; a dense call (Conv2d, R > O) is one
+    conv_pad_phases_kernel + psg_gemm_v3_kernel<1> (rows ordered (o', n)) + rotate_gemm_v3_kernel<1> (sum-of-squares GEMM)."""
+    dense = [e for n, e in kernels.items() if n.startswith("rotate_gemm_v3_kernel<1")]
+    parts = [e for n, e in kernels.items() if n.startswith(("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "rotate_gemm_v3_kernel<1",
+                                                             "psg_gemm_v3_kernel<1"))]
+    calls = sum(e["launches"] for n, e in kernels.items()
+                if n.startswith(("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "rotate_gemm_v3_kernel<1")))
+    if not calls:
+        return None, 0, None
+    total = sum(e["launches"] * (e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)) for e in parts)
+    pad = next((e for n, e in kernels.items() if n.startswith("conv_pad_phases_kernel")), None)
+    if pad is not None and dense:
+        total += sum(e["launches"] for e in dense) * (pad.get("hbm_read_bytes", 0.0) + pad.get("hbm_write_bytes", 0.0))
+    names = ("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "rotate_gemm_v3_kernel<1", "psg_gemm_v3_kernel<1")
+    util = {n: e.get("mfma_util") for n, e in kernels.items() if n.startswith(names) and e.get("mfma_util") is not None}
+    return total / calls, calls, util
+
+
 def main() -> None:
     if sys.argv[1] == "--recompute":  # python tools/pmc_summary.py --recompute <summary.json>: totals from the kept per-kernel means
         with open(sys.argv[2], encoding="utf-8") as handle:
             summary = json.load(handle)
         calls = summary["kf_pairwise_score_calls_profiled"]
         summary["kf_pairwise_score_bytes_per_launch"] = score_call_bytes(summary["kernels"], calls) / calls if calls else None
+        summary["kf_lambda_bytes_per_launch"], summary["kf_lambda_calls_profiled"], summary["lambda_mfma_util"] = lambda_call_bytes(summary["kernels"])
         with open(sys.argv[2], "w", encoding="utf-8") as handle:
             json.dump(summary, handle, indent=1)
         print(summary["kf_pairwise_score_bytes_per_launch"])
@@ -118,6 +138,7 @@ def main() -> None:
         "kernels": {n: e for n, e in kernels.items() if n.startswith(SCORE_KERNELS) or "gemm_bf16" in n or "syrk" in n or "lambda" in n
                     or "im2col" in n or "eigh" in n or "jacobi" in n or n.startswith("cov_") or n.startswith("rotate_gemm")},
     }
+    summary["kf_lambda_bytes_per_launch"], summary["kf_lambda_calls_profiled"], summary["lambda_mfma_util"] = lambda_call_bytes(summary["kernels"])
     with open(out_path, "w", encoding="utf-8") as handle:
         json.dump(summary, handle, indent=1)
     print(json.dumps({k: v for k, v in summary.items() if k != "kernels"}, indent=1))
