@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
 // rows of the pair: new[j][i] = sum_c U[c][j] old[c][i], for W^T and V^T, over this workgroup's i-range
 __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ Wt, double* __restrict__ Vt, const double* __restrict__ Ubuf,
                                                           const int* __restrict__ pair_flag, int64_t d, int nblocks, int players, int round,
-                                                          int64_t chunk, const int* __restrict__ done) {
+                                                          int64_t chunk, const int* __restrict__ done, int with_v) {
     extern __shared__ double lds[];
     if (*done) return;
     double* Ul = lds;                 // [64 c][UPITCH]  (j contiguous)
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ W
     for (int r = 0; r < 4; ++r) orow[r] = pair_row(wave * 16 + (lane >> 4) + 4 * r, P, Q, nblocks, d);
     const int64_t i_begin = blockIdx.y * chunk, i_end = min(d, i_begin + chunk);
 #pragma unroll 1
-    for (int which = 0; which < 2; ++which) {
+    for (int which = 0; which < 1 + with_v; ++which) {   // with_v == 0: the factor-first solver carries no V
         double* Mx = which == 0 ? Wt : Vt;
         for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
             double v[16];
@@ -502,6 +502,241 @@ __global__ void scatter_vectors_kernel(double* evecs, const double* Vt, const in
     for (int r = ty; r < 32; r += 8) {
         const int64_t i = i0 + r, j = j0 + tx;
         if (i < d && j < d) evecs[i * d + rank[j]] = tile[tx][r];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factor-first solver (Veselic-Hari), the default for d >= 256 (KF_EIGH_CHOLESKY=0 disables it).  Designed on the CPU prototype
+// tools/eigh_jacobi_proto.py (7-13 sweeps where the solver above needs 17-25, 40 % fewer bytes per round); on the MI355X
+// d = 3073: 10 sweeps / 200 ms against 20 / 479 ms, 12 problems on 2 lanes 1.54 s against 4.5 s
+// (profiles/r03_eigh_factor_first.log):   S' = P (S + shift I) P^T = R^T R  (columns sorted by decreasing diagonal, upper Cholesky, right-looking, 64 rows per
+// step);  then the SAME blocked one-sided Jacobi on the rows of R (= the columns of L = R^T) WITHOUT V:  L V = U Sigma, so
+// S' = U Sigma^2 U^T -- eigenvectors = normalised rows of the rotated Wt (scattered back through P), eigenvalues = squared row
+// norms - shift.  A non-positive pivot (shift too small for this matrix) sets a flag and the caller falls back to the solver
+// above.  Wt holds the working matrix: upper triangle of S' at first, R when the factorisation is done, zeros below the diagonal.
+// ------------------------------------------------------------------------------------------------
+constexpr int CB = 64;   // rows per factorisation step (= KP, so the panel transform is the update kernel's product)
+
+__device__ __forceinline__ double cov_entry(const void* cov, int is_f64, double count, int64_t d, int64_t i, int64_t j) {
+    double a, b;
+    if (is_f64) { a = reinterpret_cast<const double*>(cov)[i * d + j]; b = reinterpret_cast<const double*>(cov)[j * d + i]; }
+    else { a = reinterpret_cast<const float*>(cov)[i * d + j]; b = reinterpret_cast<const float*>(cov)[j * d + i]; }
+    return 0.5 * (a / count + b / count);   // the reference's op order (eigen.py:198-203), as eigh_init_kernel
+}
+
+// diag[j] = S[j][j];  out[0] += ||S||_F^2 (out zeroed by the caller)
+__global__ __launch_bounds__(EB) void chol_scan_kernel(double* diag, double* frob2, const void* cov, int is_f64, double count, int64_t d) {
+    __shared__ double scratch[4];
+    double s = 0.0;
+    const int64_t total = d * d;
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(EB) + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * EB) {
+        const int64_t i = e / d, j = e % d;
+        const double x = cov_entry(cov, is_f64, count, d, i, j);
+        s += x * x;
+        if (i == j) diag[i] = x;
+    }
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) atomicAdd(frob2, s);
+}
+
+// order[r] = j for the r-th LARGEST diagonal entry (ties by index)
+__global__ void chol_order_kernel(int* order, const double* diag, int64_t d) {
+    const int64_t j = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x;
+    if (j >= d) return;
+    const double x = diag[j];
+    int r = 0;
+    for (int64_t k = 0; k < d; ++k) {
+        const double y = diag[k];
+        r += (y > x || (y == x && k < j)) ? 1 : 0;
+    }
+    order[r] = static_cast<int>(j);
+}
+
+// Wt[a][b] = S[order[a]][order[b]] (+ shift on the diagonal) for b >= a, 0 below the diagonal;  shift = shift_scale * ||S||_F
+__global__ void chol_init_kernel(double* Wt, const void* cov, int is_f64, double count, int64_t d, const int* order, const double* frob2,
+                                 double shift_scale) {
+    const int64_t total = d * d;
+    const double shift = shift_scale * sqrt(frob2[0]);
+    for (int64_t e = blockIdx.x * static_cast<int64_t>(blockDim.x) + threadIdx.x; e < total; e += static_cast<int64_t>(gridDim.x) * blockDim.x) {
+        const int64_t a = e / d, b = e % d;
+        double x = 0.0;
+        if (b >= a) x = cov_entry(cov, is_f64, count, d, order[a], order[b]) + (a == b ? shift : 0.0);
+        Wt[e] = x;
+    }
+}
+
+// Step k, diagonal block: D = Wt[r0 .. r0+63][r0 .. r0+63] (upper part; rows / columns >= d count as identity) -> R_kk (upper
+// Cholesky factor, written back with zeros below the diagonal) and U = R_kk^-1 (64 x 64, row-major [c][j]) for the panel
+// transform.  One workgroup.  fail[0] = 1 when a pivot is not positive.
+constexpr int CHOL_BLOCK_LDS = 2 * CB * (CB + 1) * static_cast<int>(sizeof(double));
+__global__ __launch_bounds__(256) void chol_block_kernel(double* __restrict__ Wt, int64_t d, int k, double* __restrict__ U, int* __restrict__ fail) {
+    constexpr int LP = CB + 1;
+    extern __shared__ double lds[];   // CHOL_BLOCK_LDS bytes
+    double* D = lds;
+    double* X = lds + CB * LP;
+    __shared__ int bad;
+    const int tid = threadIdx.x;
+    const int64_t r0 = static_cast<int64_t>(k) * CB;
+    const int n = static_cast<int>(min<int64_t>(CB, d - r0));
+    if (tid == 0) bad = 0;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        double x = (r == c) ? 1.0 : 0.0;
+        if (r < n && c < n) x = Wt[(r0 + min(r, c)) * d + r0 + max(r, c)];   // the upper part, mirrored
+        D[r * LP + c] = x;
+        X[r * LP + c] = 0.0;
+    }
+    __syncthreads();
+    // right-looking inside the block: row j becomes row j of R, the trailing part loses its outer product
+    for (int j = 0; j < CB; ++j) {
+        const double pivot = D[j * LP + j];
+        if (!(pivot > 0.0)) { if (tid == 0) bad = 1; }
+        const double root = sqrt(pivot > 0.0 ? pivot : 1.0);
+        __syncthreads();
+        if (tid > j && tid < CB) D[j * LP + tid] /= root;
+        if (tid == 0) D[j * LP + j] = root;
+        __syncthreads();
+        for (int e = tid; e < CB * CB; e += 256) {
+            const int r = e / CB, c = e % CB;
+            if (r > j && c >= r) D[r * LP + c] -= D[j * LP + r] * D[j * LP + c];
+        }
+        __syncthreads();
+    }
+    // X = R^-1 (upper triangular), one thread per column, back substitution
+    if (tid < CB) {
+        const int j = tid;
+        X[j * LP + j] = 1.0 / D[j * LP + j];
+        for (int i = j - 1; i >= 0; --i) {
+            double acc = 0.0;
+            for (int m = i + 1; m <= j; ++m) acc += D[i * LP + m] * X[m * LP + j];
+            X[i * LP + j] = -acc / D[i * LP + i];
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        U[e] = X[r * LP + c];
+        if (r < n && c < n) Wt[(r0 + r) * d + r0 + c] = c >= r ? D[r * LP + c] : 0.0;
+    }
+    if (tid == 0 && bad) fail[0] = 1;
+}
+
+// Step k, panel row: Wt[r0 + j][i] <- sum_c U[c][j] Wt[r0 + c][i] for i in [i_lo, d) (= R_kk^-T A[k, i]); the product of
+// eigh_update_kernel on 64 consecutive rows.  grid.x = column chunks of `chunk` (multiple of 64).
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Wt, const double* __restrict__ U, int64_t d, int k, int64_t chunk) {
+    extern __shared__ double lds[];
+    double* Ul = lds;                 // [64 c][UPITCH]  (j contiguous)
+    double* Tl = lds + CB * UPITCH;   // [64 c][UPITCH]  (i contiguous)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = static_cast<int64_t>(k) * CB, i_lo = r0 + CB;
+    const int n = static_cast<int>(min<int64_t>(CB, d - r0));
+    for (int e = tid; e < CB * CB; e += 256) Ul[(e / CB) * UPITCH + (e % CB)] = U[e];
+    const int lrow = tid >> 2, lseg = tid & 3;   // loader: row c of the step, 16-double segment of the tile
+    const int64_t i_begin = i_lo + blockIdx.x * chunk, i_end = min(d, i_begin + chunk);
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
+        double v[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int64_t i = i0 + lseg * 16 + e;
+            v[e] = (lrow < n && i < i_end) ? Wt[(r0 + lrow) * d + i] : 0.0;
+        }
+        __syncthreads();  // previous tile consumed (and U staged, first time round)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) Tl[lrow * UPITCH + lseg * 16 + e] = v[e];
+        __syncthreads();
+        f64x4 acc[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < CB / 4; ++ks) {
+            const int c = ks * 4 + (lane >> 4);
+            const double a = Ul[c * UPITCH + wave * 16 + (lane & 15)];  // A[j][k = c] = U[c][j]
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const double bv = Tl[c * UPITCH + b * 16 + (lane & 15)];  // B[k = c][i]
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int64_t i = i0 + b * 16 + (lane & 15);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int j = wave * 16 + (lane >> 4) + 4 * r;
+                if (j < n && i < i_end) Wt[(r0 + j) * d + i] = acc[b][r];
+            }
+        }
+    }
+}
+
+// Step k, trailing update: Wt[i][j] -= sum_c Wt[r0 + c][i] Wt[r0 + c][j] for the 64 x 64 tiles (ti <= tj) of the part behind the
+// step (a diagonal tile is updated whole: what lands below the diagonal inside it is overwritten with zeros when that block is
+// factored).  grid = (tiles, tiles); tiles with tj < ti return.
+__global__ __launch_bounds__(256) void chol_trailing_kernel(double* __restrict__ Wt, int64_t d, int k) {
+    extern __shared__ double lds[];   // UPDATE_LDS bytes
+    double* Al = lds;                 // [c][i]
+    double* Bl = lds + CB * UPITCH;   // [c][j]
+    if (blockIdx.y < blockIdx.x) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t r0 = static_cast<int64_t>(k) * CB, c0 = r0 + CB;
+    const int n = static_cast<int>(min<int64_t>(CB, d - r0));
+    const int64_t i0 = c0 + static_cast<int64_t>(blockIdx.x) * CB, j0 = c0 + static_cast<int64_t>(blockIdx.y) * CB;
+    const int lrow = tid >> 2, lseg = tid & 3;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int64_t i = i0 + lseg * 16 + e, j = j0 + lseg * 16 + e;
+        Al[lrow * UPITCH + lseg * 16 + e] = (lrow < n && i < d) ? Wt[(r0 + lrow) * d + i] : 0.0;
+        Bl[lrow * UPITCH + lseg * 16 + e] = (lrow < n && j < d) ? Wt[(r0 + lrow) * d + j] : 0.0;
+    }
+    __syncthreads();
+    f64x4 acc[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int ks = 0; ks < CB / 4; ++ks) {
+        const int c = ks * 4 + (lane >> 4);
+        const double a = Al[c * UPITCH + wave * 16 + (lane & 15)];   // A[i][k = c]
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const double bv = Bl[c * UPITCH + b * 16 + (lane & 15)];   // B[k = c][j]
+            acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bv, acc[b], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const int64_t j = j0 + b * 16 + (lane & 15);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t i = i0 + wave * 16 + (lane >> 4) + 4 * r;
+            if (i < d && j < d) Wt[i * d + j] -= acc[b][r];
+        }
+    }
+}
+
+// sigma2[j] = ||row j of Wt||^2;  lam[j] = sigma2[j] - shift
+__global__ __launch_bounds__(EB) void chol_norms_kernel(double* lam, double* sigma2, const double* Wt, int64_t d, const double* frob2,
+                                                        double shift_scale) {
+    __shared__ double scratch[4];
+    const int64_t j = blockIdx.x;
+    double s = 0.0;
+    for (int64_t i = threadIdx.x; i < d; i += EB) s += Wt[j * d + i] * Wt[j * d + i];
+    s = block_sum(s, scratch);
+    if (threadIdx.x == 0) { sigma2[j] = s; lam[j] = s - shift_scale * sqrt(frob2[0]); }
+}
+
+// evecs[order[i], rank_j] = Wt[j, i] / sqrt(sigma2[j])   (eigenvectors in columns, ascending eigenvalues, original row order)
+__global__ void chol_scatter_kernel(double* evecs, const double* Wt, const int* rank, const int* order, const double* sigma2, int64_t d) {
+    __shared__ double tile[32][33];
+    const int64_t j0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+    const int tx = threadIdx.x, ty = threadIdx.y;  // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t j = j0 + r, i = i0 + tx;
+        tile[r][tx] = (j < d && i < d) ? Wt[j * d + i] / sqrt(sigma2[j]) : 0.0;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int64_t i = i0 + r, j = j0 + tx;
+        if (i < d && j < d) evecs[static_cast<int64_t>(order[i]) * d + rank[j]] = tile[tx][r];
     }
 }
 
@@ -635,7 +870,13 @@ int configure_eigh() {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_small_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 static_cast<int>(small_bytes)) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(eigh_update_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                UPDATE_LDS) != hipSuccess)
+                                UPDATE_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(chol_panel_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                UPDATE_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(chol_trailing_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                UPDATE_LDS) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(chol_block_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                CHOL_BLOCK_LDS) != hipSuccess)
             status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
@@ -685,6 +926,77 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
     const bool verbose = getenv("KF_EIGH_VERBOSE") != nullptr;
     if (d == 1) { status = KF_OK; }
 
+    const char* factor_first_env = getenv("KF_EIGH_CHOLESKY");   // "0": the solver that carries V, from the start
+    if (d >= BLOCKED_MIN_D && !(factor_first_env && atoi(factor_first_env) == 0) && getenv("KF_EIGH_SCALAR") == nullptr &&
+        getenv("KF_EIGH_BLOCK8") == nullptr) {
+        // ---- factor-first solver (see chol_* kernels): Cholesky of the diagonally sorted, shifted matrix, blocked Jacobi on the
+        //      rows of R without V.  Scratch in the (unused) V area: diag / sigma2 (d doubles each), order (d ints).
+        const BlockPlan p = block_plan(d);
+        double* partial = frob2_dev + 8;
+        double* Ubuf = partial + static_cast<int64_t>(KP) * KP * p.pairs * p.gsplit;
+        int* pair_flag = reinterpret_cast<int*>(Ubuf + static_cast<int64_t>(KP) * KP * p.pairs);
+        double* diag = Vt;
+        double* sigma2 = Vt + d;
+        int* order = reinterpret_cast<int*>(Vt + 2 * d);
+        int* state = flag;   // {rotated, done, sweeps, cholesky failed}
+        if (hipMemsetAsync(state, 0, 4 * sizeof(int), st) != hipSuccess || hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess)
+            return KF_ERR_LAUNCH_FAILED;
+        const double shift_scale = 4.0 * sqrt(static_cast<double>(d)) * eps;   // shift = shift_scale ||S||_F: above the factorisation's rounding
+        const int is_f64 = cov_dtype == KF_F64 ? 1 : 0;
+        hipLaunchKernelGGL(chol_scan_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(d * d / (EB * 16), 1024)))), dim3(EB), 0,
+                           st, diag, frob2_dev, cov, is_f64, count, d);
+        hipLaunchKernelGGL(chol_order_kernel, dim3(static_cast<unsigned>((d + 255) / 256)), dim3(256), 0, st, order, diag, d);
+        hipLaunchKernelGGL(chol_init_kernel, dim3(g), dim3(256), 0, st, Wt, cov, is_f64, count, d, order, frob2_dev, shift_scale);
+        const int steps = static_cast<int>((d + CB - 1) / CB);
+        for (int k = 0; k < steps; ++k) {
+            hipLaunchKernelGGL(chol_block_kernel, dim3(1), dim3(256), CHOL_BLOCK_LDS, st, Wt, d, k, Ubuf, state + 3);
+            const int64_t rest = d - static_cast<int64_t>(k + 1) * CB;
+            if (rest <= 0) break;
+            const int64_t chunk = 256;   // columns per panel workgroup (4 tiles of 64)
+            hipLaunchKernelGGL(chol_panel_kernel, dim3(static_cast<unsigned>((rest + chunk - 1) / chunk)), dim3(256), UPDATE_LDS, st, Wt, Ubuf, d, k, chunk);
+            const unsigned tiles = static_cast<unsigned>((rest + CB - 1) / CB);
+            hipLaunchKernelGGL(chol_trailing_kernel, dim3(tiles, tiles), dim3(256), UPDATE_LDS, st, Wt, d, k);
+        }
+        int host_state[4] = {0, 0, 0, 0};
+        if (hipMemcpyAsync(host_state, state, 4 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        if (verbose) fprintf(stderr, "[kf_eigh] d=%lld factor-first: cholesky %s\n", static_cast<long long>(d), host_state[3] ? "FAILED" : "ok");
+        if (!host_state[3]) {
+            const int* done = state + 1;
+            int enqueued = 0;
+            while (enqueued < max_sweeps && !host_state[1]) {
+                const int batch = 4;
+                for (int b = 0; b < batch && enqueued < max_sweeps; ++b, ++enqueued) {
+                    for (int r = -1; r < p.players - 1; ++r) {
+                        const int pairing = r < 0 ? 0 : r;
+                        hipLaunchKernelGGL(eigh_gram_kernel, dim3(p.pairs, p.gsplit), dim3(256), 0, st, Wt, partial, d, p.nblocks, p.players,
+                                           pairing, p.gsplit, p.gchunk, done);
+                        // null_scale 0: every column of R has norm >= sqrt(shift) -- no column is "null" here
+                        hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1,
+                                           tol, frob2_dev, 0.0, state, done);
+                        hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
+                                           p.nblocks, p.players, pairing, p.uchunk, done, 0);
+                    }
+                    hipLaunchKernelGGL(eigh_sweep_end_kernel, dim3(1), dim3(1), 0, st, state);
+                }
+                if (hipMemcpyAsync(host_state, state, 3 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+                if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+                if (verbose) fprintf(stderr, "[kf_eigh] d=%lld factor-first: %d sweeps run, done=%d\n", static_cast<long long>(d), host_state[2], host_state[1]);
+            }
+            if (sweeps_done) *sweeps_done = host_state[2];
+            hipLaunchKernelGGL(chol_norms_kernel, dim3(static_cast<unsigned>(d)), dim3(EB), 0, st, lam, sigma2, Wt, d, frob2_dev, shift_scale);
+            hipLaunchKernelGGL(rank_kernel, dim3(static_cast<unsigned>((d + 255) / 256)), dim3(256), 0, st, rank, evals, lam, d);
+            const unsigned tt = static_cast<unsigned>((d + 31) / 32);
+            hipLaunchKernelGGL(chol_scatter_kernel, dim3(tt, tt), dim3(32, 8), 0, st, evecs, Wt, rank, order, sigma2, d);
+            if (hipGetLastError() != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            return host_state[1] ? KF_OK : KF_ERR_NOT_CONVERGED;
+        }
+        // a non-positive pivot: start over with the solver that carries V (Wt / Vt are re-initialised below)
+        hipLaunchKernelGGL(eigh_init_kernel, dim3(g), dim3(256), 0, st, Wt, Vt, cov, is_f64, count, d);
+        if (hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+        hipLaunchKernelGGL(frob2_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(d * d / (EB * 16), 1024)))), dim3(EB), 0,
+                           st, frob2_dev, Wt, d * d);
+    }
     if (d >= BLOCKED_MIN_D && getenv("KF_EIGH_SCALAR") == nullptr && getenv("KF_EIGH_BLOCK8") == nullptr) {
         // ---- blocked solver on the fp64 matrix cores; ||S||_F^2 stays on the device (no host read-back up front)
         const BlockPlan p = block_plan(d);
@@ -708,7 +1020,7 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
                     hipLaunchKernelGGL(eigh_solve_kernel, dim3(p.pairs), dim3(256), 0, st, partial, Ubuf, pair_flag, p.gsplit, r < 0 ? 0 : 1,
                                        tol, frob2_dev, null_scale, state, done);
                     hipLaunchKernelGGL(eigh_update_kernel, dim3(p.pairs, p.usplit), dim3(256), UPDATE_LDS, st, Wt, Vt, Ubuf, pair_flag, d,
-                                       p.nblocks, p.players, pairing, p.uchunk, done);
+                                       p.nblocks, p.players, pairing, p.uchunk, done, 1);
                 }
                 hipLaunchKernelGGL(eigh_sweep_end_kernel, dim3(1), dim3(1), 0, st, state);
             }

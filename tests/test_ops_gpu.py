@@ -217,6 +217,27 @@ def test_eigh_invariants_and_values(ops, d, n):
     assert float((evals.cpu() - want).abs().max() / scale) < 1e-10
 
 
+@pytest.mark.parametrize("d,n", [(256, 600), (512, 200), (770, 3000), (1030, 5000), (1601, 2500)])
+def test_eigh_factor_first(ops, d, n, monkeypatch):
+    """The factor-first solver (default for d >= 256): Cholesky of the diagonally sorted, shifted covariance, then the blocked
+    Jacobi on the factor without V (kf_eigh.hip, chol_* kernels; the algorithm of tools/eigh_jacobi_proto.py).  Same invariants
+    and eigenvalue bound as the solver that carries V (KF_EIGH_CHOLESKY=0), no more sweeps; a rank-deficient fp32 covariance
+    (n < d: the factorisation meets a non-positive pivot and falls back) and ragged sizes (d % 64 != 0) included."""
+    monkeypatch.delenv("KF_EIGH_CHOLESKY", raising=False)
+    x = _rand(n, d).double() * torch.logspace(0, -3, d, dtype=torch.float64)[torch.randperm(d, generator=torch.Generator().manual_seed(d))]
+    cov = (x.t() @ x).float()
+    evals, evecs, sweeps = ops.eigh(cov.to(DEV), float(n))
+    monkeypatch.setenv("KF_EIGH_CHOLESKY", "0")
+    _, _, sweeps_default = ops.eigh(cov.to(DEV), float(n))
+    count = torch.tensor([n])
+    inv = ref.eigh_invariants(cov, count, evals.cpu(), evecs.cpu())
+    assert inv["orthogonality"] < 1e-11 and inv["reconstruction"] < 1e-11 and inv["ascending"] == 0.0, (inv, sweeps)
+    want, _ = ref.eigendecompose(cov.double(), count)
+    assert float((evals.cpu() - want).abs().max() / want.abs().max()) < 1e-10
+    print(f"factor-first d={d} n={n}: {sweeps} sweeps (V-carrying solver {sweeps_default})")
+    assert sweeps <= sweeps_default
+
+
 def test_eigh_fp64_input_and_asymmetric_noise(ops):
     x = _rand(50, 20).double()
     cov = x.t() @ x

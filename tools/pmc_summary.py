@@ -33,11 +33,14 @@ SCORE_KERNELS = SCORE_GEMM + PSG + ("conv_pad_phases_kernel", "pad_grid_kernel",
 
 
 def kernel_source_hash() -> str:
-    """sha256 over the HIP sources and the C header (same function as bench.py's): identifies the code a profile was taken on."""
+    """sha256 over the sources of the kernels the summary reports -- every HIP source and header but the eigensolver's (same
+    function as bench.py's): identifies the code a profile was taken on."""
     digest = hashlib.sha256()
     paths = sorted(glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.h"))
                    + glob.glob(os.path.join(ROOT, "include", "*.h")))
     for path in paths:
+        if os.path.basename(path) == "kf_eigh.hip":
+            continue   # the eigensolver: none of its kernels is in the PMC summary (its evidence is the eigh logs under profiles/)
         with open(path, "rb") as handle:
             digest.update(os.path.basename(path).encode() + b"\0" + handle.read())
     return digest.hexdigest()
@@ -87,6 +90,24 @@ def lambda_call_bytes(kernels: dict):
 
 
 def main() -> None:
+    if sys.argv[1] == "--rehash":  # python tools/pmc_summary.py --rehash <summary.json> <old tree>: the hash FUNCTION changed (a file
+        # was excluded); re-record the hash only if the files it still covers are byte-identical in <old tree> (the tree the
+        # profile was taken on, e.g. a `git worktree` of that commit) and in this one, and drop the rows of the excluded kernels
+        global ROOT
+        with open(sys.argv[2], encoding="utf-8") as handle:
+            summary = json.load(handle)
+        here = kernel_source_hash()
+        keep, ROOT = ROOT, os.path.abspath(sys.argv[3])
+        there = kernel_source_hash()
+        ROOT = keep
+        if here != there:
+            raise SystemExit("the covered sources differ between the two trees: take a new profile instead")
+        summary["kernel_source_sha256"] = here
+        summary["kernels"] = {n: e for n, e in summary["kernels"].items() if "eigh" not in n and "jacobi" not in n}
+        with open(sys.argv[2], "w", encoding="utf-8") as handle:
+            json.dump(summary, handle, indent=1)
+        print(here)
+        return
     if sys.argv[1] == "--recompute":  # python tools/pmc_summary.py --recompute <summary.json>: totals from the kept per-kernel means
         with open(sys.argv[2], encoding="utf-8") as handle:
             summary = json.load(handle)
@@ -136,7 +157,7 @@ def main() -> None:
         "cov_gemm_bytes_per_launch": (cov.get("hbm_read_bytes", 0.0) + cov.get("hbm_write_bytes", 0.0)) if cov else None,
         "cov_gemm_mfma_util": (cov or {}).get("mfma_util"),
         "kernels": {n: e for n, e in kernels.items() if n.startswith(SCORE_KERNELS) or "gemm_bf16" in n or "syrk" in n or "lambda" in n
-                    or "im2col" in n or "eigh" in n or "jacobi" in n or n.startswith("cov_") or n.startswith("rotate_gemm")},
+                    or "im2col" in n or n.startswith("cov_") or n.startswith("rotate_gemm")},
     }
     summary["kf_lambda_bytes_per_launch"], summary["kf_lambda_calls_profiled"], summary["lambda_mfma_util"] = lambda_call_bytes(summary["kernels"])
     with open(out_path, "w", encoding="utf-8") as handle:
