@@ -376,7 +376,7 @@ def tracked_shapes(model) -> List[Tuple[int, int]]:
     return out
 
 
-def _event_summary(events, peak_tflops: float, kernel: str, elapsed_s: Optional[float] = None) -> Optional[dict]:
+def _event_summary(events, peak_tflops: float, kernel: str, elapsed_s: Optional[float] = None, other_kernel_ms: float = 0.0) -> Optional[dict]:
     """Roofline object from ``[(start_event, end_event, algorithmic_flops, algorithmic_bytes)]``."""
     if not events:
         return None
@@ -394,6 +394,9 @@ def _event_summary(events, peak_tflops: float, kernel: str, elapsed_s: Optional[
     }
     if elapsed_s:
         out["kernel_share_of_region"] = (ms * 1e-3) / elapsed_s
+        # the rest of the region: the model's own forward / backward (MIOpen, hipBLASLt, attention), autograd and hook overhead --
+        # outside the hand-written kernels but inside the metric; it caps what faster kernels can buy
+        out["model_share_of_region"] = max(0.0, 1.0 - (ms + other_kernel_ms) * 1e-3 / elapsed_s)
     return out
 
 
@@ -513,7 +516,9 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         comm.EXCHANGE_LOG = {} if (index == passes - 1 and world > 1) else None
         t_cov, (_, cov) = timed(lambda: fit_covariance_matrices_with_loader(model, state, task, factor_loader(), fargs,
                                                                              all_ranks=True, cpu=False))
+        ops.eigh_stats(reset=True)
         t_eig, eig = timed(lambda: perform_eigendecomposition(cov, model, state, fargs, cpu=False))
+        eigh_paths = ops.eigh_stats()   # this rank's share of the 2L problems: factor-first solves / fall-backs / Cholesky retries
         t_lam, (_, lam) = timed(lambda: fit_lambda_matrices_with_loader(model, state, task, factor_loader(), fargs, eig,
                                                                          all_ranks=True, cpu=False))
         fit_times = {"covariance": t_cov, "eigendecomposition": t_eig, "lambda": t_lam}
@@ -632,8 +637,12 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         roofline = _event_summary(score_events.get("pairwise_score", []), peak,
                                   "kf_pairwise_score*: score_r1_kernel (one row per sample) | conv_pad_phases_kernel / "
                                   "transpose_rows_kernel + psg_gemm_v3_kernel / psg_gemm_pp_kernel (per-sample gradients) + "
-                                  "score_gemm_v3_kernel (256 x 256; score_gemm_v2_kernel<TM,TN,W> for the 256 x 128 / 128 x 256 "
-                                  "shapes) (score GEMM; the dominant kernel)", elapsed)
+                                  "score_gemm_v3_kernel (256 x 256; score_gemm_v4_kernel<TA,TB> for the 256 x 128 / 128 x 256 "
+                                  "shapes) (score GEMM; the dominant kernel)", elapsed,
+                                  other_kernel_ms=sum(a.elapsed_time(b) for a, b, _, _ in score_events.get("precondition", [])))
+        if roofline is not None:
+            pre = score_events.get("precondition", [])
+            roofline["precondition_share_of_region"] = sum(a.elapsed_time(b) for a, b, _, _ in pre) * 1e-3 / elapsed if pre else 0.0
         traffic = _pmc_traffic(name)
         if traffic is not None and "stale" in traffic:
             if roofline is not None:
@@ -650,7 +659,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             roofline_cov["traffic"] = traffic["cov_gemm_bytes_per_launch"]
             roofline_cov["traffic_source"] = "the covariance GEMM kernel with the most launches alone (cov_gemm_v3_kernel / cov_gemm_v2_kernel; per launch), same PMC passes as roofline.traffic"
             roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
-        roofline_lambda = _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_accum (factored form: the product of "
+        roofline_lambda = _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_rows_accum / kf_lambda_accum (factored form: the product of "
                                          "the rotated factors, 2 b R O I' flops) | kf_lambda_conv2d_accum (dense form of a Conv2d layer: "
                                          "pad + psg_gemm + rotate_gemm_v3<sumsq>, 2 b R O I' + 2 b O I'^2 flops)", fit_times["lambda"])
         if roofline_lambda is not None and traffic is not None and traffic.get("kf_lambda_bytes_per_launch") is not None:
@@ -680,8 +689,13 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             "roofline_lambda_update": _event_summary(fit_events.get("lambda_update", []), peak, "LambdaTracker backward hook: "
                                                      "rotations / per-sample gradient + squared product; algorithmic flops = F_lambda",
                                                      fit_times["lambda"]),
+            # samples_per_sec divides by ALL of the fit, eigendecomposition included -- a fixed cost per model, so at a bounded
+            # n_fit it is not a rate; the per-sample stages and the fixed seconds are therefore also given apart
             "factor_fit": {"samples_per_sec": n_fit / fit_total, "seconds": fit_times, "n_fit": n_fit,
-                           "eigen_dims": eig_dims},
+                           "eigen_dims": eig_dims, "eigh_paths": eigh_paths,
+                           "covariance_samples_per_sec": n_fit / fit_times["covariance"],
+                           "lambda_samples_per_sec": n_fit / fit_times["lambda"],
+                           "eigendecomposition_fixed_seconds": fit_times["eigendecomposition"]},
             "peak_hbm_gib": round(peak_mem, 1),
             # rank 0's collectives (RCCL over xGMI; all inside the timed regions): seconds are stream time between events
             # around each call -- for the query all-gather only the wait still exposed after overlapping with backward

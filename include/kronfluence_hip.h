@@ -186,11 +186,18 @@ int kf_gemm_bias_out(void* C, int64_t ldc, const kf_view* A, const kf_view* B, c
  * cyclic sweep, rotation applied with v_mfma_f64_16x16x4_f64); convergence -- a sweep without a rotation -- is decided
  * on the device and the kernels of sweeps enqueued past it return at once; the call enqueues sweeps in batches (8, then
  * 4) and synchronises `stream` once per batch to read three ints back.  d < 256: scalar rounds, one read-back per sweep.
+ * d >= 256, default: FACTOR FIRST -- Cholesky of the diagonally sorted matrix plus shift * I, blocked Jacobi on the factor
+ * without V (kf_eigh.hip); the shift is max(4 sqrt(d) eps, noise_rel) * ||S||_F, where noise_rel (ABI 11) is the relative
+ * rounding noise of the covariance AS STORED (0: 2^-20 for an fp32 matrix, none for fp64; pass 2^-8 for a factor that was
+ * exported in bf16); a non-positive pivot retries at 32x the shift twice, then falls back to the solver that carries V.
+ * A covariance with NaN / Inf entries returns KF_ERR_NOT_CONVERGED.
  */
 int64_t kf_eigh_workspace_bytes(int64_t d);
-int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double* evals, double* evecs,
-                void* workspace, int64_t workspace_bytes, int max_sweeps, int* sweeps_done,
-                void* stream);
+int kf_eigh_f64(const void* cov, int cov_dtype, double count, double noise_rel, int64_t d, double* evals, double* evecs,
+                void* workspace, int64_t workspace_bytes, int max_sweeps, int* sweeps_done, void* stream);
+/* Process-wide counters of the d >= 256 path taken by kf_eigh_f64 since the last reset: factor-first solves, fall-backs to the
+ * solver that carries V, and Cholesky retries at a larger shift (ABI 11).  Any pointer may be NULL. */
+void kf_eigh_stats(int64_t* factor_first, int64_t* fallback, int64_t* retries, int reset);
 
 /*
  * Batched eigendecomposition of small symmetric matrices (l <= 96), one workgroup per matrix, all in LDS:
@@ -217,6 +224,25 @@ int kf_eigh_small_batched(const float* G, int64_t batch, int l, float* evals, fl
  */
 int kf_lambda_accum(float* Lambda, int64_t ld_lambda, const void* Gt, const void* At, int64_t ld_at, int dtype,
                     int64_t b, int64_t R, int64_t O, int64_t Ip, float scale, void* stream);
+
+/*
+ * Lambda of a Linear layer on sequences, LDS-DMA engine (ABI 11; bf16 lambda_dtype, R % 64 == 0).  The same mathematics as
+ * kf_lambda_accum (module/tracker/factor.py:218-226 on the factors of module/linear.py:112-122), with the rotated factors
+ * K-CONTIGUOUS PER SAMPLE so that both operands of the per-sample product stream through global_load_lds:
+ *
+ *   kf_rotate_rows_transposed_bf16   out[s][j][r] = sum_k QT[j][k] X[s * R + r][k] (+ bias[j] for j < bias_n)
+ *       X: bf16 [n * R, d] rows (the hooked output gradient or activation of n samples), QT: bf16 [m, ldq] = the transposed
+ *       eigenvector matrix (row j = eigenvector j; only its first d columns are read -- for [A, 1] Qa the ones column is
+ *       the fp32 row bias = Qa[I, :]), out: bf16 [n][m][R].  d % 64 == 0, R % 8 == 0, ldq % 8 == 0.  No workspace.
+ *   kf_lambda_rows_accum             Lambda[o, i] += scale^2 * sum_s ( sum_r GtT[s][o][r] AtT[s][i][r] )^2,  i < Ip
+ *       GtT: bf16 [b][O][R], AtT: bf16 [b][W][R] (W >= Ip rows per sample; rows >= Ip are not used).  One work item is a
+ *       (sample range, 256 x 128 tile); per sample the 64 x 64 wave tiles are squared and summed in registers, one fp32
+ *       atomic per element and item.  No workspace, no synchronisation.
+ */
+int kf_rotate_rows_transposed_bf16(void* out, const void* X, int64_t n, int64_t R, int64_t d, const void* QT, int64_t ldq, int64_t m,
+                                   const float* bias, int64_t bias_n, void* stream);
+int kf_lambda_rows_accum(float* Lambda, int64_t ld_lambda, const void* GtT, const void* AtT, int64_t b, int64_t R, int64_t O,
+                         int64_t W, int64_t Ip, float scale, void* stream);
 
 /*
  * Lambda of a Conv2d layer in the DENSE form (ABI 10): Lambda[o', i'] += scale^2 * sum_n ( Qg^T g_n Qa )[o', i']^2 with the

@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libkronfluence_hip.so"
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 KF_F32, KF_BF16, KF_F16, KF_F64, KF_I64, KF_I32, KF_U8 = range(7)
 
@@ -58,8 +58,11 @@ SIGNATURES = {
     "kf_gemm_out": (_i, [_p, _i, _i64, _i64, ctypes.POINTER(kf_view), ctypes.POINTER(kf_view), _i64, _f, _p]),
     "kf_gemm_bias_out": (_i, [_p, _i64, ctypes.POINTER(kf_view), ctypes.POINTER(kf_view), _p, _i64, _p]),
     "kf_eigh_workspace_bytes": (_i64, [_i64]),
-    "kf_eigh_f64": (_i, [_p, _i, _d, _i64, _p, _p, _p, _i64, _i, ctypes.POINTER(_i), _p]),
+    "kf_eigh_f64": (_i, [_p, _i, _d, _d, _i64, _p, _p, _p, _i64, _i, ctypes.POINTER(_i), _p]),
+    "kf_eigh_stats": (None, [ctypes.POINTER(_i64), ctypes.POINTER(_i64), ctypes.POINTER(_i64), _i]),
     "kf_lambda_accum": (_i, [_p, _i64, _p, _p, _i64, _i, _i64, _i64, _i64, _i64, _f, _p]),
+    "kf_rotate_rows_transposed_bf16": (_i, [_p, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p]),
+    "kf_lambda_rows_accum": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p]),
     "kf_lambda_conv2d_workspace_bytes": (_i64, [_i64] * 5 + [_i] * 8),
     "kf_lambda_conv2d_accum": (_i, [_p, _i64, _p, _p] + [_i64] * 5 + [_i] * 8 + [_p, _i64, _i64, _f, _p, _i64, _p]),
     "kf_inv_lambda": (_i, [_p, _p, _i64, _d, _d, _p, _p]),

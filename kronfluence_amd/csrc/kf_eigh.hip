@@ -15,6 +15,8 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cmath>
 #include <mutex>
 
 #include "../../include/kronfluence_hip.h"
@@ -894,7 +896,18 @@ int64_t kf_eigh_workspace_bytes(int64_t d) {
     return bytes;
 }
 
-int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double* evals, double* evecs, void* workspace,
+namespace {
+std::atomic<int64_t> g_factor_first{0}, g_fallback{0}, g_retries{0};
+}
+
+void kf_eigh_stats(int64_t* factor_first, int64_t* fallback, int64_t* retries, int reset) {
+    if (factor_first) *factor_first = g_factor_first.load();
+    if (fallback) *fallback = g_fallback.load();
+    if (retries) *retries = g_retries.load();
+    if (reset) { g_factor_first = 0; g_fallback = 0; g_retries = 0; }
+}
+
+int kf_eigh_f64(const void* cov, int cov_dtype, double count, double noise_rel, int64_t d, double* evals, double* evecs, void* workspace,
                 int64_t workspace_bytes, int max_sweeps, int* sweeps_done, void* stream) {
     if (!cov || !evals || !evecs || !workspace || d <= 0 || !(count > 0.0)) return KF_ERR_INVALID_ARGUMENT;
     if (cov_dtype != KF_F32 && cov_dtype != KF_F64) return KF_ERR_UNSUPPORTED_DTYPE;
@@ -913,12 +926,17 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
     double* frob2_dev = reinterpret_cast<double*>(tail);
 
     const unsigned g = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>((d * d + 255) / 256, 4096)));
-    hipLaunchKernelGGL(eigh_init_kernel, dim3(g), dim3(256), 0, st, Wt, Vt, cov, cov_dtype == KF_F64 ? 1 : 0, count, d);
-
-    // ||S||_F^2 -> threshold below which a column of W = S V counts as numerically null
-    if (hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-    hipLaunchKernelGGL(frob2_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(d * d / (EB * 16), 1024)))), dim3(EB), 0,
-                       st, frob2_dev, Wt, d * d);
+    const int is_f64 = cov_dtype == KF_F64 ? 1 : 0;
+    // W = S, V = I and ||S||_F^2 (the threshold below which a column of W = S V counts as numerically null) for the solvers that
+    // carry V; the factor-first solver below sets up its own working matrix and only comes here when it gives up
+    auto init_with_v = [&]() -> bool {
+        hipLaunchKernelGGL(eigh_init_kernel, dim3(g), dim3(256), 0, st, Wt, Vt, cov, is_f64, count, d);
+        if (hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess) return false;
+        hipLaunchKernelGGL(frob2_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(d * d / (EB * 16), 1024)))), dim3(EB), 0,
+                           st, frob2_dev, Wt, d * d);
+        return true;
+    };
+    bool initialised = false;
     const double eps = 2.220446049250313e-16;
     const double null_scale = (eps * eps) * static_cast<double>(d);
     const double tol = 4.0 * eps * sqrt(static_cast<double>(d));
@@ -939,29 +957,50 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
         double* sigma2 = Vt + d;
         int* order = reinterpret_cast<int*>(Vt + 2 * d);
         int* state = flag;   // {rotated, done, sweeps, cholesky failed}
-        if (hipMemsetAsync(state, 0, 4 * sizeof(int), st) != hipSuccess || hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess)
+        // The shift must exceed the most negative eigenvalue of the matrix AS STORED.  An exact fp64 covariance needs only the
+        // factorisation's own rounding, 4 sqrt(d) eps ||S||_F; a rank-deficient covariance accumulated / stored in fp32 has noise
+        // eigenvalues of ~ -1e-8 .. -1e-6 ||S||, one exported in bf16 of ~ -2^-9 ||S||: `noise_rel` (0: derived from the dtype)
+        // says which.  The shift is added and subtracted in fp64 and the eigenvectors of S + shift I are those of S, so its
+        // size costs no accuracy in the LAPACK sense (absolute, eps ||S|| / gap: tools/eigh_jacobi_proto.py) -- it
+        // makes the factor BETTER conditioned.  A non-positive pivot retries with 32x the shift (a factorisation is a few
+        // per cent of the solve), twice, before the solver that carries V takes over.
+        const double noise = noise_rel > 0.0 ? noise_rel : (is_f64 ? 0.0 : 9.5367431640625e-07 /* 2^-20 */);
+        const double shift_floor = 4.0 * sqrt(static_cast<double>(d)) * eps;
+        if (hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess || hipMemsetAsync(order, 0, d * sizeof(int), st) != hipSuccess)
             return KF_ERR_LAUNCH_FAILED;
-        const double shift_scale = 4.0 * sqrt(static_cast<double>(d)) * eps;   // shift = shift_scale ||S||_F: above the factorisation's rounding
-        const int is_f64 = cov_dtype == KF_F64 ? 1 : 0;
         hipLaunchKernelGGL(chol_scan_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(d * d / (EB * 16), 1024)))), dim3(EB), 0,
                            st, diag, frob2_dev, cov, is_f64, count, d);
+        // (a NaN diagonal entry has no rank: `order` was zeroed above so that every slot holds a valid index whatever happens)
         hipLaunchKernelGGL(chol_order_kernel, dim3(static_cast<unsigned>((d + 255) / 256)), dim3(256), 0, st, order, diag, d);
-        hipLaunchKernelGGL(chol_init_kernel, dim3(g), dim3(256), 0, st, Wt, cov, is_f64, count, d, order, frob2_dev, shift_scale);
-        const int steps = static_cast<int>((d + CB - 1) / CB);
-        for (int k = 0; k < steps; ++k) {
-            hipLaunchKernelGGL(chol_block_kernel, dim3(1), dim3(256), CHOL_BLOCK_LDS, st, Wt, d, k, Ubuf, state + 3);
-            const int64_t rest = d - static_cast<int64_t>(k + 1) * CB;
-            if (rest <= 0) break;
-            const int64_t chunk = 256;   // columns per panel workgroup (4 tiles of 64)
-            hipLaunchKernelGGL(chol_panel_kernel, dim3(static_cast<unsigned>((rest + chunk - 1) / chunk)), dim3(256), UPDATE_LDS, st, Wt, Ubuf, d, k, chunk);
-            const unsigned tiles = static_cast<unsigned>((rest + CB - 1) / CB);
-            hipLaunchKernelGGL(chol_trailing_kernel, dim3(tiles, tiles), dim3(256), UPDATE_LDS, st, Wt, d, k);
+        int host_state[4] = {0, 0, 0, 1};
+        double shift_scale = std::max(shift_floor, noise);
+        for (int attempt = 0; attempt < 3 && host_state[3]; ++attempt, shift_scale = std::min(shift_scale * 32.0, 0.05)) {
+            if (hipMemsetAsync(state, 0, 4 * sizeof(int), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            hipLaunchKernelGGL(chol_init_kernel, dim3(g), dim3(256), 0, st, Wt, cov, is_f64, count, d, order, frob2_dev, shift_scale);
+            const int steps = static_cast<int>((d + CB - 1) / CB);
+            for (int k = 0; k < steps; ++k) {
+                hipLaunchKernelGGL(chol_block_kernel, dim3(1), dim3(256), CHOL_BLOCK_LDS, st, Wt, d, k, Ubuf, state + 3);
+                const int64_t rest = d - static_cast<int64_t>(k + 1) * CB;
+                if (rest <= 0) break;
+                const int64_t chunk = 256;   // columns per panel workgroup (4 tiles of 64)
+                hipLaunchKernelGGL(chol_panel_kernel, dim3(static_cast<unsigned>((rest + chunk - 1) / chunk)), dim3(256), UPDATE_LDS, st, Wt, Ubuf, d, k, chunk);
+                const unsigned tiles = static_cast<unsigned>((rest + CB - 1) / CB);
+                hipLaunchKernelGGL(chol_trailing_kernel, dim3(tiles, tiles), dim3(256), UPDATE_LDS, st, Wt, d, k);
+            }
+            double frob2_host = 0.0;
+            if (hipMemcpyAsync(host_state, state, 4 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess ||
+                hipMemcpyAsync(&frob2_host, frob2_dev, sizeof(double), hipMemcpyDeviceToHost, st) != hipSuccess)
+                return KF_ERR_LAUNCH_FAILED;
+            if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+            if (verbose)
+                fprintf(stderr, "[kf_eigh] d=%lld factor-first: shift %.2e ||S||_F: cholesky %s\n", static_cast<long long>(d), shift_scale,
+                        host_state[3] ? "FAILED" : "ok");
+            if (!std::isfinite(frob2_host)) return KF_ERR_NOT_CONVERGED;   // NaN / Inf in the covariance (the reference's eigh raises)
+            if (!host_state[3]) break;
+            ++g_retries;
         }
-        int host_state[4] = {0, 0, 0, 0};
-        if (hipMemcpyAsync(host_state, state, 4 * sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-        if (hipStreamSynchronize(st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-        if (verbose) fprintf(stderr, "[kf_eigh] d=%lld factor-first: cholesky %s\n", static_cast<long long>(d), host_state[3] ? "FAILED" : "ok");
         if (!host_state[3]) {
+            ++g_factor_first;
             const int* done = state + 1;
             int enqueued = 0;
             while (enqueued < max_sweeps && !host_state[1]) {
@@ -991,12 +1030,11 @@ int kf_eigh_f64(const void* cov, int cov_dtype, double count, int64_t d, double*
             if (hipGetLastError() != hipSuccess) return KF_ERR_LAUNCH_FAILED;
             return host_state[1] ? KF_OK : KF_ERR_NOT_CONVERGED;
         }
-        // a non-positive pivot: start over with the solver that carries V (Wt / Vt are re-initialised below)
-        hipLaunchKernelGGL(eigh_init_kernel, dim3(g), dim3(256), 0, st, Wt, Vt, cov, is_f64, count, d);
-        if (hipMemsetAsync(frob2_dev, 0, sizeof(double), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-        hipLaunchKernelGGL(frob2_kernel, dim3(static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(d * d / (EB * 16), 1024)))), dim3(EB), 0,
-                           st, frob2_dev, Wt, d * d);
+        // three non-positive pivots: start over with the solver that carries V
+        ++g_fallback;
     }
+    if (!initialised && !init_with_v()) return KF_ERR_LAUNCH_FAILED;
+    initialised = true;
     if (d >= BLOCKED_MIN_D && getenv("KF_EIGH_SCALAR") == nullptr && getenv("KF_EIGH_BLOCK8") == nullptr) {
         // ---- blocked solver on the fp64 matrix cores; ||S||_F^2 stays on the device (no host read-back up front)
         const BlockPlan p = block_plan(d);

@@ -33,6 +33,7 @@
 #include "../../include/kronfluence_hip.h"
 #include "kf_engine.h"
 #include "kf_pingpong.h"
+#include "kf_pingpong64.h"
 
 using namespace kf;
 
@@ -344,6 +345,126 @@ __global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args 
             }
 }
 
+constexpr int PP64_SMEM = pp64::Geo<256, 128>::SMEM_BYTES;   // == Geo<128, 256>::SMEM_BYTES: three stages of 48 KB
+// Round 4: the 256 x 128 / 128 x 256 shapes of the score GEMM on the wave-role-split loop for waves of 64 x 64
+// (kf_pingpong64.h): GPT-2's train batches of 128 sequences, query counts just above a multiple of 256.  Same work items and
+// operand layouts as above.
+template <int TA, int TB>
+__global__ __launch_bounds__(pp64::THREADS) void score_gemm_v4_kernel(ScoreV2Args a) {
+    using G = pp64::Geo<TA, TB>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / G::WB, wn = wave % G::WB;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.ksplit) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int chunk = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int m0 = (tile / a.tiles_n) * TA, n0 = (tile % a.tiles_n) * TB;
+    const int kt_begin = chunk * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
+    if (kt_begin >= kt_end) return;
+
+    pp64::Sources<TA, TB> src;
+    const int64_t kt_a = static_cast<int64_t>(a.M) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
+    const uint16_t* abase = a.A + kt_begin * kt_a;
+    const uint16_t* bbase = a.B + kt_begin * kt_b;
+    pp64::make_sources<TA, TB>(src, wave, lane,
+                               [&](int row) { return abase + static_cast<int64_t>(min(m0 + row, a.M - 1)) * 64; },
+                               [&](int row) { return bbase + static_cast<int64_t>(min(n0 + row, a.N - 1)) * 64; });
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    pp64::PlainCtl ctl;
+    pp64::mainloop<TA, TB>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; }, ctl);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 64 + jn * 32 + (lane & 31);
+                if (m < a.M && n < a.N) atomicAdd(a.C + static_cast<int64_t>(m) * a.ldc + n, a.alpha * acc[i][jn][r]);
+            }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Lambda of a Linear layer on sequences (reference module/linear.py:112-122 + module/tracker/factor.py:218-226):
+//     Lambda[o, i] += scale^2 * sum_n ( sum_r GtT[n][o][r] AtT[n][i][r] )^2
+// over K-contiguous rotated factors GtT[n][O][R], AtT[n][W][R] (kf_rotate_rows_transposed_bf16 writes them).  One work item =
+// (sample range, 256 x 128 tile of Lambda): the k-tiles of all its samples run through the 64 x 64-wave loop WITHOUT a break in
+// the DMA pipeline; at the end of a sample every lane folds its 64 accumulators, squared, into 64 running sums (the first
+// MFMAs of the next sample take C = 0), and the item ends with ONE coalesced fp32 atomic per element.  The round-2 kernel
+// (lambda_bf16_kernel: 128 x 128 register-staged TN tiles) re-read the factors 3.6x and ran at 12 % of the MFMA peak.
+// ------------------------------------------------------------------------------------------------
+struct LambdaRowsArgs {
+    float* L; int64_t ldl;
+    const uint16_t* G; const uint16_t* A;   // [batch][O][R], [batch][W][R]
+    int O, W, Ip, KS;                       // KS = R / 64
+    int batch, tiles_m, tiles_n, zchunk, zblocks;
+    float scale2;
+};
+
+struct LambdaFold {
+    f32x16 (&sum)[2][2];
+    int ks, KS;
+    __device__ __forceinline__ bool first(int) const { return ks == 0; }
+    __device__ __forceinline__ void done(int, f32x16 (&acc)[2][2]) {
+        if (++ks == KS) {   // (wave-uniform) end of a sample
+            ks = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sum[i][jn][r] = fmaf(acc[i][jn][r], acc[i][jn][r], sum[i][jn][r]);
+        }
+    }
+};
+
+__global__ __launch_bounds__(pp64::THREADS) void lambda_rows_kernel(LambdaRowsArgs a) {
+    using G = pp64::Geo<256, 128>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / G::WB, wn = wave % G::WB;
+    // XCD-aware order as the covariance kernels: sample range major, so the tiles of a sample range (which share its rotated
+    // factors) are consecutive items of one XCD
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.zblocks) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int zb = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int m0 = (tile / a.tiles_n) * 256, n0 = (tile % a.tiles_n) * 128;
+    const int z_begin = zb * a.zchunk, z_end = min(a.batch, z_begin + a.zchunk);
+    if (z_begin >= z_end) return;
+
+    const int64_t R = static_cast<int64_t>(a.KS) * 64, stride_g = a.O * R, stride_a = a.W * R;
+    pp64::Sources<256, 128> src;
+    const uint16_t* gbase = a.G + z_begin * stride_g;
+    const uint16_t* abase = a.A + z_begin * stride_a;
+    pp64::make_sources<256, 128>(src, wave, lane,
+                                 [&](int row) { return gbase + static_cast<int64_t>(min(m0 + row, a.O - 1)) * R; },
+                                 [&](int row) { return abase + static_cast<int64_t>(min(n0 + row, a.W - 1)) * R; });
+    const int kshift = (a.KS & (a.KS - 1)) == 0 ? __builtin_ctz(a.KS) : -1;
+    auto split = [&](int t, int& zq, int& ks) { zq = kshift >= 0 ? t >> kshift : t / a.KS; ks = t - zq * a.KS; };
+    f32x16 acc[2][2], sum[2][2];
+    zero_acc(acc);
+    zero_acc(sum);
+    LambdaFold ctl{sum, 0, a.KS};
+    pp64::mainloop<256, 128>(acc, sm, src, (z_end - z_begin) * a.KS, wave, lane,
+                             [&](int t) { int zq, ks; split(t, zq, ks); return zq * stride_g + ks * 64; },
+                             [&](int t) { int zq, ks; split(t, zq, ks); return zq * stride_a + ks * 64; }, ctl);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int o = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int c = n0 + wn * 64 + jn * 32 + (lane & 31);
+                if (o < a.O && c < a.Ip) atomicAdd(a.L + static_cast<int64_t>(o) * a.ldl + c, a.scale2 * sum[i][jn][r]);
+            }
+}
+
 // RotateArgs with two additions: col_add (per output ROW m: the bias row when the roles of the operands are swapped to get a
 // transposed result) and a blocked result layout -- element (m, n) at (n / c_inner) * c_outer + m * c_inner + n % c_inner
 // (c_inner == 0: plain row-major with ldc) -- which is how "Gt^T[n][o][r]" (K-contiguous per sample) is written.
@@ -443,6 +564,15 @@ __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Arg
                 *reinterpret_cast<u32x4*>(a.C + col + m * row_stride) = *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ch ^ (ml & 31)) << 4));
         }
     }
+}
+
+// 256 x 128 / 128 x 256 score shapes: 4 = wave-role-split loop of kf_pingpong64.h (round 4), 2 = the round-2 lock-step loop
+// (KF_ENGINE=2 or KF_HALF_TILE_ENGINE=2: A/B measurements, fallback)
+inline int engine_generation();
+inline int half_tile_engine() {
+    const char* e = getenv("KF_HALF_TILE_ENGINE");
+    if (e && atoi(e) == 2) return 2;
+    return engine_generation() == 3 ? 4 : 2;
 }
 
 inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A/B measurements, fallback)
@@ -1304,6 +1434,9 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
@@ -1329,6 +1462,7 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     int shape = 0;
     if (area[1] * 115 < area[shape] * 100) shape = 1;
     if (area[2] * 115 < (shape == 0 ? area[0] * 100 : area[1] * 115)) shape = 2;
+    if (const char* e = getenv("KF_SCORE_SHAPE")) shape = std::min(2, std::max(0, atoi(e)));   // measurements only
     const int tm = shape == 2 ? 128 : 256, tn = shape == 1 ? 128 : 256;
     s.tiles_m = static_cast<int>(cdiv(Q, tm)); s.tiles_n = static_cast<int>(cdiv(b, tn));
     const int64_t tiles = static_cast<int64_t>(s.tiles_m) * s.tiles_n;
@@ -1342,6 +1476,10 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     const dim3 grid(static_cast<unsigned>(8 * cdiv(ksplit * tiles, 8)));
     if (shape == 0 && engine_generation() == 3) hipLaunchKernelGGL(score_gemm_v3_kernel, grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, s);
     else if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
+    else if (shape == 1 && half_tile_engine() == 4)
+        hipLaunchKernelGGL((score_gemm_v4_kernel<256, 128>), grid, dim3(pp64::THREADS), PP64_SMEM, st, s);
+    else if (half_tile_engine() == 4)
+        hipLaunchKernelGGL((score_gemm_v4_kernel<128, 256>), grid, dim3(pp64::THREADS), PP64_SMEM, st, s);
     else if (shape == 1) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 128, 4>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     else hipLaunchKernelGGL((score_gemm_v2_kernel<128, 256, 2>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     return launch_status();
@@ -1693,6 +1831,54 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
     int rc = launch_psg_v2(g, st);
     if (rc != KF_OK) return rc;
     return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
+}
+
+int kf_rotate_rows_transposed_bf16(void* out, const void* X, int64_t n, int64_t R, int64_t d, const void* QT, int64_t ldq, int64_t m,
+                                   const float* bias, int64_t bias_n, void* stream) {
+    if (!out || !X || !QT || n < 0 || R <= 0 || d <= 0 || m <= 0 || ldq < d || bias_n < 0 || bias_n > m || (bias_n > 0 && !bias))
+        return KF_ERR_INVALID_ARGUMENT;
+    if (d % 64 != 0 || R % 8 != 0 || ldq % 8 != 0 || m * R + 64 >= (1LL << 31) ||
+        ((reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(QT)) & 15) != 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    if (n == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    // roles swapped (tile rows = rows of Q^T, tile columns = the n R rows of X): the blocked epilogue writes element
+    // (m', (sample, r)) at sample * m R + m' R + r, i.e. K-contiguous per sample
+    return launch_rotate_blocked(reinterpret_cast<uint16_t*>(out), reinterpret_cast<const uint16_t*>(QT), ldq,
+                                 reinterpret_cast<const uint16_t*>(X), d, m, n * R, d, 1.0f, bias_n > 0 ? bias : nullptr,
+                                 static_cast<int>(bias_n), R, m * R, as_stream(stream));
+}
+
+int kf_lambda_rows_accum(float* Lambda, int64_t ld_lambda, const void* GtT, const void* AtT, int64_t b, int64_t R, int64_t O, int64_t W,
+                         int64_t Ip, float scale, void* stream) {
+    if (!Lambda || !GtT || !AtT || b < 0 || R <= 0 || O <= 0 || W <= 0 || Ip <= 0 || Ip > W || ld_lambda < Ip) return KF_ERR_INVALID_ARGUMENT;
+    if (R % 64 != 0 || ((reinterpret_cast<uintptr_t>(GtT) | reinterpret_cast<uintptr_t>(AtT)) & 15) != 0 || O >= (1LL << 24) ||
+        W >= (1LL << 24) || b * (R / 64) >= (1LL << 30))
+        return KF_ERR_INVALID_ARGUMENT;
+    if (b == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    LambdaRowsArgs a;
+    a.L = Lambda; a.ldl = ld_lambda; a.G = reinterpret_cast<const uint16_t*>(GtT); a.A = reinterpret_cast<const uint16_t*>(AtT);
+    a.O = static_cast<int>(O); a.W = static_cast<int>(W); a.Ip = static_cast<int>(Ip); a.KS = static_cast<int>(R / 64);
+    a.batch = static_cast<int>(b); a.tiles_m = static_cast<int>(cdiv(O, 256)); a.tiles_n = static_cast<int>(cdiv(Ip, 128));
+    a.scale2 = scale * scale;
+    // one workgroup per CU (144 KB of LDS): items run in rounds of 256.  Split the samples so that the last round is nearly full;
+    // among 1-4 rounds take the cheapest by (k-tiles per item + ~6 k-tiles for the prologue and the 32 K atomics of an item).
+    const int64_t tiles = static_cast<int64_t>(a.tiles_m) * a.tiles_n;
+    int64_t zblocks = 1, best = INT64_MAX;
+    a.zchunk = a.batch;
+    for (int rounds = 1; rounds <= 4; ++rounds) {
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>(b, rounds * 256 / tiles));
+        const int64_t chunk = cdiv(b, want), blocks = cdiv(b, chunk);
+        const int64_t cost = cdiv(blocks * tiles, 256) * (chunk * a.KS + 6);
+        if (cost < best) { best = cost; zblocks = blocks; a.zchunk = static_cast<int>(chunk); }
+    }
+    a.zblocks = static_cast<int>(zblocks);
+    const int64_t blocks = 8 * cdiv(zblocks * tiles, 8);
+    if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(lambda_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(pp64::THREADS), PP64_SMEM,
+                       as_stream(stream), a);
+    return launch_status();
 }
 
 int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int append_ones) {

@@ -109,9 +109,10 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
         module_name, cov_name, count_name, _vec, _val = job
         with (torch.cuda.stream(stream) if stream is not None else contextlib.nullcontext()):
             work = covariance_factors[cov_name][module_name].to(device=state.device)
+            noise = ops.STORAGE_NOISE.get(work.dtype, 0.0)   # a bf16-exported factor: the eigensolver's shift must clear its rounding
             if work.dtype not in (torch.float32, torch.float64):
                 work = work.to(torch.float32)
-            evals, evecs, _ = ops.eigh(work, float(covariance_factors[count_name][module_name].item()))
+            evals, evecs, _ = ops.eigh(work, float(covariance_factors[count_name][module_name].item()), noise_rel=noise)
         return evals, evecs
 
     # The eigenproblems are independent and one Jacobi round kernel is latency / L2 bound far below the chip's

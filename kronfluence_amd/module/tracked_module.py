@@ -97,6 +97,10 @@ class TrackedModule(nn.Module):
         # how many query gradients the score stage is about to hold in this module (None: unknown) -- lets the
         # PreconditionTracker make one allocation per layer (QueryBuffer)
         self.query_capacity: Optional[int] = None
+        # True only while the pairwise query loop of a multi-rank job is running: the PreconditionTracker may then issue the
+        # all-gather of a freshly preconditioned block from the backward hook (the loop calls ``synchronize`` after every query
+        # batch).  Every other user of PRECONDITION_GRADIENT mode (self-influence with measurement, ...) exchanges nothing.
+        self.async_query_gather: bool = False
         self.storage: Dict[str, Any] = {}
         for key in (COVARIANCE_FACTOR_NAMES + EIGENDECOMPOSITION_FACTOR_NAMES + LAMBDA_FACTOR_NAMES
                     + [AGGREGATED_GRADIENT_NAME, PRECONDITIONED_GRADIENT_NAME,

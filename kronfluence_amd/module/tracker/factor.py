@@ -118,6 +118,9 @@ class LambdaTracker(BaseTracker):
     # Q_A whose epilogue squares and sums -- instead of rotating the [b R, I'] patch matrix: fewer flops (SURVEY.md 8d:
     # F_lambda is the cheaper of the two exact forms) and no patch tensor.  ``kf_lambda_conv2d_accum``.
     CONV_DENSE = True
+    # Linear layers on sequences with whole 64-deep k-tiles (O, I, R multiples of 64: every transformer config): rotations
+    # written K-contiguous per sample + ``kf_lambda_rows_accum`` (round 4).  False selects the round-2 kernel (A/B, tests).
+    ROWS_ENGINE = True
 
     @staticmethod
     def algorithmic_flops(r: int, o: int, ip: int) -> float:
@@ -193,6 +196,13 @@ class LambdaTracker(BaseTracker):
                 self._bf16_eigenvectors = (qa_t, q_g.t().contiguous().to(torch.bfloat16),
                                            q_a[i].contiguous() if append_ones else None)
             qa_t, qg_t, bias_row = self._bf16_eigenvectors
+            if self.ROWS_ENGINE and ops.lambda_rows_eligible(o, i, r):
+                # round 4: both rotations written K-contiguous per sample, the per-sample product + square + sum over
+                # samples on the LDS-DMA engine (kf_lambda_rows_accum) -- the factors are read once
+                gt_t = ops.rotate_rows_transposed(g, qg_t)
+                at_t = ops.rotate_rows_transposed(a, qa_t, bias_row)
+                ops.lambda_rows_accum(storage[LAMBDA_MATRIX_NAME], gt_t, at_t, scale=module.gradient_scale)
+                return
             gt = ops.rotate_bf16(g.reshape(b * r, o), qg_t)
             at = ops.rotate_bf16(a.reshape(b * r, i), qa_t, bias_row)
             ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)

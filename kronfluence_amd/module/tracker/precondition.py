@@ -39,7 +39,9 @@ class PreconditionTracker(BaseTracker):
     # Multi-GPU: the all-gather of a layer's block (C4, reference precondition.py:181-201) is ISSUED from the backward hook
     # that produced it, asynchronously -- it travels over xGMI while autograd runs the remaining layers' backward and their
     # preconditioners -- and ``synchronize`` only waits for it and interleaves.  All ranks run the same graph, so the
-    # collectives are issued in the same order everywhere.
+    # collectives are issued in the same order everywhere.  Opt-in per stage: only the pairwise query loop, which follows every
+    # query batch with ``synchronize`` and whose strided sampler gives all ranks equal blocks, sets
+    # ``module.async_query_gather`` (multi-GPU self-influence with measurement runs in this mode too and exchanges nothing).
     ASYNC_QUERY_GATHER = True
     _pending = None  # (work, gathered, local) of the all-gather in flight
     _held_layout = None  # (block shape, query_padding, queries_in_eigenbasis) of the blocks accumulated so far
@@ -88,7 +90,10 @@ class PreconditionTracker(BaseTracker):
             preconditioned = preconditioned.to(self._out_dtype())
         preconditioned = preconditioned.contiguous()
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = preconditioned
-        if from_hook and self.ASYNC_QUERY_GATHER and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if (from_hook and self.ASYNC_QUERY_GATHER and self.module.async_query_gather and dist.is_available() and dist.is_initialized()
+                and dist.get_world_size() > 1):
+            if self._pending is not None:   # never drop a collective in flight
+                self._pending[0].wait()
             local = preconditioned
             world = dist.get_world_size()
             gathered = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -236,14 +241,38 @@ class PreconditionTracker(BaseTracker):
             layout = (tuple(new.shape[1:]), self.module.query_padding, self.module.queries_in_eigenbasis)
             if layout != self._held_layout:
                 shape, padding, eigen = self._held_layout
-                if eigen != layout[2] or tuple(new.shape[1:-1]) != shape[:-1] or new.shape[-1] - layout[1] != shape[-1] - padding:
+                if tuple(new.shape[1:-1]) != shape[:-1] or new.shape[-1] - layout[1] != shape[-1] - padding:
                     raise RuntimeError(
-                        f"Module '{self.module.name}': query batches produced preconditioned gradients in different layouts "
-                        f"({self._held_layout} then {layout}); use query batches of one kind per score call.")
-                new = torch.nn.functional.pad(new[..., :new.shape[-1] - layout[1]], (0, padding))
-                self.module.query_padding = padding
+                        f"Module '{self.module.name}': query batches produced preconditioned gradients of different shapes "
+                        f"({self._held_layout} then {layout}).")
+                # a later query batch laid out differently (a one-row batch among sequence batches: eigenbasis-resident,
+                # unpadded fp32 against padded bf16 parameter-space blocks, or the other way round) is brought to the held
+                # layout -- the reference accepts such mixes (precondition.py:203-240)
+                new = new[..., :new.shape[-1] - layout[1]]
+                if eigen != layout[2]:
+                    new = self._change_basis(new, into_eigenbasis=eigen)
+                if new.dtype != held.dtype:
+                    new = new.to(held.dtype)
+                new = torch.nn.functional.pad(new, (0, padding))
+                self.module.query_padding, self.module.queries_in_eigenbasis = padding, eigen
             held.append(new.contiguous())
         storage[PRECONDITIONED_GRADIENT_NAME] = None
+
+    def _change_basis(self, block: torch.Tensor, into_eigenbasis: bool) -> torch.Tensor:
+        """``Q_G^T P Q_A`` (parameter space -> eigenbasis) or ``Q_G M Q_A^T`` (back) for a ``[q, O, I']`` block, fp32."""
+        storage = self.module.storage
+        q_a, q_g = storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
+        block = block.to(torch.float32).contiguous()
+        q, o, ip = block.shape
+        t1 = torch.empty((q * o, ip), dtype=torch.float32, device=block.device)
+        out = torch.empty((q, o, ip), dtype=torch.float32, device=block.device)
+        if into_eigenbasis:
+            ops.gemm(t1, ip, 0, ops.view(block, 0, ip, 1, q * o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
+            ops.gemm(out, ip, o * ip, ops.view(q_g, 0, 1, o, o, o), ops.view(t1, o * ip, 1, ip, ip, o), batch=q)
+        else:
+            ops.gemm(t1, ip, 0, ops.view(block, 0, ip, 1, q * o, ip), ops.view(q_a, 0, ip, 1, ip, ip))
+            ops.gemm(out, ip, o * ip, ops.view(q_g, 0, o, 1, o, o), ops.view(t1, o * ip, 1, ip, ip, o), batch=q)
+        return out
 
     @torch.no_grad()
     def finalize_all_iterations(self) -> None:
@@ -266,6 +295,7 @@ class PreconditionTracker(BaseTracker):
             self._pending[0].wait()
             self._pending = None
         self._bf16_q = None
+        self._held_layout = None
         self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = None
         self.clear_all_cache()

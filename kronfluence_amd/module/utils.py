@@ -211,6 +211,13 @@ def set_query_capacity(model: nn.Module, tracked_module_names: Optional[List[str
         m.query_capacity = capacity
 
 
+def set_async_query_gather(model: nn.Module, tracked_module_names: Optional[List[str]], enabled: bool) -> None:
+    """Lets (or stops letting) the PreconditionTrackers issue their query all-gather from the backward hook; set by the
+    pairwise query loop only, around the passes it follows with ``synchronize_modules``."""
+    for m in _tracked(model, tracked_module_names):
+        m.async_query_gather = enabled
+
+
 def truncate(model: nn.Module, tracked_module_names: List[str], keep_size: int) -> None:
     for m in _tracked(model, tracked_module_names):
         m.truncate(keep_size=keep_size)

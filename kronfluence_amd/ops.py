@@ -325,7 +325,20 @@ def per_sample_gradient(g: torch.Tensor, a: torch.Tensor, append_ones: bool) -> 
 # ---------------------------------------------------------------------------------------------
 # Stage 2: eigendecomposition, Lambda
 # ---------------------------------------------------------------------------------------------
-def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0) -> Tuple[torch.Tensor, torch.Tensor, int]:
+def eigh_stats(reset: bool = False) -> dict:
+    """Paths ``eigh`` took for ``d >= 256`` since the last reset (kf_eigh_stats): factor-first solves, fall-backs to the
+    solver that carries V, Cholesky retries at a larger shift."""
+    first, fallback, retries = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    nat.lib().kf_eigh_stats(ctypes.byref(first), ctypes.byref(fallback), ctypes.byref(retries), int(reset))
+    return {"factor_first": first.value, "fallback": fallback.value, "cholesky_retries": retries.value}
+
+
+# relative rounding noise of a covariance by the dtype it was STORED in (``eigh(noise_rel=...)``): sizes the shift of the
+# factor-first eigensolver (kf_eigh_f64).  fp32 / fp64: the library's defaults.
+STORAGE_NOISE = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -10}
+
+
+def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0, noise_rel: float = 0.0) -> Tuple[torch.Tensor, torch.Tensor, int]:
     """fp64 ``eigh(0.5 (cov + cov^T) / count)`` (factor/eigen.py:193-205) -> (evals, evecs, sweeps)."""
     nat.require_device(cov, "cov")
     _require(cov.dim() == 2 and cov.shape[0] == cov.shape[1] and cov.dtype in (torch.float32, torch.float64), 'cov.dim() == 2 and cov.shape[0] == cov.shape[1] and cov.dtype in (torch.float32, torch.float64)')
@@ -337,7 +350,7 @@ def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0) -> Tuple[torch.Te
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=cov.device)
     sweeps = ctypes.c_int(0)
     nat.check(
-        nat.lib().kf_eigh_f64(cov.data_ptr(), nat.dtype_code(cov.dtype), float(count), d, evals.data_ptr(), evecs.data_ptr(),
+        nat.lib().kf_eigh_f64(cov.data_ptr(), nat.dtype_code(cov.dtype), float(count), float(noise_rel), d, evals.data_ptr(), evecs.data_ptr(),
                               ws.data_ptr(), ws_bytes, max_sweeps, ctypes.byref(sweeps), nat.stream_ptr(cov.device)),
         "kf_eigh_f64",
     )
@@ -440,6 +453,52 @@ def lambda_accum(lam: torch.Tensor, gt: torch.Tensor, at: torch.Tensor, b: int, 
             nat.lib().kf_lambda_accum(lam.data_ptr(), ip, gt.data_ptr(), at.data_ptr(), ld_at, nat.dtype_code(gt.dtype), b, r, o, ip,
                                       scale, nat.stream_ptr(lam.device)),
             "kf_lambda_accum",
+        )
+
+
+def rotate_rows_transposed(x: torch.Tensor, q_t: torch.Tensor, bias_row: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``out[s, j, r] = sum_k q_t[j, k] x[s, r, k] (+ bias_row[j])`` for ``x: [n, R, d]`` bf16 and ``q_t``: contiguous bf16
+    ``[m, ld]`` holding the transposed eigenvector matrix in its first ``d`` columns -> bf16 ``[n, m, R]``: the eigenbasis
+    rotation of ``rotate_bf16`` written K-contiguous per sample, the operand layout of ``lambda_rows_accum``
+    (kf_rotate_rows_transposed_bf16)."""
+    nat.require_device(x, "x")
+    x, q_t = _contig(x), _contig(q_t)
+    n, r, d = x.shape
+    m, ld = q_t.shape
+    _require(x.dtype == q_t.dtype == torch.bfloat16 and ld >= d, "rotate_rows_transposed: bf16 operands, ld >= d")
+    if bias_row is not None:
+        bias_row = _contig(bias_row)
+        _require(bias_row.dtype == torch.float32 and bias_row.numel() <= m, "rotate_rows_transposed: fp32 bias of <= m entries")
+    out = torch.empty((n, m, r), dtype=torch.bfloat16, device=x.device)
+    nat.check(
+        nat.lib().kf_rotate_rows_transposed_bf16(out.data_ptr(), x.data_ptr(), n, r, d, q_t.data_ptr(), ld, m, _ptr(bias_row),
+                                                 bias_row.numel() if bias_row is not None else 0, nat.stream_ptr(x.device)),
+        "kf_rotate_rows_transposed_bf16",
+    )
+    return out
+
+
+def lambda_rows_eligible(o: int, i: int, r: int) -> bool:
+    """Shapes ``lambda_rows_accum`` (and the rotations that feed it) take: whole 64-deep k-tiles in all three contractions."""
+    return o % 64 == 0 and i % 64 == 0 and r % 64 == 0 and o >= 128 and i >= 64
+
+
+def lambda_rows_accum(lam: torch.Tensor, gt_t: torch.Tensor, at_t: torch.Tensor, scale: float = 1.0) -> None:
+    """``lam[o, i] += scale^2 * sum_s (sum_r gt_t[s, o, r] at_t[s, i, r])^2`` (kf_lambda_rows_accum): the Lambda update of
+    tracker/factor.py:218-226 from K-contiguous rotated factors ``gt_t: [b, O, R]``, ``at_t: [b, W, R]`` (``W >= I'``)."""
+    nat.require_device(lam, "lam")
+    nat.require_device(gt_t, "gt_t")
+    _require(lam.dtype == torch.float32 and lam.is_contiguous() and gt_t.dtype == at_t.dtype == torch.bfloat16
+             and gt_t.is_contiguous() and at_t.is_contiguous(), "lambda_rows_accum: fp32 Lambda, contiguous bf16 factors")
+    o, ip = lam.shape
+    b, o2, r = gt_t.shape
+    w = at_t.shape[1]
+    _require(o2 == o and at_t.shape[0] == b and at_t.shape[2] == r and w >= ip, "lambda_rows_accum: shapes")
+    with _Timed("lambda_accum", lam.device, 2.0 * b * r * o * ip, float(b) * r * (o + ip) * 2):
+        nat.check(
+            nat.lib().kf_lambda_rows_accum(lam.data_ptr(), ip, gt_t.data_ptr(), at_t.data_ptr(), b, r, o, w, ip, scale,
+                                           nat.stream_ptr(lam.device)),
+            "kf_lambda_rows_accum",
         )
 
 
@@ -555,14 +614,16 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     out = torch.empty((q, o, width), dtype=out_dtype, device=g.device)
     ws_bytes = nat.lib().kf_precondition_workspace_bytes(q, r, o, ip)
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
-    nat.check(
-        nat.lib().kf_precondition(out.data_ptr(), nat.dtype_code(out_dtype), width, g.data_ptr(), a.data_ptr(),
-                                  nat.dtype_code(g.dtype), q, r, o, i,
-                                  int(append_ones), q_g.data_ptr(), q_a.data_ptr(), lam_inv.data_ptr(), scale,
-                                  _ptr(q_a_bf16), _ptr(q_g_t_bf16), _ptr(q_a_t_bf16), ldq, ws.data_ptr(), ws_bytes,
-                                  nat.stream_ptr(g.device)),
-        "kf_precondition",
-    )
+    flops = 2.0 * q * r * (o * o + i * ip) + (2.0 * q * r * o * ip if r > 1 else 0.0) + 2.0 * q * o * ip * (ip + o)
+    with _Timed("precondition", g.device, flops, float(q) * (r * (o + i) * g.element_size() + o * width * out.element_size())):
+        nat.check(
+            nat.lib().kf_precondition(out.data_ptr(), nat.dtype_code(out_dtype), width, g.data_ptr(), a.data_ptr(),
+                                      nat.dtype_code(g.dtype), q, r, o, i,
+                                      int(append_ones), q_g.data_ptr(), q_a.data_ptr(), lam_inv.data_ptr(), scale,
+                                      _ptr(q_a_bf16), _ptr(q_g_t_bf16), _ptr(q_a_t_bf16), ldq, ws.data_ptr(), ws_bytes,
+                                      nat.stream_ptr(g.device)),
+            "kf_precondition",
+        )
     return out
 
 

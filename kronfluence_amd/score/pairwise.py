@@ -16,7 +16,8 @@ from kronfluence_amd.factor.covariance import _loss_scale
 from kronfluence_amd.module.tracked_module import ModuleMode
 from kronfluence_amd.module.utils import (
     accumulate_iterations, finalize_all_iterations, finalize_iteration, get_tracked_module_names, prepare_modules,
-    set_factors, set_gradient_scale, set_mode, set_query_capacity, synchronize_modules, truncate, update_factor_args,
+    set_async_query_gather, set_factors, set_gradient_scale, set_mode, set_query_capacity, synchronize_modules, truncate,
+    update_factor_args,
     update_score_args,
 )
 from kronfluence_amd.score.dot_product import (
@@ -79,6 +80,7 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
     remaining = len(query_loader.dataset)  # queries still to be preconditioned (each rank ends up holding all of them)
     window = score_args.query_gradient_accumulation_steps * total_query_batch_size
     set_query_capacity(model, tracked_module_names, min(window, remaining))
+    set_async_query_gather(model, tracked_module_names, bool(state.use_distributed))
     try:
         for query_index, query_batch in enumerate(query_loader):
             query_batch = send_to_device(query_batch, state.device)
@@ -112,6 +114,7 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
             set_query_capacity(model, tracked_module_names, min(window, max(remaining, 0)))
     finally:
         set_query_capacity(model, tracked_module_names, None)  # also when the score loop raises
+        set_async_query_gather(model, tracked_module_names, False)
 
     total: SCORE_TYPE = {}
     if state.is_main_process:

@@ -99,7 +99,7 @@ def im2col(x, conv, append_ones, out_dtype=torch.float32):
     return patches.to(out_dtype).contiguous()
 
 
-def eigh(cov, count, max_sweeps=0):
+def eigh(cov, count, max_sweeps=0, noise_rel=0.0):
     sym = cov.double() / count
     sym = 0.5 * (sym + sym.t())
     evals, evecs = torch.linalg.eigh(sym)
@@ -116,6 +116,20 @@ def eigh_small(g, inv_sqrt=False, floor_rel=1e-12):
         scale = torch.where(clipped > 0, clipped.rsqrt(), torch.zeros_like(clipped))
         evecs = evecs * scale.unsqueeze(1)
     return evals.float(), evecs.float().contiguous()
+
+
+def eigh_stats(reset=False):
+    return {"factor_first": 0, "fallback": 0, "cholesky_retries": 0}
+
+
+def rotate_rows_transposed(x, q_t, bias_row=None):
+    n, r, d = x.shape
+    return rotate_bf16(x.reshape(n * r, d), q_t, bias_row).reshape(n, r, -1).transpose(1, 2).contiguous()
+
+
+def lambda_rows_accum(lam, gt_t, at_t, scale=1.0) -> None:
+    b, o, r = gt_t.shape
+    lambda_accum(lam, gt_t.transpose(1, 2).contiguous(), at_t.transpose(1, 2).contiguous(), b, r, scale)
 
 
 def lambda_accum(lam, gt, at, b, r, scale=1.0) -> None:
@@ -195,7 +209,7 @@ def cast(src, dtype):
     return src.to(dtype).clone()
 
 
-LEAVES = ("view", "gemm", "rotate_bf16", "syrk_accum", "im2col", "eigh", "eigh_small", "lambda_accum", "inv_lambda", "precondition",
+LEAVES = ("view", "gemm", "rotate_bf16", "rotate_rows_transposed", "lambda_rows_accum", "eigh_stats", "syrk_accum", "im2col", "eigh", "eigh_small", "lambda_accum", "inv_lambda", "precondition",
           "pairwise_score", "conv2d_cov_geometry", "conv2d_score_geometry", "pairwise_score_conv2d", "pairwise_score_rows", "rowwise_dot", "mul_bcast", "cast")
 
 

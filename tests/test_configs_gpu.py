@@ -257,6 +257,85 @@ def test_eigh_transformer_sizes(d):
     assert inv["orthogonality"] <= 1e-11 and inv["reconstruction"] <= 1e-11 and inv["ascending"] == 0.0, inv
 
 
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
+@pytest.mark.parametrize("n_seq", [2, 24])
+def test_eigh_factor_first_fires_on_product_covariances(storage, n_seq):
+    """The factor-first eigensolver on covariances the PRODUCT's covariance stage makes (not synthetic fp64-exact ones): a sequence
+    model with 320- / 1280-wide Linear layers (bias: d = 321 / 1281; 640 wide gradients), fitted on 2 sequences (128 rows: every
+    factor rank deficient, its smallest eigenvalues are rounding noise below zero) and on 24 (full rank), exported in fp32 or in
+    bf16 (GPT-2's ``low_cov`` preset).  Asserts, per factor: the E2 invariants and LAPACK's eigenvalues on the matrix AS STORED
+    -- and, through ``kf_eigh_stats``, that the Cholesky path was TAKEN for every one of them (round 3 fell back silently on
+    exactly these matrices: its shift sat 1e6x below the storage noise)."""
+    from kronfluence_amd import FactorArguments, Task, ops, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    torch.manual_seed(7)
+    width, inner, t = 320, 1280, 64
+    model = nn.Sequential(nn.Linear(width, inner), nn.GELU(), nn.Linear(inner, 640), nn.Tanh(), nn.Linear(640, width))
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            x, y = batch
+            return torch.nn.functional.mse_loss(model(x), y, reduction="sum")
+
+        def compute_measurement(self, batch, model):
+            return self.compute_train_loss(batch, model)
+
+    state = State()
+    task = T()
+    prepared = prepare_model(model, task).to(state.device)
+    gen = torch.Generator().manual_seed(3)
+    scale = torch.logspace(0, -2, width)
+    x = (torch.randn(n_seq, t, width, generator=gen) * scale).to(state.device)
+    y = torch.randn(n_seq, t, width, generator=gen).to(state.device)
+    low = storage == "bf16"
+    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16 if low else None,
+                            activation_covariance_dtype=torch.bfloat16 if low else torch.float32,
+                            gradient_covariance_dtype=torch.bfloat16 if low else torch.float32)
+    _, cov = fit_covariance_matrices_with_loader(prepared, state, task, ResidentLoader((x, y), 2), fargs)
+    ops.eigh_stats(reset=True)
+    solved = 0
+    for cov_name, count_name in (("activation_covariance", "num_activation_covariance_processed"),
+                                 ("gradient_covariance", "num_gradient_covariance_processed")):
+        for module, stored in cov[cov_name].items():
+            d = stored.shape[0]
+            assert d >= 256 and stored.dtype == (torch.bfloat16 if low else torch.float32)
+            count = float(cov[count_name][module].item())
+            work = stored.to(state.device).float()
+            evals, evecs, sweeps = ops.eigh(work, count, noise_rel=ops.STORAGE_NOISE.get(stored.dtype, 0.0))
+            c = work.double().cpu() / count
+            c = 0.5 * (c + c.t())
+            want = torch.linalg.eigvalsh(c)
+            lam, q = evals.cpu(), evecs.cpu()
+            top = float(want.abs().max())
+            assert float((lam - want).abs().max()) <= 1e-10 * top, (module, cov_name, float((lam - want).abs().max()) / top)
+            inv = ref.eigh_invariants(work.cpu(), torch.tensor([count]), lam, q)
+            assert inv["orthogonality"] <= 1e-11 and inv["reconstruction"] <= 1e-11 and inv["ascending"] == 0.0, (module, inv, sweeps)
+            solved += 1
+    stats = ops.eigh_stats()
+    print(f"eigh paths ({storage}, {n_seq} sequences): {stats}")
+    assert solved == 6 and stats["factor_first"] == solved and stats["fallback"] == 0, stats
+
+
+def test_eigh_nan_covariance_is_an_error_not_a_fault():
+    """A covariance with NaN entries (a NaN loss) must come back as an error status from the factor-first path -- round 3 indexed
+    the covariance with uninitialised ranks there."""
+    from kronfluence_amd import ops
+    from kronfluence_amd._native import KfError
+
+    cov = torch.eye(512, device="cuda") * 3.0
+    cov[5, 5] = float("nan")
+    with pytest.raises(KfError):
+        ops.eigh(cov, 10.0)
+    bad = torch.full((300, 300), float("nan"), device="cuda")
+    with pytest.raises(KfError):
+        ops.eigh(bad, 10.0)
+    evals, _, _ = ops.eigh(torch.eye(512, device="cuda") * 3.0, 10.0)   # the device is still healthy
+    assert float((evals - 0.3).abs().max()) < 1e-12
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # (d) one Llama-3-8B MLP projection at full width
 # ------------------------------------------------------------------------------------------------------------------

@@ -145,6 +145,9 @@ def _query_allgather_async(rank, world, out_dir):
     idx = list(DistributedSampler(range(n_query), world, rank, shuffle=False, drop_last=False))[:per_rank]
     comm.EXCHANGE_LOG = {}
     tracker._store(torch.stack([torch.full((2, 3), float(i)) for i in idx]), from_hook=True)
+    assert tracker._pending is None   # opt-in: nothing is exchanged unless the pairwise query loop has asked for it
+    m.async_query_gather = True
+    tracker._store(torch.stack([torch.full((2, 3), float(i)) for i in idx]), from_hook=True)
     assert tracker._pending is not None
     m.synchronize(num_processes=world)
     assert tracker._pending is None

@@ -746,6 +746,102 @@ def test_lambda_bf16_odd_augmented_axis(ops, b, r, o, i, bias):
     assert rel(lam, want) <= 2e-2, rel(lam, want)
 
 
+@pytest.mark.parametrize("b,r,o,i,bias", [(4, 64, 128, 128, True), (5, 128, 768, 768, True), (3, 128, 192, 3072, True), (70, 64, 128, 192, False),
+                                          (3, 192, 320, 256, True), (9, 512, 256, 64, True), (1, 64, 128, 64, False)])
+def test_lambda_rows_engine(ops, b, r, o, i, bias):
+    """Round-4 Lambda of a sequence layer: both rotations written K-contiguous per sample (``rotate_rows_transposed``, bias row in
+    the epilogue, augmented axis zero-padded to a multiple of 8) + ``lambda_rows_accum`` (per-sample 256 x 128 tiles squared and
+    summed in registers; ragged tiles in both directions, one / several sample ranges, 1-8 k-tiles per sample, k-tile counts that
+    are not powers of two) against tracker/factor.py:218-226 in fp64 -- and against the round-2 kernel on the same rotations."""
+    ip = i + int(bias)
+    w = ip + (-ip) % 8
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0]
+    q_a = torch.linalg.qr(_rand(ip, ip, seed=3).double())[0]
+    want = torch.zeros(o, ip, dtype=torch.float64)
+    ref.lambda_update(want, ref.linear_per_sample_gradient(a.double(), g.double(), bias) * 0.5, q_a, q_g)
+    qa_t = torch.nn.functional.pad(q_a.float().t(), (0, w - ip, 0, w - ip)).to(torch.bfloat16).contiguous().to(DEV)
+    qg_t = q_g.float().t().contiguous().to(torch.bfloat16).to(DEV)
+    bias_row = q_a[i].float().contiguous().to(DEV) if bias else None
+    assert ops.lambda_rows_eligible(o, i, r)
+    at_t = ops.rotate_rows_transposed(a.to(DEV), qa_t, bias_row)
+    gt_t = ops.rotate_rows_transposed(g.to(DEV), qg_t)
+    assert at_t.shape == (b, w, r) and gt_t.shape == (b, o, r)
+    # the same rotations, row-major, from the round-2 entry point: identical bf16 values, transposed per sample
+    at = ops.rotate_bf16(a.reshape(b * r, i).to(DEV), qa_t, bias_row).reshape(b, r, w)
+    gt = ops.rotate_bf16(g.reshape(b * r, o).to(DEV), qg_t).reshape(b, r, o)
+    assert torch.equal(at_t, at.transpose(1, 2)) and torch.equal(gt_t, gt.transpose(1, 2))
+    lam = torch.full((o, ip), 3.0, device=DEV)   # accumulates INTO Lambda
+    for _ in range(2):
+        ops.lambda_rows_accum(lam, gt_t, at_t, scale=0.5)
+    assert rel((lam - 3.0) / 2, want) <= 2e-2, rel((lam - 3.0) / 2, want)
+    old = torch.zeros(o, ip, device=DEV)
+    ops.lambda_accum(old, gt.contiguous(), at.contiguous(), b, r, scale=0.5)
+    assert rel((lam - 3.0) / 2, old) <= 1e-5, rel((lam - 3.0) / 2, old)   # same bf16 factors: fp32 summation order only
+
+
+@pytest.mark.parametrize("q,b", [(1024, 128), (300, 128), (128, 1000), (100, 520), (640, 100)])
+@pytest.mark.parametrize("engine", ["4", "2"])
+def test_score_gemm_half_tile_shapes(ops, q, b, engine, monkeypatch):
+    """The 256 x 128 / 128 x 256 score shapes (GPT-2's train batches of 128 sequences; few queries against many samples) on the
+    round-4 wave-role-split loop for 64 x 64 wave tiles (csrc/kf_pingpong64.h) and on the round-2 loop, against torch on the
+    SAME bf16 per-sample gradients; long split-K chunks, ragged tiles, repeated launches."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    monkeypatch.setenv("KF_HALF_TILE_ENGINE", engine)
+    r, o, i = 16, 128, 1152
+    p = _rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    psg = torch.einsum("bro,bri->boi", g.float(), a.float()).to(torch.bfloat16)
+    want = p.float().flatten(1) @ psg.float().flatten(1).t()
+    tiled = TiledQueries(p, 0)
+    for _ in range(3):
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(scores, 0, tiled, g, a, False)
+        assert rel(scores, want) <= 1e-5, rel(scores, want)
+    for short in (8, 16, 24, 40):   # D = 8 * short: 1, 2, 3 and 5 k-tiles, no split-K -- the prologue / tail paths of the loop
+        ps = _rand(q, 8, short, seed=9).to(torch.bfloat16).to(DEV)
+        gs, as_ = _rand(b, r, 8, dtype=torch.bfloat16, seed=2).to(DEV), _rand(b, r, short, dtype=torch.bfloat16, seed=3).to(DEV)
+        psg = torch.einsum("bro,bri->boi", gs.float(), as_.float()).to(torch.bfloat16)
+        want_s = ps.float().flatten(1) @ psg.float().flatten(1).t()
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(scores, 0, TiledQueries(ps, 0), gs, as_, False)
+        assert rel(scores, want_s) <= 1e-5, (short, rel(scores, want_s))
+
+
+def test_wave_role_split_64_loop_race_screen(ops):
+    """Race screen of the round-4 loop (csrc/kf_pingpong64.h: three LDS stages, counted ``vmcnt``, raw barriers): the 256 x 128
+    score GEMM and the Lambda kernel launched 60 times on the same operands beside a stream that keeps HBM unevenly busy; every
+    result must equal the first launch up to fp32 atomic-order noise (a stale 64-deep k-tile is >= 1e-4 of the result)."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    q, b, r, o, i = 1024, 128, 16, 128, 1152
+    p = TiledQueries(_rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV), 0)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    gt_t = _rand(48, 768, 128, dtype=torch.bfloat16, seed=3).to(DEV)
+    at_t = _rand(48, 776, 128, dtype=torch.bfloat16, seed=4).to(DEV)
+    noise = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    first = {}
+    for launch in range(60):
+        with torch.cuda.stream(side):
+            if launch % 3 != 2:
+                noise[: (launch % 5 + 1) << 25].add_(1)
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(scores, 0, p, g, a, False)
+        lam = torch.zeros(768, 769, device=DEV)
+        ops.lambda_rows_accum(lam, gt_t, at_t)
+        for key, value in (("score", scores), ("lambda", lam)):
+            if launch == 0:
+                first[key] = value.clone()
+            else:
+                worst = float((value - first[key]).abs().max() / first[key].abs().max())
+                assert worst <= 1e-5, (key, launch, worst)
+    torch.cuda.synchronize()
+    want = torch.einsum("sor,sir->soi", gt_t.float(), at_t.float()[:, :769]).square().sum(0)
+    assert rel(first["lambda"], want) <= 1e-5
+
+
 # ---- SURVEY.md 8(f) kernels: row-wise weighted dots, broadcast product, squared-operand GEMM ---------------------
 @pytest.mark.parametrize("rows,d", [(1, 1), (5, 37), (48, 16 * 17), (3, 1 << 20), (1000, 1024 * 8), (7, 4096 + 8)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
