@@ -192,4 +192,149 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
 }
 
 }  // namespace pp
+
+// ------------------------------------------------------------------------------------------------
+// Round 4: the SAME loop for other wave grids -- WM x WN waves of 128 x 64, tile (WM 128) x (WN 64): 4 x 2 = 512 x 128 and
+// 1 x 8 = 128 x 512 (pp above is the 2 x 4 case, kept as it is: its kernels carry three rounds of verification).  A parameter
+// change of that template, not a new synchronisation structure: the phases, the four pieces per k-tile and their liveness
+// order (A0 | B0, B1 | A1), the issue order (L(2t): B1, A1 of t + 1; L(2t+1): A0, B0 of t + 2) and the RAW / WAR argument at the
+// top of this file carry over verbatim; only the request counts per piece change -- NA = WM per A piece, NB = WN / 2 per B
+// piece and wave -- and with them the counted waits:
+//     end of L(2t)    in flight: A0, B0, B1, A1 of t + 1     = 2 NA + 2 NB
+//     end of L(2t+1)  in flight: A1(t + 1), A0, B0 of t + 2  = 2 NA + NB      (no t + 2: A1(t + 1) = NA)
+// Two stages of (WM 128 + WN 64) x 128 B: 80 KB each for 4 x 2 and 1 x 8, i.e. ALL 160 KB of a CU's LDS.
+// Why: a train batch of 128 sequences (GPT-2) against >= 512 queries fills a 512 x 128 tile with 8 + 2 = 10 DMA requests per
+// wave and k-tile for 32 MFMAs -- the 256 x 128 tile of kf_pingpong64.h needs 12 for the same MFMAs.
+// ------------------------------------------------------------------------------------------------
+namespace ppw {
+
+using pp::bf16x8;
+using pp::glds16;
+using pp::swz;
+
+template <int WM, int WN>
+struct Geo {
+    static_assert(WM * WN == 8 && WN % 2 == 0, "8 waves, an even number of wave columns");
+    static constexpr int TA = WM * 128, TB = WN * 64;
+    static constexpr int NA = WM, NB = WN / 2;   // requests per wave for one A piece / one B piece
+    static constexpr int A_BYTES = TA * 128, STAGE_BYTES = (TA + TB) * 128, SMEM_BYTES = 2 * STAGE_BYTES;
+};
+
+// p[0 .. NA): A0, p[NA .. 2 NA): A1, then B0 (NB), B1 (NB)
+template <int WM, int WN>
+struct Sources {
+    const uint16_t* p[2 * Geo<WM, WN>::NA + 2 * Geo<WM, WN>::NB];
+};
+
+// first row (within the operand tile) of request r of `wave`; every such row is 8 (8 j' + wave): bit 3 = wave & 1, so
+// pp::lane_octet holds here too
+template <int WM, int WN>
+__device__ __forceinline__ int request_row0(int r, int wave) {
+    using G = Geo<WM, WN>;
+    if (r < 2 * G::NA) { const int h = r / G::NA, j = r % G::NA; return j * 128 + h * 64 + wave * 8; }
+    const int rb = r - 2 * G::NA, h = rb / G::NB, j = rb % G::NB;
+    return h * (G::TB / 2) + j * 64 + wave * 8;
+}
+
+template <int WM, int WN, class RowA, class RowB>
+__device__ __forceinline__ void make_sources(Sources<WM, WN>& s, int wave, int lane, RowA row_a, RowB row_b) {
+    using G = Geo<WM, WN>;
+#pragma unroll
+    for (int r = 0; r < 2 * G::NA + 2 * G::NB; ++r) {
+        const int row = request_row0<WM, WN>(r, wave) + (lane >> 3);
+        const int chunk = (lane & 7) ^ swz(row);
+        s.p[r] = (r < 2 * G::NA ? row_a(row) : row_b(row)) + chunk * 8;
+    }
+}
+
+template <int WM, int WN, class WalkA, class WalkB>
+__device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources<WM, WN>& src, int nt, int wave, int lane,
+                                         WalkA walk_a, WalkB walk_b) {
+    using G = Geo<WM, WN>;
+    constexpr int NA = G::NA, NB = G::NB;
+    const int wm = wave / WN, wn = wave % WN, role = wave >> 2;
+    const int lr = lane & 31, hi = lane >> 5, sw = (lr >> 1) & 7;
+    int co[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) co[kk] = ((kk * 2 + hi) ^ sw) * 16;
+    const unsigned char* frag_a = sm + (wm * 128 + lr) * 128;
+    const unsigned char* frag_b = sm + G::A_BYTES + (wn * 64 + lr) * 128;
+
+    // piece: 0 A0, 1 A1, 2 B0, 3 B1 of k-tile t -> stage t & 1
+    auto issue_at = [&](int piece, int t, int64_t off) {
+        const int first = piece < 2 ? piece * NA : 2 * NA + (piece - 2) * NB, count = piece < 2 ? NA : NB;
+#pragma unroll
+        for (int r = first; r < first + count; ++r) {
+            unsigned char* dst = sm + (t & 1) * G::STAGE_BYTES + (r < 2 * NA ? 0 : G::A_BYTES) + request_row0<WM, WN>(r, wave) * 128;
+            glds16(src.p[r] + off, dst);
+        }
+    };
+    auto issue_piece = [&](int piece, int t) { issue_at(piece, t, piece < 2 ? walk_a(t) : walk_b(t)); };
+
+    bf16x8 a[2][4], b[2][4];
+    auto read_a = [&](int half, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                a[i][kk] = *reinterpret_cast<const bf16x8*>(frag_a + buf * G::STAGE_BYTES + (half * 2 + i) * 4096 + co[kk]);
+    };
+    auto read_b = [&](int buf) {
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                b[jn][kk] = *reinterpret_cast<const bf16x8*>(frag_b + buf * G::STAGE_BYTES + jn * 4096 + co[kk]);
+    };
+#define KF_PPW_MFMA(HALF)                                                                                              \
+    do {                                                                                                               \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        _Pragma("unroll") for (int kk = 0; kk < 4; ++kk)                                                               \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                              \
+                _Pragma("unroll") for (int jn = 0; jn < 2; ++jn)                                                       \
+                    acc[(HALF) * 2 + i][jn] =                                                                          \
+                        __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[jn][kk], acc[(HALF) * 2 + i][jn], 0, 0, 0); \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+    } while (0)
+
+    // prologue: k-tile 0 complete, A0 / B0 of k-tile 1 on their way
+    issue_piece(0, 0); issue_piece(2, 0); issue_piece(3, 0); issue_piece(1, 0);
+    if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); pp::wait_vmcnt<2 * NA + NB>(); }   // in flight: A1(0), A0(1), B0(1)
+    else pp::wait_vmcnt<NA>();                                                               // in flight: A1(0)
+    pp::barrier();
+    if (role == 1) pp::barrier();   // Y runs half a phase behind X from here on (wave-uniform branch)
+
+#define KF_PPW_TILE(T, MORE1, MORE2)                                                                                   \
+    do {                                                                                                               \
+        const int t_ = (T), buf_ = t_ & 1;                                                                             \
+        int64_t oa_ = 0, ob_ = 0;                                                                                      \
+        if (MORE1) { oa_ = walk_a(t_ + 1); ob_ = walk_b(t_ + 1); }                                                     \
+        read_a(0, buf_);                                                                                               \
+        read_b(buf_);                                                                                                  \
+        if (MORE1) { issue_at(3, t_ + 1, ob_); issue_at(1, t_ + 1, oa_); pp::wait_vmcnt<2 * NA + 2 * NB>(); }          \
+        else pp::wait_vmcnt<0>();                                                                                      \
+        pp::wait_lds_reads();                                                                                          \
+        pp::barrier();                                                                                                 \
+        KF_PPW_MFMA(0);                                                                                                \
+        pp::barrier();                                                                                                 \
+        if (MORE2) { oa_ = walk_a(t_ + 2); ob_ = walk_b(t_ + 2); }                                                     \
+        read_a(1, buf_);                                                                                               \
+        if (MORE2) { issue_at(0, t_ + 2, oa_); issue_at(2, t_ + 2, ob_); pp::wait_vmcnt<2 * NA + NB>(); }              \
+        else if (MORE1) pp::wait_vmcnt<NA>();                                                                          \
+        pp::wait_lds_reads();                                                                                          \
+        pp::barrier();                                                                                                 \
+        KF_PPW_MFMA(1);                                                                                                \
+        pp::barrier();                                                                                                 \
+    } while (0)
+
+    int t = 0;
+    for (; t + 2 < nt; ++t) KF_PPW_TILE(t, true, true);
+    if (t + 1 < nt) { KF_PPW_TILE(t, true, false); ++t; }
+    KF_PPW_TILE(t, false, false);
+    if (role == 0) pp::barrier();   // X waits for Y's last segment: barrier counts match, all LDS reads are done
+#undef KF_PPW_TILE
+#undef KF_PPW_MFMA
+}
+
+}  // namespace ppw
 }  // namespace kf

@@ -387,6 +387,51 @@ __global__ __launch_bounds__(pp64::THREADS) void score_gemm_v4_kernel(ScoreV2Arg
             }
 }
 
+// Round 4: 512 x 128 (4 x 2 waves of 128 x 64) and 128 x 512 (1 x 8) shapes on the generic wave grid of kf_pingpong.h (ppw):
+// the two-phase loop of score_gemm_v3_kernel with 10 DMA requests per wave and k-tile instead of 8, all 160 KB of LDS.
+template <int WM, int WN>
+__global__ __launch_bounds__(pp::THREADS) void score_gemm_v5_kernel(ScoreV2Args a) {
+    using G = ppw::Geo<WM, WN>;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave / WN, wn = wave % WN;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.ksplit) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int chunk = static_cast<int>(item / tiles), tile = static_cast<int>(item % tiles);
+    const int m0 = (tile / a.tiles_n) * G::TA, n0 = (tile % a.tiles_n) * G::TB;
+    const int kt_begin = chunk * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
+    if (kt_begin >= kt_end) return;
+
+    ppw::Sources<WM, WN> src;
+    const int64_t kt_a = static_cast<int64_t>(a.M) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
+    const uint16_t* abase = a.A + kt_begin * kt_a;
+    const uint16_t* bbase = a.B + kt_begin * kt_b;
+    ppw::make_sources<WM, WN>(src, wave, lane,
+                              [&](int row) { return abase + static_cast<int64_t>(min(m0 + row, a.M - 1)) * 64; },
+                              [&](int row) { return bbase + static_cast<int64_t>(min(n0 + row, a.N - 1)) * 64; });
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    ppw::mainloop<WM, WN>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; });
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const int n = n0 + wn * 64 + jn * 32 + (lane & 31);
+                if (m < a.M && n < a.N) atomicAdd(a.C + static_cast<int64_t>(m) * a.ldc + n, a.alpha * acc[i][jn][r]);
+            }
+}
+constexpr int PPW_SMEM = 2 * (512 + 128) * 128;   // == ppw::Geo<4, 2>::SMEM_BYTES == ppw::Geo<1, 8>::SMEM_BYTES: all of the CU's LDS
+
 // ------------------------------------------------------------------------------------------------
 // Lambda of a Linear layer on sequences (reference module/linear.py:112-122 + module/tracker/factor.py:218-226):
 //     Lambda[o, i] += scale^2 * sum_n ( sum_r GtT[n][o][r] AtT[n][i][r] )^2
@@ -574,6 +619,8 @@ inline int half_tile_engine() {
     if (e && atoi(e) == 2) return 2;
     return engine_generation() == 3 ? 4 : 2;
 }
+
+inline bool wide_tile_enabled() { const char* e = getenv("KF_WIDE_TILE"); return !(e && atoi(e) == 0); }
 
 inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A/B measurements, fallback)
     const char* e = getenv("KF_ENGINE");
@@ -1437,6 +1484,8 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v5_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PPW_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v5_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, PPW_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
@@ -1462,8 +1511,14 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     int shape = 0;
     if (area[1] * 115 < area[shape] * 100) shape = 1;
     if (area[2] * 115 < (shape == 0 ? area[0] * 100 : area[1] * 115)) shape = 2;
-    if (const char* e = getenv("KF_SCORE_SHAPE")) shape = std::min(2, std::max(0, atoi(e)));   // measurements only
-    const int tm = shape == 2 ? 128 : 256, tn = shape == 1 ? 128 : 256;
+    // round 4: when a half tile wins, the 512 x 128 / 128 x 512 shapes (two-phase loop, 128 x 64 waves) cover the same narrow
+    // side with fewer DMA requests per MFMA -- taken when they pad no more than the 256-row shape does
+    if (half_tile_engine() == 4 && wide_tile_enabled()) {
+        if (shape == 1 && cdiv(Q, 512) * 512 == cdiv(Q, 256) * 256) shape = 3;
+        else if (shape == 2 && cdiv(b, 512) * 512 == cdiv(b, 256) * 256) shape = 4;
+    }
+    if (const char* e = getenv("KF_SCORE_SHAPE")) shape = std::min(4, std::max(0, atoi(e)));   // measurements only
+    const int tm = shape == 3 ? 512 : (shape == 2 || shape == 4) ? 128 : 256, tn = shape == 4 ? 512 : (shape == 1 || shape == 3) ? 128 : 256;
     s.tiles_m = static_cast<int>(cdiv(Q, tm)); s.tiles_n = static_cast<int>(cdiv(b, tn));
     const int64_t tiles = static_cast<int64_t>(s.tiles_m) * s.tiles_n;
     // one workgroup per CU: ONE round of work items over the 256 CUs (measured 4-6 % faster than two rounds of half the
@@ -1476,6 +1531,8 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     const dim3 grid(static_cast<unsigned>(8 * cdiv(ksplit * tiles, 8)));
     if (shape == 0 && engine_generation() == 3) hipLaunchKernelGGL(score_gemm_v3_kernel, grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, s);
     else if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
+    else if (shape == 3) hipLaunchKernelGGL((score_gemm_v5_kernel<4, 2>), grid, dim3(pp::THREADS), PPW_SMEM, st, s);
+    else if (shape == 4) hipLaunchKernelGGL((score_gemm_v5_kernel<1, 8>), grid, dim3(pp::THREADS), PPW_SMEM, st, s);
     else if (shape == 1 && half_tile_engine() == 4)
         hipLaunchKernelGGL((score_gemm_v4_kernel<256, 128>), grid, dim3(pp64::THREADS), PP64_SMEM, st, s);
     else if (half_tile_engine() == 4)

@@ -781,14 +781,20 @@ def test_lambda_rows_engine(ops, b, r, o, i, bias):
 
 
 @pytest.mark.parametrize("q,b", [(1024, 128), (300, 128), (128, 1000), (100, 520), (640, 100)])
-@pytest.mark.parametrize("engine", ["4", "2"])
+@pytest.mark.parametrize("engine", ["wide", "half", "round2"])
 def test_score_gemm_half_tile_shapes(ops, q, b, engine, monkeypatch):
-    """The 256 x 128 / 128 x 256 score shapes (GPT-2's train batches of 128 sequences; few queries against many samples) on the
-    round-4 wave-role-split loop for 64 x 64 wave tiles (csrc/kf_pingpong64.h) and on the round-2 loop, against torch on the
-    SAME bf16 per-sample gradients; long split-K chunks, ragged tiles, repeated launches."""
+    """Score GEMMs whose train batch or query count is half a 256-row tile (GPT-2's train batches of 128 sequences; few queries
+    against many samples) on the three engines that take them: "wide" = the default choice, 512 x 128 / 128 x 512 tiles on the
+    two-phase wave-role-split loop where they pad no more (csrc/kf_pingpong.h, ppw) and 256 x 128 / 128 x 256 otherwise;
+    "half" = always 256 x 128 / 128 x 256 on the loop for 64 x 64 wave tiles (csrc/kf_pingpong64.h); "round2" = the lock-step
+    loop.  Against torch on the SAME bf16 per-sample gradients; long split-K chunks, ragged tiles, repeated launches, and
+    1 / 2 / 3 / 5 k-tiles per item (prologue and tail paths)."""
     from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 
-    monkeypatch.setenv("KF_HALF_TILE_ENGINE", engine)
+    if engine == "half":
+        monkeypatch.setenv("KF_WIDE_TILE", "0")
+    elif engine == "round2":
+        monkeypatch.setenv("KF_HALF_TILE_ENGINE", "2")
     r, o, i = 16, 128, 1152
     p = _rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV)
     g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
@@ -810,13 +816,14 @@ def test_score_gemm_half_tile_shapes(ops, q, b, engine, monkeypatch):
 
 
 def test_wave_role_split_64_loop_race_screen(ops):
-    """Race screen of the round-4 loop (csrc/kf_pingpong64.h: three LDS stages, counted ``vmcnt``, raw barriers): the 256 x 128
-    score GEMM and the Lambda kernel launched 60 times on the same operands beside a stream that keeps HBM unevenly busy; every
+    """Race screen of the round-4 loops (csrc/kf_pingpong64.h: three LDS stages, counted ``vmcnt``, raw barriers; the 4 x 2 wave grid
+    of csrc/kf_pingpong.h with its re-counted waits): the 512 x 128 and 256 x 128 score GEMMs and the Lambda kernel launched 60 times on the same operands beside a stream that keeps HBM unevenly busy; every
     result must equal the first launch up to fp32 atomic-order noise (a stale 64-deep k-tile is >= 1e-4 of the result)."""
     from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 
     q, b, r, o, i = 1024, 128, 16, 128, 1152
     p = TiledQueries(_rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV), 0)
+    p640 = TiledQueries(_rand(640, o, i, seed=8).to(torch.bfloat16).to(DEV), 0)   # 640 queries: the 256 x 128 tile (512 would pad more)
     g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
     gt_t = _rand(48, 768, 128, dtype=torch.bfloat16, seed=3).to(DEV)
     at_t = _rand(48, 776, 128, dtype=torch.bfloat16, seed=4).to(DEV)
@@ -828,10 +835,12 @@ def test_wave_role_split_64_loop_race_screen(ops):
             if launch % 3 != 2:
                 noise[: (launch % 5 + 1) << 25].add_(1)
         scores = torch.zeros(q, b, device=DEV)
-        ops.pairwise_score(scores, 0, p, g, a, False)
+        ops.pairwise_score(scores, 0, p, g, a, False)            # 512 x 128 tiles (ppw loop)
+        scores640 = torch.zeros(640, b, device=DEV)
+        ops.pairwise_score(scores640, 0, p640, g, a, False)      # 256 x 128 tiles (pp64 loop)
         lam = torch.zeros(768, 769, device=DEV)
         ops.lambda_rows_accum(lam, gt_t, at_t)
-        for key, value in (("score", scores), ("lambda", lam)):
+        for key, value in (("score", scores), ("score640", scores640), ("lambda", lam)):
             if launch == 0:
                 first[key] = value.clone()
             else:

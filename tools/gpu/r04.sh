@@ -1,0 +1,65 @@
+#!/usr/bin/env bash
+# The GPU command lines of round 4, one sub-command each:  gpurun --timeout S -- 'bash tools/gpu/r04.sh <what>'
+#   check1    the new kernels: targeted GPU tests (Lambda rows engine, half / wide score tiles, race screens, eigensolver on product
+#             covariances), then tools/r04_ab.py under rocprofv3 --kernel-trace --stats (score, lambda) and its eigh part
+#   suite     the full GPU suite + smoke
+#   record    kernel trace + the three PMC passes of the bench command (-> profiles/pmc_resnet9.json), default bench line
+#   traces    per-kernel totals of one BERT-base and one GPT-2-small step at bounded sizes
+# Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
+set -u
+what="${1:-check1}"
+mkdir -p gpurun_out
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+CMD="python $GRAFT_REPO_ROOT/bench.py --n-train 4000 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 1"
+pmc() {  # pmc <tag> <counters...>: one counter-collection pass of the bench command
+    local tag="$1"; shift
+    ( cd /tmp && timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_pmc_$tag" -- $CMD ) > "gpurun_out/r04_pmc_$tag.log" 2>&1
+}
+case "$what" in
+check1)
+    ( timeout 900 python -m pytest tests/test_ops_gpu.py -q -x -k "lambda or half_tile or race_screen or eigh or score_gemm_long or rotate_bf16" --durations=8 ) > gpurun_out/r04_check1_ops.log 2>&1
+    tail -5 gpurun_out/r04_check1_ops.log
+    ( timeout 600 python -m pytest tests/test_configs_gpu.py -q -k "eigh" --durations=8 -s ) > gpurun_out/r04_check1_eigh.log 2>&1
+    tail -5 gpurun_out/r04_check1_eigh.log
+    ( timeout 600 python -m pytest tests/test_layer_shapes_gpu.py -q --durations=5 ) > gpurun_out/r04_check1_shapes.log 2>&1
+    tail -3 gpurun_out/r04_check1_shapes.log
+    ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_ab_trace" -- python "$GRAFT_REPO_ROOT/tools/r04_ab.py" score lambda ) > gpurun_out/r04_ab_score_lambda.log 2>&1
+    find gpurun_out/r04_ab_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_ab_kernel_stats.csv \;
+    rm -rf gpurun_out/r04_ab_trace
+    cat gpurun_out/r04_ab_score_lambda.log | grep -v "^W0\|rocprof" | tail -30
+    ( KF_EIGH_VERBOSE=1 timeout 600 python tools/r04_ab.py eigh ) > gpurun_out/r04_ab_eigh.log 2>&1
+    grep -v "kf_eigh\]" gpurun_out/r04_ab_eigh.log | tail -14
+    ;;
+suite)
+    ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r04_pytest_gpu.log 2>&1
+    tail -15 gpurun_out/r04_pytest_gpu.log
+    ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/r04_smoke.log 2>&1
+    tail -2 gpurun_out/r04_smoke.log
+    ;;
+record)
+    ( cd /tmp && timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace" -- $CMD ) > gpurun_out/r04_trace.log 2>&1
+    find gpurun_out/r04_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_resnet9_n4000_kernel_stats.csv \;
+    rm -rf gpurun_out/r04_trace
+    pmc fetch FETCH_SIZE
+    pmc write WRITE_SIZE
+    pmc mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+    ( python tools/pmc_summary.py resnet9 profiles/pmc_resnet9.json gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma ) > gpurun_out/r04_pmc_summary.log 2>&1
+    cp profiles/pmc_resnet9.json gpurun_out/r04_pmc_resnet9.json
+    find gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma -name "*.csv" -size +4M -delete
+    ( timeout 1500 python bench.py ) > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.log
+    tail -c 3000 gpurun_out/r04_bench_default.json
+    ;;
+traces)
+    for w in bert_base:2048 gpt2_small:1024; do
+        name="${w%%:*}"; n="${w##*:}"
+        ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace_$name" -- \
+            python "$GRAFT_REPO_ROOT/bench.py" --workload "$name" --n-train "$n" --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > "gpurun_out/r04_trace_$name.log" 2>&1
+        find "gpurun_out/r04_trace_$name" -name "*kernel_stats.csv" -exec cp {} "gpurun_out/r04_${name}_n${n}_kernel_stats.csv" \;
+        rm -rf "gpurun_out/r04_trace_$name"
+        tail -c 1500 "gpurun_out/r04_trace_$name.log"
+    done
+    ;;
+*)
+    echo "unknown sub-command $what"; exit 2 ;;
+esac
