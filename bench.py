@@ -21,6 +21,8 @@ Workloads (synthetic random-weight models of the BASELINE.json layer shapes, SUR
              alone defaults to 8 192 of the 67 349 train sequences; ``--n-train`` overrides)
   gpt2_small configs[3]: GPT-2-small-shaped decoder (48 tracked block Linears with bias, T = 512, D = 85.0 M), bf16 incl. the
              covariances (the reference's all-low-precision preset); 2 048 train x 1 024 query sequences by default
+  llama_block configs[4] as a one-block slice: the seven projections of a Llama-3-8B decoder block at full width (D = 218 M),
+             T = 512, rank-64 low-rank query gradients, covariances released as their eigendecompositions finish; 64 x 8 sequences
 
 With the default workload the same JSON line also carries ``targets.mnist_mlp`` (N = 1; the north-star target: GPU pairs/s,
 CPU-oracle pairs/s on the SAME full workload, their ratio and the GPU-vs-oracle score error at damping 1e-8) and
@@ -141,6 +143,62 @@ class GPT2(nn.Module):
 
 def gpt2_small() -> nn.Module:
     return GPT2()
+
+
+class _LlamaBlock(nn.Module):
+    """One Llama-3-8B decoder block at FULL width (examples/openwebtext/pipeline.py loads Meta-Llama-3-8B; here random
+    init): RMSNorm, grouped-query causal attention (32 heads, 8 KV heads), SwiGLU MLP -- seven bias-free Linears:
+    q / o (4096, 4096), k / v (1024, 4096), gate / up (14336, 4096), down (4096, 14336)."""
+
+    def __init__(self, width: int = 4096, heads: int = 32, kv_heads: int = 8, inter: int = 14336) -> None:
+        super().__init__()
+        self.heads, self.kv_heads, self.head_dim = heads, kv_heads, width // heads
+        self.input_norm, self.post_norm = nn.RMSNorm(width, eps=1e-5), nn.RMSNorm(width, eps=1e-5)
+        self.q_proj = nn.Linear(width, width, bias=False)
+        self.k_proj = nn.Linear(width, kv_heads * self.head_dim, bias=False)
+        self.v_proj = nn.Linear(width, kv_heads * self.head_dim, bias=False)
+        self.o_proj = nn.Linear(width, width, bias=False)
+        self.gate_proj = nn.Linear(width, inter, bias=False)
+        self.up_proj = nn.Linear(width, inter, bias=False)
+        self.down_proj = nn.Linear(inter, width, bias=False)
+
+    def forward(self, x):
+        b, t, d = x.shape
+        h = self.input_norm(x)
+        q = self.q_proj(h).reshape(b, t, self.heads, self.head_dim).transpose(1, 2)
+        k = self.k_proj(h).reshape(b, t, self.kv_heads, self.head_dim).transpose(1, 2)
+        v = self.v_proj(h).reshape(b, t, self.kv_heads, self.head_dim).transpose(1, 2)
+        rep = self.heads // self.kv_heads
+        y = F.scaled_dot_product_attention(q, k.repeat_interleave(rep, dim=1), v.repeat_interleave(rep, dim=1), is_causal=True)
+        x = x + self.o_proj(y.transpose(1, 2).reshape(b, t, d))
+        h = self.post_norm(x)
+        return x + self.down_proj(F.silu(self.gate_proj(h)) * self.up_proj(h))
+
+
+class LlamaSlice(nn.Module):
+    """``blocks`` Llama-3-8B decoder blocks between a (reduced-vocabulary, untracked) embedding and head: the slice of
+    configs[4] one GPU's worth of layers stands for.  Tracked: the seven projections of every block ("Linear layers only")."""
+
+    def __init__(self, blocks: int = 1, width: int = 4096, vocab: int = 32000) -> None:
+        super().__init__()
+        self.embed = nn.Embedding(vocab, width)
+        self.layers = nn.ModuleList(_LlamaBlock(width) for _ in range(blocks))
+        self.norm = nn.RMSNorm(width, eps=1e-5)
+        self.lm_head = nn.Linear(width, vocab, bias=False)
+
+    def forward(self, ids):
+        x = self.embed(ids)
+        for block in self.layers:
+            x = block(x)
+        return self.lm_head(self.norm(x))
+
+    def tracked_names(self) -> List[str]:
+        return [f"layers.{i}.{name}" for i in range(len(self.layers))
+                for name in ("q_proj", "k_proj", "v_proj", "o_proj", "gate_proj", "up_proj", "down_proj")]
+
+
+def llama_block() -> nn.Module:
+    return LlamaSlice(blocks=1)
 
 
 class _BertLayer(nn.Module):
@@ -320,6 +378,14 @@ WORKLOADS = {
     "gpt2_small": dict(model=gpt2_small, kind="lm", vocab=50257, tokens=512, n_train=2048, n_query=1024,
                        full_n_train=100_000, full_n_query=2000, amp=torch.bfloat16, low_cov=True, factor_batch=64, train_batch=128,
                        query_batch=32, cpu_sample=dict(n_train=8, n_query=2, n_fit=4)),
+    # configs[4] (OpenWebText Llama-3-8B, Linear layers only, 100k x 1k on 8 GPUs, AMP bf16) as a ONE-BLOCK slice at full
+    # width: all seven projections tracked, T = 512, the reference's rank-64 low-rank query gradients
+    # (examples/openwebtext/files/scores_raw/score_arguments.json), all-low-precision factors; the covariances (3 of
+    # 14336^2) are released one by one as their eigendecompositions finish.  The vocabulary of the untracked embedding /
+    # head is reduced to 32 000.
+    "llama_block": dict(model=llama_block, kind="lm", vocab=32000, tokens=512, n_train=64, n_query=8, full_n_train=100_000,
+                        full_n_query=1000, amp=torch.bfloat16, low_cov=True, factor_batch=8, train_batch=8, query_batch=4,
+                        low_rank=64, release_covariances=True, cpu_sample=dict(n_train=2, n_query=1, n_fit=1)),
 }
 
 
@@ -350,7 +416,8 @@ def score_arguments(spec, n_query: int, world: int, per_dev_q: int):
     accumulate = -(-n_query // (per_dev_q * world))
     return ScoreArguments(amp_dtype=amp, query_gradient_accumulation_steps=accumulate,
                           score_dtype=torch.bfloat16 if low else torch.float32,
-                          precondition_dtype=torch.bfloat16 if low else torch.float32)
+                          precondition_dtype=torch.bfloat16 if low else torch.float32,
+                          query_gradient_low_rank=spec.get("low_rank"))
 
 
 def workload_parts(spec, raw_model):
@@ -517,7 +584,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         t_cov, (_, cov) = timed(lambda: fit_covariance_matrices_with_loader(model, state, task, factor_loader(), fargs,
                                                                              all_ranks=True, cpu=False))
         ops.eigh_stats(reset=True)
-        t_eig, eig = timed(lambda: perform_eigendecomposition(cov, model, state, fargs, cpu=False))
+        t_eig, eig = timed(lambda: perform_eigendecomposition(cov, model, state, fargs, cpu=False,
+                                                              release_covariances=bool(spec.get("release_covariances"))))
         eigh_paths = ops.eigh_stats()   # this rank's share of the 2L problems: factor-first solves / fall-backs / Cholesky retries
         t_lam, (_, lam) = timed(lambda: fit_lambda_matrices_with_loader(model, state, task, factor_loader(), fargs, eig,
                                                                          all_ranks=True, cpu=False))
@@ -525,7 +593,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         fit_events, ops.EVENT_LOG = (ops.EVENT_LOG or {}), None
         fit_exchanges, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
     factors = {k: {n: v.to(dev) for n, v in d.items()} for k, d in {**eig, **lam}.items()}
-    eig_dims = sorted({int(v.shape[0]) for d in (cov["activation_covariance"], cov["gradient_covariance"]) for v in d.values()})
+    eig_dims = sorted({int(v.shape[0]) for d in (eig["activation_eigenvalues"], eig["gradient_eigenvalues"]) for v in d.values()})
     del cov
     fit_total = sum(fit_times.values())
 

@@ -365,6 +365,18 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
 int kf_rowwise_dot(float* out, const void* X, int x_dtype, const void* Y, int y_dtype, const float* W,
                    int64_t rows, int64_t D, float scale, int accumulate, void* stream);
 
+/*
+ * Factored score of LOW-RANK query gradients against samples with R rows each (ABI 11): the reference contracts
+ * "qik,qko,b...i,b...o->qb" (module/linear.py:83-99) along whichever path opt_einsum finds cheapest; when the train batch is
+ * small and the layer wide (Llama-3-8B projections, k = 64: expanding P_q = L_q R_q costs more bytes per pair than the factored
+ * form costs flops) that is  scores[q, n] += scale * sum_{r, k} (G_n L_q)[r, k] (A'_n R_q^T)[r, k].  The two products are tall
+ * NT GEMMs on the LDS-DMA engine (kf_gemm_out / kf_gemm_bias_out with the queries' factors stacked to [Q k, O] and [Q k, I']);
+ * this entry reduces their bf16 results U, V: [b R, Q K] row-major over (r, k).  K % 8 == 0; fp32 accumulation, one atomic per
+ * (query, sample, row split).
+ */
+int kf_lowrank_rows_dot(float* scores, int64_t ld_scores, const void* U, const void* V, int64_t b, int64_t R, int64_t Q, int64_t K,
+                        float scale, void* stream);
+
 /* out[r,i] = scale * X[r,i] * M[i]: the diagonal strategy's preconditioner (factor/config.py:215-222). */
 int kf_mul_bcast(float* out, const void* X, int x_dtype, const float* M, int64_t rows, int64_t D,
                  float scale, void* stream);

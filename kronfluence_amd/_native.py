@@ -76,6 +76,7 @@ SIGNATURES = {
     "kf_pairwise_score_rows": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
     "kf_eigh_small_batched": (_i, [_p, _i64, _i, _p, _p, _i, _f, _i, _p]),
     "kf_rowwise_dot": (_i, [_p, _p, _i, _p, _i, _p, _i64, _i64, _f, _i, _p]),
+    "kf_lowrank_rows_dot": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _f, _p]),
     "kf_mul_bcast": (_i, [_p, _p, _i, _p, _i64, _i64, _f, _p]),
     "kf_cast": (_i, [_p, _i, _p, _i, _i64, _p]),
 }

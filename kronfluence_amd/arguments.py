@@ -100,10 +100,8 @@ class ScoreArguments(Arguments):
 def unsupported_score_options(score_args: ScoreArguments) -> Dict[str, Any]:
     """Options outside the accelerated hot path ("next" rows); the score stage
     rejects them explicitly instead of silently computing something else."""
-    flagged = {}
-    if score_args.query_gradient_low_rank is not None and score_args.query_gradient_low_rank > 96 - 8:
-        flagged["query_gradient_low_rank"] = score_args.query_gradient_low_rank  # in-LDS eigensolver: rank + 8 <= 96
-    return flagged
+    del score_args   # every ScoreArguments option is implemented (ranks above 88 leave the in-LDS eigensolver, see ops.eigh_small)
+    return {}
 
 
 def all_field_names(cls) -> set:

@@ -753,6 +753,47 @@ __global__ __launch_bounds__(256) void rowwise_dot_kernel(float* out, const void
     if (threadIdx.x == 0) atomicAdd(out + row, scale * (part[0] + part[1] + part[2] + part[3]));
 }
 
+// Factored score of low-rank queries against SEQUENCE samples (module/linear.py:83-99, "qik,qko,b...i,b...o->qb" contracted as
+// (G L_q) . (A' R_q^T)): scores[q, n] += scale * sum_{r < R} sum_{k < K} U[(n R + r), q K + k] V[(n R + r), q K + k] for bf16
+// U, V = [b R, Q K] row-major (two tall GEMMs made them).  A pure HBM stream: a thread owns 8 consecutive columns (16 bytes) of
+// one sample's rows, a workgroup 2048 columns; partial sums of the K / 8 lanes of a query are folded with shuffles when K / 8 is
+// a power of two <= 64, else every lane adds its own partial.
+struct SegDotArgs {
+    float* scores; int64_t ld_scores;
+    const uint16_t* U; const uint16_t* V;
+    int64_t ld;       // Q * K
+    int R, K, rsplit; float scale;
+};
+
+__global__ __launch_bounds__(256) void lowrank_rows_dot_kernel(SegDotArgs a) {
+    const int64_t col = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 8;
+    const int n = blockIdx.y, part = blockIdx.z;
+    const bool live = col < a.ld;
+    const int r_per = (a.R + a.rsplit - 1) / a.rsplit, r_begin = part * r_per, r_end = min(a.R, r_begin + r_per);
+    float s = 0.0f;
+    if (live) {
+        const uint16_t* u = a.U + (static_cast<int64_t>(n) * a.R + r_begin) * a.ld + col;
+        const uint16_t* v = a.V + (static_cast<int64_t>(n) * a.R + r_begin) * a.ld + col;
+        for (int r = r_begin; r < r_end; ++r, u += a.ld, v += a.ld) {
+            const uint4 x = *reinterpret_cast<const uint4*>(u), y = *reinterpret_cast<const uint4*>(v);
+            const uint32_t xs[4] = {x.x, x.y, x.z, x.w}, ys[4] = {y.x, y.y, y.z, y.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = fmaf(__uint_as_float(xs[e] << 16), __uint_as_float(ys[e] << 16), s);
+                s = fmaf(__uint_as_float(xs[e] & 0xffff0000u), __uint_as_float(ys[e] & 0xffff0000u), s);
+            }
+        }
+    }
+    const int lanes = a.K >> 3;   // lanes per query
+    const bool fold = lanes <= 64 && (lanes & (lanes - 1)) == 0;
+    if (fold) {
+        for (int off = 1; off < lanes; off <<= 1) s += __shfl_xor(s, off, 64);   // (all 64 lanes take part: dead lanes carry 0)
+        if (live && (threadIdx.x & (lanes - 1)) == 0) atomicAdd(a.scores + (col / a.K) * a.ld_scores + n, a.scale * s);
+    } else if (live) {
+        atomicAdd(a.scores + (col / a.K) * a.ld_scores + n, a.scale * s);
+    }
+}
+
 template <int DTX>
 __global__ __launch_bounds__(256) void mul_bcast_kernel(float* out, const void* X, const float* M, int64_t rows, int64_t D,
                                                         float scale) {
@@ -1193,6 +1234,24 @@ int kf_rowwise_dot(float* out, const void* X, int x_dtype, const void* Y, int y_
         hipLaunchKernelGGL((rowwise_dot_kernel<F32, BF16>), grid, dim3(256), 0, st, out, X, Y, W, D, scale, vec);
     else
         hipLaunchKernelGGL((rowwise_dot_kernel<BF16, BF16>), grid, dim3(256), 0, st, out, X, Y, W, D, scale, vec);
+    return launch_status();
+}
+
+int kf_lowrank_rows_dot(float* scores, int64_t ld_scores, const void* U, const void* V, int64_t b, int64_t R, int64_t Q, int64_t K,
+                        float scale, void* stream) {
+    if (!scores || !U || !V || b < 0 || R <= 0 || Q < 0 || K <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (K % 8 != 0 || ((reinterpret_cast<uintptr_t>(U) | reinterpret_cast<uintptr_t>(V)) & 15) != 0 || b > 65535 || R >= (1LL << 31))
+        return KF_ERR_INVALID_ARGUMENT;
+    if (b == 0 || Q == 0) return KF_OK;
+    SegDotArgs a;
+    a.scores = scores; a.ld_scores = ld_scores; a.U = reinterpret_cast<const uint16_t*>(U); a.V = reinterpret_cast<const uint16_t*>(V);
+    a.ld = Q * K; a.R = static_cast<int>(R); a.K = static_cast<int>(K); a.scale = scale;
+    const int64_t col_blocks = cdiv(a.ld, 2048);
+    // >= ~4 workgroups per CU: split the rows of a sample when (column blocks x samples) alone would not fill the chip
+    a.rsplit = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({cdiv(1024, col_blocks * b), R / 8, static_cast<int64_t>(64)})));
+    if (col_blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+    hipLaunchKernelGGL(lowrank_rows_dot_kernel, dim3(static_cast<unsigned>(col_blocks), static_cast<unsigned>(b), static_cast<unsigned>(a.rsplit)),
+                       dim3(256), 0, as_stream(stream), a);
     return launch_status();
 }
 

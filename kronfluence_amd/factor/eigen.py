@@ -85,12 +85,15 @@ def lambda_matrices_exist(output_dir: Path, partition=None) -> bool:
 
 @torch.no_grad()
 def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module, state: State,
-                               factor_args: FactorArguments, disable_tqdm: bool = False, cpu: bool = True) -> FACTOR_TYPE:
+                               factor_args: FactorArguments, disable_tqdm: bool = False, cpu: bool = True,
+                               release_covariances: bool = False) -> FACTOR_TYPE:
     """``eigh(0.5 (C + C^T) / count)`` in fp64 for both factors of every tracked layer, on the MI355X
     (``kf_eigh_f64``).  The 2L matrices are independent: with several ranks they are dealt
     round-robin and the results are exchanged by broadcast, instead of rank 0 doing all of them while
     the others wait at a barrier (reference ``factor_computer.py:449-470``).  Results are cast back
-    to the covariance dtype and returned on the CPU (``eigen.py:214-219``), or left in HBM with ``cpu=False``."""
+    to the covariance dtype and returned on the CPU (``eigen.py:214-219``), or left in HBM with ``cpu=False``.
+    ``release_covariances``: every covariance matrix is dropped from ``covariance_factors`` as soon as its problem is solved --
+    the streaming the wide configs need (Llama-3-8B: 85 GB of covariances next to 85 GB of eigenvectors)."""
     del disable_tqdm
     out: FACTOR_TYPE = {name: {} for name in EIGENDECOMPOSITION_FACTOR_NAMES}
     jobs = []
@@ -113,13 +116,21 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
             if work.dtype not in (torch.float32, torch.float64):
                 work = work.to(torch.float32)
             evals, evecs, _ = ops.eigh(work, float(covariance_factors[count_name][module_name].item()), noise_rel=noise)
+            del work
+            if release_covariances:
+                del covariance_factors[cov_name][module_name]
+            # cast on the solver's own stream: the fp64 results (2 d^2 x 8 bytes) do not pile up until the exchange below
+            dtype = meta[(module_name, cov_name)][0]
+            evals, evecs = evals.to(dtype), evecs.to(dtype).contiguous()
         return evals, evecs
+
+    meta = {(job[0], job[1]): (covariance_factors[job[1]][job[0]].dtype, covariance_factors[job[1]][job[0]].shape[0]) for job in jobs}
 
     # The eigenproblems are independent and one Jacobi round kernel is latency / L2 bound far below the chip's
     # capacity, so several are kept in flight on separate HIP streams, each driven by its own host thread (the C
     # call releases the GIL and synchronises only its own stream, once per sweep).  Largest first.
     results = {}
-    order = sorted(mine, key=lambda job: -covariance_factors[job[1]][job[0]].shape[0])
+    order = sorted(mine, key=lambda job: -meta[(job[0], job[1])][1])
     lanes = max(1, min(EIGH_STREAMS, len(order))) if state.device.type == "cuda" else 1
     if lanes == 1:
         for job in order:
@@ -146,13 +157,12 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
     # Results travel in the factor's own dtype (fp32 unless the covariances were fp64): half the bytes of the fp64
     # solver output, tensor broadcasts over RCCL (no pickling), one per matrix.
     for index, (module_name, cov_name, count_name, vec_name, val_name) in enumerate(jobs):
-        cov = covariance_factors[cov_name][module_name]
-        original_dtype = cov.dtype
+        original_dtype, d = meta[(module_name, cov_name)]
         owner = index % world
-        d = cov.shape[0]
+        if release_covariances:
+            covariance_factors[cov_name].pop(module_name, None)   # (problems solved on other ranks)
         if (module_name, cov_name) in results:
             evals, evecs = results.pop((module_name, cov_name))
-            evals, evecs = evals.to(original_dtype), evecs.to(original_dtype).contiguous()
         else:
             evals = torch.empty(d, dtype=original_dtype, device=state.device)
             evecs = torch.empty((d, d), dtype=original_dtype, device=state.device)

@@ -59,14 +59,26 @@ class ScoreSink:
         return self._flat
 
 
-# Low-rank query gradients of layers applied to SEQUENCES (several rows per sample) are expanded to dense [q, O, I'] blocks
-# just ahead of the score GEMM, this many bytes (fp32) at a time; if ALL held queries of a layer fit, the expansion is done once
-# per train pass and cached.  (For R rows per sample the factored contraction costs 2 R k (O + I') flops per pair against
-# 2 O I' for the dense one -- with R = 512 tokens and k = 64 that is ten times MORE -- so for sequences low rank buys storage,
-# and the dense block is the cheaper way to spend flops; the block is made as large as HBM allows, since every block re-forms
-# the train batch's per-sample gradients.)  Layers with ONE row per sample use the factored contraction, below.
-LOW_RANK_EXPANSION_BYTES = 32 << 30
-LOW_RANK_CACHE_BYTES = 1 << 30  # per layer: only small expansions are kept for the whole train pass (storage is what low rank buys)
+# Low-rank query gradients ``[L_q [O, k], R_q [k, I']]`` against a train batch: the reference hands "qik,qko,b...i,b...o->qb" to
+# opt_einsum (module/linear.py:83-99), which picks the cheaper of two exact orders per call.  So does this tracker, per hook call,
+# with bytes in the model as well as flops (``_low_rank_plan``):
+#   * EXPAND  P_q = L_q R_q, then the dense score path: 2 O I' (k + b) flops per query and batch plus one write and one read of
+#     the O I' block -- right for narrow layers and large train batches (BERT: O I' = 0.6 M, b = 512).  If all held queries of a
+#     layer fit ``LOW_RANK_CACHE_BYTES`` the expansion is done once per train pass and kept; otherwise it is re-done per train
+#     batch in blocks of at most ``low_rank_block_bytes()`` (storage is what low rank buys).
+#   * FACTORED  scores[q, n] = sum_{r, k} (G_n L_q)[r, k] (A'_n R_q^T)[r, k]: 2 R k (O + I') flops per pair and NO O I' block --
+#     right when the block dominates: one row per sample (always), or wide layers against small batches (a Llama-3-8B MLP
+#     projection, O I' = 58.7 M, k = 64, 16 sequences: expanding costs 0.23 GB per query and batch, 3x the time of the factored
+#     flops).  Two tall NT GEMMs on the LDS-DMA engine + ``kf_lowrank_rows_dot``.
+LOW_RANK_CACHE_BYTES = 1 << 30  # per layer: only small expansions are kept for the whole train pass
+LOW_RANK_FACTORED_BYTES = 2 << 30  # bf16 bytes of ONE of the two [b R, q k] products per query chunk
+
+
+def low_rank_block_bytes(device) -> int:
+    """fp32 bytes of one expanded query block: a third of the HBM that is free right now, at most 32 GiB (the bf16 copy for the
+    score GEMM is another half of it)."""
+    free = torch.cuda.mem_get_info(device)[0] if device.type == "cuda" else 8 << 30
+    return int(max(256 << 20, min(32 << 30, free // 3)))
 
 
 def unpadded_queries(module, preconditioned):
@@ -145,6 +157,8 @@ class TiledQueries:
 class PairwiseScoreTracker(BaseTracker):
     _expanded = None  # (left factor, dense tensor): per-pass cache of expanded low-rank queries
 
+    LOW_RANK_ROW_CHUNK = 1 << 28   # fp32 elements of one [q_c, b, k] product of the one-row factored contraction
+
     def _score_low_rank_rows(self, left: torch.Tensor, right: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool,
                              scores: torch.Tensor, offset: int, scale: float) -> None:
         """One row per sample: ``scores[q, n] += sum_k (g_n . L_q[:, k]) (R_q[k, :] . a'_n)`` -- the reference's
@@ -161,13 +175,68 @@ class PairwiseScoreTracker(BaseTracker):
             self._low_rank_f32 = (left, left.float().contiguous(), right.float().contiguous())
         _, lf, rf = self._low_rank_f32
         dev = g.device
-        u = ops._bmm((q, b, k), ops.view(gq, 0, o, 1, b, o), ops.view(lf, o * k, 1, k, k, o), q, dev)          # [q, b, k] = g L_q
-        v = ops._bmm((q, b, k), ops.view(aq, 0, ip, 1, b, ip), ops.view(rf, k * ip, ip, 1, k, ip), q, dev)      # [q, b, k] = a' R_q^T
-        block = torch.empty(q * b, dtype=torch.float32, device=dev)
-        ops.rowwise_dot(block, u.reshape(q * b, k), v.reshape(q * b, k), scale=scale, accumulate=False)
-        scores[:, offset:offset + b].add_(block.view(q, b))
+        step = max(1, self.LOW_RANK_ROW_CHUNK // max(1, b * k))   # queries per chunk: bounds the two [q_c, b, k] temporaries
+        for first in range(0, q, step):
+            lc, rc = lf[first:first + step], rf[first:first + step]
+            qc = lc.shape[0]
+            u = ops._bmm((qc, b, k), ops.view(gq, 0, o, 1, b, o), ops.view(lc, o * k, 1, k, k, o), qc, dev)          # g L_q
+            v = ops._bmm((qc, b, k), ops.view(aq, 0, ip, 1, b, ip), ops.view(rc, k * ip, ip, 1, k, ip), qc, dev)      # a' R_q^T
+            block = torch.empty(qc * b, dtype=torch.float32, device=dev)
+            ops.rowwise_dot(block, u.reshape(qc * b, k), v.reshape(qc * b, k), scale=scale, accumulate=False)
+            scores[first:first + qc, offset:offset + b].add_(block.view(qc, b))
 
     _low_rank_f32 = None  # (left as held, left fp32, right fp32): per-pass cache for the factored contraction
+    _low_rank_stacked = None  # (left as held, L^T stacked [Q k, O], R stacked [Q k, W], bias column [Q k]): sequence layers
+
+    # effective rates of the plan's cost model (measured orders of magnitude, MI355X): tall bf16 NT GEMMs, HBM streams
+    _PLAN_FLOPS, _PLAN_BYTES = 8.0e14, 3.0e12
+
+    def _low_rank_plan(self, left: torch.Tensor, right: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool) -> str:
+        """``"factored"`` or ``"expand"`` for this hook call (see the module comment): estimated seconds of both exact orders."""
+        q, o, k = left.shape
+        ip = right.shape[2]
+        b, r = g.shape[0], g.shape[1]
+        if r == 1:
+            return "factored"
+        i = a.shape[-1]
+        eligible = (g.is_cuda and o % 8 == 0 and i % 8 == 0 and k % 8 == 0 and o >= 64 and i >= 64 and ip == i + int(ones)
+                    and b <= 65535)
+        if not eligible:
+            return "expand"
+        block = float(q) * o * ip
+        cached = block * 4 <= LOW_RANK_CACHE_BYTES
+        factored = 2.0 * b * r * q * k * (o + ip) / self._PLAN_FLOPS + 6.0 * b * r * q * k * 2 / self._PLAN_BYTES
+        expand = 2.0 * block * b / self._PLAN_FLOPS + block * 2 / self._PLAN_BYTES
+        if not cached:   # re-expanded on every train batch: fp32 product written, read, bf16 copy written
+            expand += 2.0 * block * k / self._PLAN_FLOPS + block * 10 / self._PLAN_BYTES
+        return "factored" if factored < expand else "expand"
+
+    def _score_low_rank_sequences(self, left: torch.Tensor, right: torch.Tensor, g: torch.Tensor, a: torch.Tensor, ones: bool,
+                                  scores: torch.Tensor, offset: int, scale: float) -> None:
+        """Several rows per sample, factored: ``U = G [L_1 .. L_Q]`` and ``V = A' [R_1^T .. R_Q^T]`` as two tall NT GEMMs over
+        all rows of the batch (bias column of ``R`` in the epilogue), then ``kf_lowrank_rows_dot`` over (row, k) per pair --
+        ``"qik,qko,b...i,b...o->qb"`` of module/linear.py:83-99 without any ``[O, I']`` block."""
+        q, o, k = left.shape
+        ip = right.shape[2]
+        b, r = g.shape[0], g.shape[1]
+        i = a.shape[-1]
+        if self._low_rank_stacked is None or self._low_rank_stacked[0] is not left:
+            lt = left.transpose(1, 2).to(torch.bfloat16).reshape(q * k, o).contiguous()
+            width = i + (-i) % 8   # the GEMM reads the first I columns; the bias column (if any) travels as a row addend
+            rt = right[..., :i].to(torch.bfloat16).reshape(q * k, i)
+            rt = torch.nn.functional.pad(rt, (0, width - i)).contiguous() if width != i else rt.contiguous()
+            bias = right[..., i].to(torch.float32).reshape(q * k).contiguous() if ones else None
+            self._low_rank_stacked = (left, lt, rt, bias)
+        _, lt, rt, bias = self._low_rank_stacked
+        g2 = (g if g.dtype == torch.bfloat16 else g.to(torch.bfloat16)).reshape(b * r, o)
+        a2 = (a if a.dtype == torch.bfloat16 else a.to(torch.bfloat16)).reshape(b * r, i)
+        step = max(1, LOW_RANK_FACTORED_BYTES // max(1, b * r * k * 2))
+        for first in range(0, q, step):
+            rows = slice(first * k, min(q, first + step) * k)
+            qc = (rows.stop - rows.start) // k
+            u = ops.rotate_bf16(g2, lt[rows])
+            v = ops.rotate_bf16(a2, rt[rows], bias[rows] if bias is not None else None)
+            ops.lowrank_rows_dot(scores[first:first + qc], offset, u, v, b, r, qc, k, scale=scale)
 
     def _query_blocks(self, preconditioned):
         """Yields ``(first_row, dense [q_c, O, I'])`` covering the held queries."""
@@ -189,7 +258,7 @@ class PairwiseScoreTracker(BaseTracker):
                 self._expanded = (left, dense_queries(preconditioned, score_dtype))
             yield 0, self._expanded[1]
             return
-        step = max(1, LOW_RANK_EXPANSION_BYTES // per_query)
+        step = max(1, low_rank_block_bytes(left.device) // per_query)
         for start in range(0, q, step):
             yield start, dense_queries([left[start:start + step], right[start:start + step]], score_dtype)
 
@@ -329,8 +398,9 @@ class PairwiseScoreTracker(BaseTracker):
                     a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
                                       append_ones=ones).reshape(n, r, -1)
                     ones = False
-                if isinstance(preconditioned, list) and g.shape[1] == 1:
-                    self._score_low_rank_rows(preconditioned[0], preconditioned[1], g, a, ones, scores, offset, module.gradient_scale)
+                if isinstance(preconditioned, list) and self._low_rank_plan(preconditioned[0], preconditioned[1], g, a, ones) == "factored":
+                    score = self._score_low_rank_rows if g.shape[1] == 1 else self._score_low_rank_sequences
+                    score(preconditioned[0], preconditioned[1], g, a, ones, scores, offset, module.gradient_scale)
                     return
                 fast = self._fast_layout(preconditioned, g, a, ones)
                 if fast is not None:
@@ -401,6 +471,7 @@ class PairwiseScoreTracker(BaseTracker):
         self.module.score_sink = None
         self._expanded = None
         self._low_rank_f32 = None
+        self._low_rank_stacked = None
         self.clear_all_cache()
 
     def release_memory(self) -> None:

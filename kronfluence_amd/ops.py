@@ -361,12 +361,26 @@ EIGH_SMALL_MAX = 96
 
 
 def eigh_small(g: torch.Tensor, inv_sqrt: bool = False, floor_rel: float = 1e-12) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Batched eigendecomposition of ``[batch, l, l]`` fp32 symmetric matrices, ``l <= 96`` (kf_eigh_small_batched):
+    """Batched eigendecomposition of ``[batch, l, l]`` fp32 symmetric matrices (kf_eigh_small_batched for ``l <= 96``, one
+    ``kf_eigh_f64`` problem per matrix above):
     eigenvalues DESCENDING, eigenvectors in columns; ``inv_sqrt`` scales column j by ``1/sqrt(lambda_j)``."""
     nat.require_device(g, "g")
     g = _contig(g)
     batch, l, l2 = g.shape
-    _require(g.dtype == torch.float32 and l == l2 and l <= EIGH_SMALL_MAX, 'g.dtype == torch.float32 and l == l2 and l <= EIGH_SMALL_MAX')
+    _require(g.dtype == torch.float32 and l == l2, 'g.dtype == torch.float32 and l == l2')
+    if l > EIGH_SMALL_MAX:
+        # beyond the in-LDS solver (ranks above 88): one kf_eigh_f64 problem per matrix -- slower (a host read-back per sweep
+        # below d = 256), same result
+        evals = torch.empty((batch, l), dtype=torch.float32, device=g.device)
+        evecs = torch.empty((batch, l, l), dtype=torch.float32, device=g.device)
+        for j in range(batch):
+            lam, vec, _ = eigh(g[j], 1.0)
+            lam, vec = lam.flip(0), vec.flip(1)
+            if inv_sqrt:
+                clipped = torch.maximum(lam, floor_rel * lam[:1].clamp(min=0.0))
+                vec = vec * torch.where(clipped > 0, clipped.rsqrt(), torch.zeros_like(clipped))
+            evals[j], evecs[j] = lam.float(), vec.float()
+        return evals, evecs
     evals = torch.empty((batch, l), dtype=torch.float32, device=g.device)
     evecs = torch.empty((batch, l, l), dtype=torch.float32, device=g.device)
     nat.check(
@@ -398,7 +412,7 @@ def low_rank_factors(p: torch.Tensor, rank: int, power_iterations: int = 2, over
     p = _contig(p)
     _require(p.dtype == torch.float32 and p.dim() == 3, 'p.dtype == torch.float32 and p.dim() == 3')
     q, o, ip = p.shape
-    l = min(rank + oversample, o, ip, EIGH_SMALL_MAX)
+    l = min(rank + oversample, o, ip)
     k = min(rank, l)
     dev = p.device
     gen = torch.Generator(device=dev).manual_seed(0x5eed)
@@ -776,6 +790,23 @@ def rowwise_dot(out: torch.Tensor, x: torch.Tensor, y: torch.Tensor, weight: Opt
         nat.lib().kf_rowwise_dot(out.data_ptr(), x.data_ptr(), nat.dtype_code(x.dtype), y.data_ptr(), nat.dtype_code(y.dtype),
                                  _ptr(weight), rows, d, scale, int(accumulate), nat.stream_ptr(x.device)),
         "kf_rowwise_dot",
+    )
+
+
+def lowrank_rows_dot(scores: torch.Tensor, col_offset: int, u: torch.Tensor, v: torch.Tensor, b: int, r: int, q: int, k: int,
+                     scale: float = 1.0) -> None:
+    """``scores[j, col_offset + n] += scale * sum_{t, c} u[n r + t, j k + c] v[n r + t, j k + c]`` for bf16 ``u, v: [b r, q k]``
+    (kf_lowrank_rows_dot): the reduction of the factored low-rank score of module/linear.py:83-99."""
+    nat.require_device(scores, "scores")
+    nat.require_device(u, "u")
+    _require(scores.dtype == torch.float32 and scores.is_contiguous() and u.dtype == v.dtype == torch.bfloat16
+             and u.is_contiguous() and v.is_contiguous() and u.shape == v.shape == (b * r, q * k),
+             "lowrank_rows_dot: fp32 scores, contiguous bf16 [b r, q k] operands")
+    _require(scores.shape[0] >= q and col_offset + b <= scores.shape[1], "lowrank_rows_dot: score block too small")
+    nat.check(
+        nat.lib().kf_lowrank_rows_dot(scores.data_ptr() + 4 * col_offset, scores.shape[1], u.data_ptr(), v.data_ptr(), b, r, q, k, scale,
+                                      nat.stream_ptr(u.device)),
+        "kf_lowrank_rows_dot",
     )
 
 

@@ -451,3 +451,90 @@ def test_llama_projection_full_width(o, i):
     err = rel(got, want)
     print(f"llama {o}x{i}: scores rel_F (bf16, heuristic damping) {err:.2e}; got {got.flatten().tolist()} want {want.flatten().tolist()}")
     assert got.shape == (n_query, n_train) and err <= 4e-2, err
+
+
+def test_llama_projection_low_rank_queries_full_width(monkeypatch):
+    """C5's query side at full width: a Llama-3-8B MLP up projection (14336 x 4096), T = 512, ``query_gradient_low_rank = 64``
+    (examples/openwebtext/files/scores_raw/score_arguments.json), 8 queries against 8 train sequences in batches of 4, bf16
+    preset.  The tracker must take the FACTORED contraction (a dense [O, I'] block per query is 235 MB: re-expanding the queries
+    per train batch would move 30x the bytes the factored form needs flops for) and its scores must match an fp64 restatement of
+    the reference's low-rank contraction ``"qik,qko,b...i,b...o->qb"`` (module/linear.py:83-99) on the captured train tensors and
+    the very factors the product held; the factors themselves are checked against the optimal rank-64 error (Eckart-Young, from
+    the eigenvalues of P^T P in fp64) for one query."""
+    from kronfluence_amd import FactorArguments, ScoreArguments, Task, prepare_model
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    class ProjTask(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return _proj_loss(model, tuple(batch))
+
+        def compute_measurement(self, batch, model):
+            return _proj_measure(model, tuple(batch))
+
+    o, i, t, n_train, n_query, rank = 14336, 4096, 512, 8, 8, 64
+    state = State()
+    dev = state.device
+    torch.manual_seed(0)
+    task = ProjTask()
+    model = prepare_model(Projection(i, o), task).to(dev)
+    tracked = [m for m in model.modules() if isinstance(m, TrackedModule)]
+    gen = torch.Generator().manual_seed(1)
+    train = (torch.randn(n_train, t, i, generator=gen).to(dev), torch.randint(0, o, (n_train, t), generator=gen).to(dev))
+    query = (torch.randn(n_query, t, i, generator=gen).to(dev), torch.randint(0, o, (n_query, t), generator=gen).to(dev))
+    low = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16, activation_covariance_dtype=torch.bfloat16,
+                          gradient_covariance_dtype=torch.bfloat16, per_sample_gradient_dtype=torch.bfloat16,
+                          lambda_dtype=torch.bfloat16)
+    q_a64, q_g64 = _householder(i, 11), _householder(o, 12)
+    lam = (torch.rand(o, i, generator=gen) + 0.5)   # any positive Lambda is a valid factor for the stage under test
+    factors = {"activation_eigenvectors": {"lin": q_a64.float()}, "gradient_eigenvectors": {"lin": q_g64.float()},
+               "activation_eigenvalues": {"lin": torch.ones(i)}, "gradient_eigenvalues": {"lin": torch.ones(o)},
+               "lambda_matrix": {"lin": lam}, "num_lambda_processed": {"lin": torch.tensor([1])}}
+    sargs = ScoreArguments(amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16,
+                           per_sample_gradient_dtype=torch.bfloat16, damping_factor=1e-2, query_gradient_low_rank=rank,
+                           query_gradient_accumulation_steps=2)   # both query batches are held, then ONE train pass
+
+    held = {}
+    original = PairwiseScoreTracker._score_low_rank_sequences
+
+    def recording(self, left, right, *args, **kwargs):
+        held.setdefault("factors", (left.clone(), right.clone()))
+        held["calls"] = held.get("calls", 0) + 1
+        return original(self, left, right, *args, **kwargs)
+
+    monkeypatch.setattr(PairwiseScoreTracker, "_score_low_rank_sequences", recording)
+    with Capture(tracked) as cap:
+        got = compute_pairwise_scores_with_loaders(factors, model, state, task, ResidentLoader(query, 4), 4,
+                                                   ResidentLoader(train, 4), sargs, low, None)["all_modules"]
+    assert held.get("calls") == 2, "the factored contraction was not taken for a 14336 x 4096 layer against 4 sequences"
+    left, right = (f.double() for f in held["factors"])          # [Q, O, k], [Q, k, I]  (bf16 as held)
+    assert left.shape == (n_query, o, rank) and right.shape == (n_query, rank, i)
+    trains = cap.held["lin"][2:]   # two query batches first, then the train batches
+    want = []
+    for xt, gt in trains:          # fp64 on the GPU: U = G L_q, V = A R_q^T, sum over (token, k)
+        xt, gt = xt.to(gt.dtype).double(), gt.double()
+        u = torch.einsum("nto,qok->qntk", gt, left)
+        v = torch.einsum("nti,qki->qntk", xt, right)
+        want.append((u * v).sum(dim=(2, 3)))
+    want = torch.cat(want, dim=1).cpu()
+    err = rel(got, want)
+    print(f"llama {o}x{i} low-rank {rank}: scores rel_F vs fp64 low-rank contraction {err:.2e}")
+    assert got.shape == (n_query, n_train) and err <= 4e-2, err
+
+    # the held factors of query 0 against the best possible rank-64 approximation of its preconditioned gradient
+    xq, gq = cap.held["lin"][0]
+    xq, gq = xq[0].to(gq.dtype).double(), gq[0].double()
+    q_a16, q_g16 = q_a64.float().to(torch.bfloat16).double().to(dev), q_g64.float().to(torch.bfloat16).double().to(dev)
+    psg = gq.t() @ xq                                                          # [O, I]
+    lam_inv = 1.0 / (lam.double().to(dev) + 1e-2)
+    p = q_g16 @ ((q_g16.t() @ psg @ q_a16) * lam_inv) @ q_a16.t()               # factor/config.py:341-353
+    total = float(p.square().sum())
+    top = torch.linalg.eigvalsh(p.t() @ p)[-rank:].sum()
+    best = max(total - float(top), 0.0) ** 0.5
+    mine = float((p - left[0] @ right[0]).norm())
+    print(f"rank-{rank} factors of query 0: error {mine / total ** 0.5:.4f} of ||P||, optimal {best / total ** 0.5:.4f}")
+    assert mine <= 1.05 * best + 4e-3 * total ** 0.5, (mine, best)
+

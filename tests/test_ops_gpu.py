@@ -851,6 +851,19 @@ def test_wave_role_split_64_loop_race_screen(ops):
     assert rel(first["lambda"], want) <= 1e-5
 
 
+@pytest.mark.parametrize("b,r,q,k", [(3, 64, 5, 64), (16, 128, 40, 64), (2, 512, 130, 32), (5, 72, 7, 24), (1, 8, 1, 8), (4, 64, 300, 128)])
+def test_lowrank_rows_dot(ops, b, r, q, k):
+    """kf_lowrank_rows_dot: ``scores[j, n] += scale * sum_{t, c} U[n r + t, j k + c] V[n r + t, j k + c]`` -- the reduction of the
+    factored low-rank score ("qik,qko,b...i,b...o->qb", module/linear.py:83-99) -- against torch in fp64 on the same bf16 values;
+    K / 8 a power of two (shuffle fold) and not (24: per-lane atomics), ragged column blocks, row splits."""
+    u, v = _rand(b * r, q * k, dtype=torch.bfloat16), _rand(b * r, q * k, dtype=torch.bfloat16, seed=1)
+    want = 0.5 * (u.double() * v.double()).reshape(b, r, q, k).sum(dim=(1, 3)).t()
+    scores = torch.full((q + 2, b + 3), 1.0, device=DEV)
+    ops.lowrank_rows_dot(scores, 2, u.to(DEV), v.to(DEV), b, r, q, k, scale=0.5)
+    assert rel(scores[:q, 2:2 + b] - 1.0, want) <= 1e-5
+    assert float((scores[q:] - 1.0).abs().max()) == 0.0 and float((scores[:, :2] - 1.0).abs().max()) == 0.0
+
+
 # ---- SURVEY.md 8(f) kernels: row-wise weighted dots, broadcast product, squared-operand GEMM ---------------------
 @pytest.mark.parametrize("rows,d", [(1, 1), (5, 37), (48, 16 * 17), (3, 1 << 20), (1000, 1024 * 8), (7, 4096 + 8)])
 @pytest.mark.parametrize("xdt,ydt", [(torch.float32, torch.float32), (torch.bfloat16, torch.float32),
@@ -939,7 +952,7 @@ def test_eigh_small_batched(ops, l):
     assert float(off.abs().max()) <= 1e-3
 
 
-@pytest.mark.parametrize("q,o,ip,k", [(3, 16, 13, 4), (2, 40, 120, 8), (5, 256, 300, 32), (2, 1024, 785, 64)])
+@pytest.mark.parametrize("q,o,ip,k", [(3, 16, 13, 4), (2, 40, 120, 8), (5, 256, 300, 32), (2, 1024, 785, 64), (2, 512, 400, 128)])
 def test_low_rank_factors_are_near_optimal(ops, q, o, ip, k):
     g = torch.Generator().manual_seed(q * 1000 + k)
     r = min(o, ip)

@@ -31,6 +31,32 @@ check1)
     ( KF_EIGH_VERBOSE=1 timeout 600 python tools/r04_ab.py eigh ) > gpurun_out/r04_ab_eigh.log 2>&1
     grep -v "kf_eigh\]" gpurun_out/r04_ab_eigh.log | tail -14
     ;;
+check2)
+    ( timeout 600 python -m pytest tests/test_ops_gpu.py -q -x -k "lowrank or low_rank or eigh_small" --durations=5 ) > gpurun_out/r04_check2_ops.log 2>&1
+    tail -4 gpurun_out/r04_check2_ops.log
+    ( timeout 900 python -m pytest tests/test_configs_gpu.py -q -x -k "low_rank" -s --durations=5 ) > gpurun_out/r04_check2_c5.log 2>&1
+    tail -8 gpurun_out/r04_check2_c5.log
+    ( timeout 600 python -m pytest tests/test_widen.py tests/test_distributed_gpu.py -q --durations=5 ) > gpurun_out/r04_check2_widen.log 2>&1
+    tail -4 gpurun_out/r04_check2_widen.log
+    for w in llama_block gpt2_small bert_base; do
+        ( timeout 900 python bench.py --workload $w --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r04_check2_bench_$w.json 2> gpurun_out/r04_check2_bench_$w.log
+        python - "$w" <<'PY'
+import json, sys
+w = sys.argv[1]
+try:
+    line = [l for l in open(f"gpurun_out/r04_check2_bench_{w}.json") if l.startswith("{")][-1]
+    r = json.loads(line)
+    print(w, "value", r["value"], "ms/step", r["ms_per_step"], "peak GiB", r["peak_hbm_gib"])
+    print("  factor_fit", r["factor_fit"])
+    for k in ("roofline", "roofline_cov", "roofline_lambda", "roofline_lambda_update"):
+        v = r.get(k) or {}
+        print("  ", k, {x: v.get(x) for x in ("achieved", "frac", "launches", "avg_launch_ms", "kernel_share_of_region", "model_share_of_region")})
+except Exception as e:
+    print(w, "FAILED", e)
+    print(open(f"gpurun_out/r04_check2_bench_{w}.log").read()[-3000:])
+PY
+    done
+    ;;
 suite)
     ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r04_pytest_gpu.log 2>&1
     tail -15 gpurun_out/r04_pytest_gpu.log
