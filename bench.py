@@ -727,6 +727,13 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             roofline_cov["traffic"] = traffic["cov_gemm_bytes_per_launch"]
             roofline_cov["traffic_source"] = "the covariance GEMM kernel with the most launches alone (cov_gemm_v3_kernel / cov_gemm_v2_kernel; per launch), same PMC passes as roofline.traffic"
             roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
+        # covariance calls whose rows arrive in fp32 (LayerNorm outputs under autocast with fp32 factors: BERT) run on the exact-fp32
+        # MFMA engine: their own line against that engine's peak
+        roofline_cov_f32 = (_event_summary(fit_events.get("syrk_accum_f32", []), PEAK_FP32_MFMA_TFLOPS, "kf_syrk_accum on fp32 rows "
+                                           "(syrk_kernel<F32>: v_mfma_f32_32x32x2_f32)", fit_times["covariance"]) if low else None)
+        if not low:
+            roofline_cov = _event_summary(fit_events.get("syrk_accum_f32", []) + fit_events.get("syrk_accum", []), peak,
+                                          "covariance calls: kf_syrk_accum (fp32 rows)", fit_times["covariance"])
         roofline_lambda = _event_summary(fit_events.get("lambda_accum", []), peak, "kf_lambda_rows_accum / kf_lambda_accum (factored form: the product of "
                                          "the rotated factors, 2 b R O I' flops) | kf_lambda_conv2d_accum (dense form of a Conv2d layer: "
                                          "pad + psg_gemm + rotate_gemm_v3<sumsq>, 2 b R O I' + 2 b O I'^2 flops)", fit_times["lambda"])
@@ -751,6 +758,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                           if n_train < spec.get("full_n_train", 0) else {})},
             "roofline": roofline,
             "roofline_cov": roofline_cov,
+            "roofline_cov_f32": roofline_cov_f32,
             "roofline_lambda": roofline_lambda,
             # the WHOLE Lambda update of a hook (eigenbasis rotations included) against F_lambda, the cheaper of the two exact
             # formulations
@@ -846,23 +854,26 @@ def main() -> None:
     if default_run:
         # N = 1: BERT-base and GPT-2-small at bounded sizes.  N > 1: GPT-2-small only -- the config the north-star scaling
         # target (>= 6x strong scaling 1 -> 8) is stated on -- sharded like the headline, same fixed size at every N.
-        others = ("bert_base", "gpt2_small") if world == 1 else ("gpt2_small",)
+        others = ("bert_base", "gpt2_small", "llama_block") if world == 1 else ("gpt2_small",)
         # BERT-base at its FULL 67 349 x 872 (configs[2]); GPT-2-small at 16 384 x 1 024 sequences of 512 tokens (the score
         # contraction dominates the stage from there on; the full 100 k x 2 k is the 8-GPU configuration).  The factors are
         # fitted on a bounded prefix (n_fit) and the warm-up step scores a small prefix, so the default run stays within minutes.
         sizes = {"bert_base": dict(n_train=WORKLOADS["bert_base"]["full_n_train"], n_fit=8192, warm_n_train=1024),
-                 "gpt2_small": dict(n_train=16384, n_fit=2048, warm_n_train=512)}
+                 "gpt2_small": dict(n_train=16384, n_fit=2048, warm_n_train=512),
+                 # configs[4] as a one-block slice at full width (C5 proper is 32 blocks x 100k x 1k on 8 GPUs): ONE cold factor
+                 # fit -- its 40 s are three 14336^2 eigendecompositions
+                 "llama_block": dict(n_train=64, n_fit=64, warm_n_train=16, factor_reps=0)}
         extras: Dict[str, dict] = {}
         for other in others:
             try:
                 # factor_reps=1: the reported fit is the second, warm one (the first GPT-2 covariance pass alone spends ~5 s in
                 # first-touch allocations and GEMM heuristics)
                 size = sizes[other]
-                r = run_workload(other, state, size["n_train"], None, steps=1, warmup=1, factor_reps=1, cpu_baseline=False,
+                r = run_workload(other, state, size["n_train"], None, steps=1, warmup=1, factor_reps=size.get("factor_reps", 1), cpu_baseline=False,
                                  n_fit=size["n_fit"], warm_n_train=size["warm_n_train"])
                 if rank == 0:
                     extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline",
-                                                      "roofline_cov", "roofline_lambda", "roofline_lambda_update", "factor_fit",
+                                                      "roofline_cov", "roofline_cov_f32", "roofline_lambda", "roofline_lambda_update", "factor_fit",
                                                       "exchanges", "peak_hbm_gib")}
             except Exception as error:  # an extra must never take the headline down with it
                 extras[other] = {"error": f"{type(error).__name__}: {error}"[:300]}

@@ -352,6 +352,13 @@ int64_t kf_pairwise_rows_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_
 int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G, const void* A,
                            int64_t b, int64_t R, int64_t O, int64_t I, int64_t Ip, int append_ones, float scale,
                            void* workspace, int64_t workspace_bytes, void* stream);
+/* The same with the train batch handed over in TWO segments (ABI 11): rows of (G, A) first (b0 samples -> score columns 0 .. b0),
+ * then (G1, A1) (b1 samples -> columns b0 .. b0 + b1); b1 == 0 ignores the second segment.  With b0 + b1 = 256 the score GEMM
+ * reads P once for two micro-batches of 128 -- at that batch size it is bound by the HBM stream of P (intensity = b flop/byte),
+ * not by the matrix cores.  Workspace: kf_pairwise_rows_workspace_bytes(b0 + b1, ...). */
+int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G, const void* A, int64_t b0,
+                            const void* G1, const void* A1, int64_t b1, int64_t R, int64_t O, int64_t I, int64_t Ip, int append_ones,
+                            float scale, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
  * out[r] (+)= scale * sum_i X[r,i] * Y[r,i] * (W ? W[i] : 1)      r < rows, i < D

@@ -74,6 +74,7 @@ SIGNATURES = {
     "kf_pairwise_score_conv2d": (_i, [_p, _i64, _p, _i64, _p, _p] + [_i64] * 5 + [_i] * 8 + [_f, _p, _i64, _p]),
     "kf_pairwise_rows_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "kf_pairwise_score_rows": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
+    "kf_pairwise_score_rows2": (_i, [_p, _i64, _p, _i64, _p, _p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
     "kf_eigh_small_batched": (_i, [_p, _i64, _i, _p, _p, _i, _f, _i, _p]),
     "kf_rowwise_dot": (_i, [_p, _p, _i, _p, _i, _p, _i64, _i64, _f, _i, _p]),
     "kf_lowrank_rows_dot": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _f, _p]),

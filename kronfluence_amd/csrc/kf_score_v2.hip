@@ -1859,11 +1859,21 @@ int64_t kf_pairwise_rows_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_
 int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G, const void* A, int64_t b,
                            int64_t R, int64_t O, int64_t I, int64_t Ip, int append_ones, float scale, void* workspace,
                            int64_t workspace_bytes, void* stream) {
-    if (!scores || !P_tiled || !G || !A || Q < 0 || b < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
+    return kf_pairwise_score_rows2(scores, ld_scores, P_tiled, Q, G, A, b, nullptr, nullptr, 0, R, O, I, Ip, append_ones, scale, workspace,
+                                   workspace_bytes, stream);
+}
+
+int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tiled, int64_t Q, const void* G, const void* A, int64_t b0,
+                            const void* G1, const void* A1, int64_t b1, int64_t R, int64_t O, int64_t I, int64_t Ip, int append_ones,
+                            float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!scores || !P_tiled || !G || !A || Q < 0 || b0 < 0 || b1 < 0 || R <= 0 || O <= 0 || I <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (b1 > 0 && (!G1 || !A1)) return KF_ERR_INVALID_ARGUMENT;
     if (R % 64 != 0 || O % 8 != 0 || I % 8 != 0 || Ip % 8 != 0 || Ip < I + (append_ones ? 1 : 0) || (O * Ip) % 64 != 0)
         return KF_ERR_INVALID_ARGUMENT;
-    if (((reinterpret_cast<uintptr_t>(P_tiled) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(A)) & 15) != 0)
+    if (((reinterpret_cast<uintptr_t>(P_tiled) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(A) |
+          reinterpret_cast<uintptr_t>(G1) | reinterpret_cast<uintptr_t>(A1)) & 15) != 0)
         return KF_ERR_INVALID_ARGUMENT;
+    const int64_t b = b0 + b1;
     if (!workspace || workspace_bytes < kf_pairwise_rows_workspace_bytes(b, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (Q == 0 || b == 0) return KF_OK;
     if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
@@ -1872,14 +1882,24 @@ int kf_pairwise_score_rows(float* scores, int64_t ld_scores, const void* P_tiled
     uint16_t* gt = reinterpret_cast<uint16_t*>(workspace);
     uint16_t* at = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align256(2 * b * O * R));
     uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(at) + align256(2 * b * Ip * R));
-    TransposeArgs t;
-    t.out = gt; t.x = reinterpret_cast<const uint16_t*>(G); t.T = static_cast<int>(R); t.C = static_cast<int>(O); t.Cp = static_cast<int>(O);
-    t.ones = 0; t.mask = nullptr; t.mask_dtype = 0;
-    hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(O, 64)), static_cast<unsigned>(b)),
-                       dim3(256), 0, st, t);
-    t.out = at; t.x = reinterpret_cast<const uint16_t*>(A); t.C = static_cast<int>(I); t.Cp = static_cast<int>(Ip); t.ones = append_ones ? 1 : 0;
-    hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(Ip, 64)), static_cast<unsigned>(b)),
-                       dim3(256), 0, st, t);
+    // the two segments (train micro-batches) land one behind the other in the transposed copies: from there on ONE batch of b0 + b1
+    const void* seg_g[2] = {G, G1};
+    const void* seg_a[2] = {A, A1};
+    const int64_t seg_b[2] = {b0, b1};
+    int64_t done = 0;
+    for (int seg = 0; seg < 2; ++seg) {
+        if (seg_b[seg] == 0) continue;
+        TransposeArgs t;
+        t.out = gt + done * O * R; t.x = reinterpret_cast<const uint16_t*>(seg_g[seg]); t.T = static_cast<int>(R); t.C = static_cast<int>(O);
+        t.Cp = static_cast<int>(O); t.ones = 0; t.mask = nullptr; t.mask_dtype = 0;
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(O, 64)), static_cast<unsigned>(seg_b[seg])),
+                           dim3(256), 0, st, t);
+        t.out = at + done * Ip * R; t.x = reinterpret_cast<const uint16_t*>(seg_a[seg]); t.C = static_cast<int>(I); t.Cp = static_cast<int>(Ip);
+        t.ones = append_ones ? 1 : 0;
+        hipLaunchKernelGGL(transpose_rows_kernel, dim3(static_cast<unsigned>(R / 64), static_cast<unsigned>(cdiv(Ip, 64)), static_cast<unsigned>(seg_b[seg])),
+                           dim3(256), 0, st, t);
+        done += seg_b[seg];
+    }
     PsgV2Args g{};
     g.out = psg; g.out_tile_stride = b * 64; g.out_rows = 0;
     g.A = gt; g.a_sample_stride = O * R; g.B = at; g.b_sample_stride = Ip * R;

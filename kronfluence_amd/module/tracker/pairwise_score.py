@@ -345,10 +345,70 @@ class PairwiseScoreTracker(BaseTracker):
                 return False
             a = activation if activation.dtype == torch.bfloat16 else activation.to(torch.bfloat16)
             b = activation.shape[0]
-            ops.pairwise_score_rows(scores, offset, tiled, output_gradient.reshape(b, rows, o), a.reshape(b, rows, i),
-                                    original.bias is not None, scale=module.gradient_scale)
+            self._score_rows_paired(scores, offset, tiled, output_gradient.reshape(b, rows, o), a.reshape(b, rows, i),
+                                    original.bias is not None, module.gradient_scale)
             return True
         return False
+
+    # Train micro-batches of a sequence layer are scored IN PAIRS when they are small: the score GEMM reads the whole P of the
+    # layer (Q O I' x 2 bytes: 1.2 - 4.8 GB per GPT-2 layer at 1 024 queries) once per launch, so at b = 128 sequences its
+    # arithmetic intensity is 128 flop/byte -- HBM bound (measured 5.5 TB/s on P alone, profiles/README.md round 4), not MFMA
+    # bound.  The hooked (gradient, activation) pair of one batch is therefore HELD (by reference; version-checked) until the
+    # next batch's hook of the same layer arrives, and both go through ONE call (kf_pairwise_score_rows2: b = 256, half the P
+    # traffic per pair, 256 x 256 tiles).  An odd last batch, a layer used twice per pass, non-adjacent score columns: the held
+    # batch is scored alone.  Bounded by ``PAIR_HOLD_FRACTION`` of the device memory over all layers.
+    PAIR_MAX_BATCH = 192          # micro-batches above this size fill the 256-row tile well enough on their own
+    PAIR_MIN_QUERIES = 256
+    PAIR_HOLD_FRACTION = 0.10
+    _pair_held = None             # (scores, offset, g, a, versions, ones, scale, bytes)
+    _pair_bytes_all_layers = [0]  # shared by every tracker of the process
+
+    def _score_rows_paired(self, scores, offset, tiled, g, a, ones, scale) -> None:
+        held = self._pair_held
+        b = g.shape[0]
+        if held is not None:
+            h_scores, h_offset, h_g, h_a, versions, h_ones, h_scale, _ = held
+            adjacent = (h_scores is scores and h_offset + h_g.shape[0] == offset and h_ones == ones and h_scale == scale
+                        and tuple(h_g.shape[1:]) == tuple(g.shape[1:]) and tuple(h_a.shape[1:]) == tuple(a.shape[1:])
+                        and h_g.shape[0] + b <= 65535)
+            if adjacent:
+                self._check_held_versions(h_g, h_a, versions)
+                self._drop_held()
+                ops.pairwise_score_rows(scores, h_offset, tiled, h_g, h_a, ones, scale=scale, second=(g, a))
+                return
+            self._flush_pair(tiled)
+        nbytes = (g.numel() + a.numel()) * 2
+        budget = self.PAIR_HOLD_FRACTION * torch.cuda.get_device_properties(g.device).total_memory if g.is_cuda else 0
+        if (self.module.score_sink is not None and b <= self.PAIR_MAX_BATCH and tiled.shape[0] >= self.PAIR_MIN_QUERIES
+                and self._pair_bytes_all_layers[0] + nbytes <= budget):
+            self._pair_held = (scores, offset, g, a, (g._version, a._version), ones, scale, nbytes)
+            self._pair_bytes_all_layers[0] += nbytes
+            return
+        ops.pairwise_score_rows(scores, offset, tiled, g, a, ones, scale=scale)
+
+    def _check_held_versions(self, g, a, versions) -> None:
+        if (g._version, a._version) != versions:
+            raise RuntimeError(
+                f"A tensor hooked at module '{self.module.name}' was modified in place while the score tracker held it for the next "
+                "train batch; make the offending operation out-of-place (or set PairwiseScoreTracker.PAIR_MAX_BATCH = 0).")
+
+    def _drop_held(self) -> None:
+        if self._pair_held is not None:
+            self._pair_bytes_all_layers[0] -= self._pair_held[-1]
+            self._pair_held = None
+
+    def _flush_pair(self, tiled=None) -> None:
+        """Scores a held micro-batch on its own (end of the train pass, or the next batch could not be paired with it)."""
+        held = self._pair_held
+        if held is None:
+            return
+        scores, offset, g, a, versions, ones, scale, _ = held
+        self._check_held_versions(g, a, versions)
+        self._drop_held()
+        if tiled is None:
+            tiled = self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
+        if isinstance(tiled, TiledQueries):
+            ops.pairwise_score_rows(scores, offset, tiled, g, a, ones, scale=scale)
 
     def register_hooks(self) -> None:
         module = self.module
@@ -443,6 +503,7 @@ class PairwiseScoreTracker(BaseTracker):
         """With ``aggregate_train_gradients`` the ``GradientTracker`` left the summed train gradient in storage:
         its dot product with every held query gradient is column 0 of the sink (reference ``pairwise_score.py:119-133``)."""
         module, storage = self.module, self.module.storage
+        self._flush_pair()   # a train micro-batch still waiting for a partner (odd number of batches)
         summed = storage[AGGREGATED_GRADIENT_NAME]
         if summed is not None and module.score_sink is not None:
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
@@ -475,5 +536,6 @@ class PairwiseScoreTracker(BaseTracker):
         self.clear_all_cache()
 
     def release_memory(self) -> None:
+        self._drop_held()
         self.clear_all_cache()
         self.module.storage[PAIRWISE_SCORE_MATRIX_NAME] = None

@@ -80,7 +80,10 @@ def syrk_accum(cov: torch.Tensor, x: torch.Tensor, n_rows: int, d_in: int, rows_
         nat.require_device(count, "count")
         _require(count.dtype == torch.int64, 'count.dtype == torch.int64')
     d = d_in + int(append_ones)
-    with _Timed("syrk_accum", x.device, float(n_rows) * d * (d + 1), float(n_rows) * d_in * x.element_size()):
+    # fp32 rows run on the exact-fp32 MFMA engine (v_mfma_f32_32x32x2_f32, 157 TFLOP/s peak): timed under their own name so that
+    # bench.py prices them against THAT peak, not the bf16 one
+    with _Timed("syrk_accum" if x.element_size() == 2 else "syrk_accum_f32", x.device, float(n_rows) * d * (d + 1),
+                float(n_rows) * d_in * x.element_size()):
         nat.check(
             nat.lib().kf_syrk_accum(cov.data_ptr(), cov.shape[1], x.data_ptr(), nat.dtype_code(x.dtype), n_rows, d_in,
                                     rows_inner, outer_stride, row_stride, col_stride, _ptr(mask),
@@ -744,16 +747,25 @@ def pairwise_score_conv2d(scores: torch.Tensor, col_offset: int, p, g_nchw: torc
 
 
 def pairwise_score_rows(scores: torch.Tensor, col_offset: int, p, g: torch.Tensor, a: torch.Tensor, append_ones: bool,
-                        scale: float = 1.0) -> None:
+                        scale: float = 1.0, second: Optional[Tuple[torch.Tensor, torch.Tensor]] = None) -> None:
     """Score of a Linear layer on ``[b, R, .]`` activations on the LDS-DMA kernels (kf_pairwise_score_rows): ``p.tiled`` is
     k-tile-major bf16 with the augmented axis padded to ``p.shape[2]`` (a multiple of 8); bias column and padding of the
-    train side are generated inside the call."""
+    train side are generated inside the call.  ``second = (g1, a1)``: a second train micro-batch whose scores go to the columns
+    right behind the first one's -- both are contracted in ONE score GEMM (kf_pairwise_score_rows2)."""
     nat.require_device(scores, "scores")
     nat.require_device(g, "g")
     g, a = _contig(g), _contig(a)
     _require(g.dtype == a.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32, 'g.dtype == a.dtype == p.tiled.dtype == torch.bfloat16 and scores.dtype == torch.float32')
-    b, r, o = g.shape
+    b0, r, o = g.shape
     i = a.shape[2]
+    g1 = a1 = None
+    b1 = 0
+    if second is not None:
+        g1, a1 = _contig(second[0]), _contig(second[1])
+        b1 = g1.shape[0]
+        _require(g1.dtype == a1.dtype == torch.bfloat16 and tuple(g1.shape[1:]) == (r, o) and tuple(a1.shape) == (b1, r, i),
+                 "pairwise_score_rows: the second segment must have the first one's row and feature counts")
+    b = b0 + b1
     q, ipp = p.shape[0], p.shape[2]
     _require(p.shape[1] == o and scores.shape[0] == q and col_offset + b <= scores.shape[1], 'p.shape[1] == o and scores.shape[0] == q and col_offset + b <= scores.shape[1]')
     ws_bytes = nat.lib().kf_pairwise_rows_workspace_bytes(b, r, o, ipp)
@@ -763,10 +775,10 @@ def pairwise_score_rows(scores: torch.Tensor, col_offset: int, p, g: torch.Tenso
     nbytes = b * r * (o + i) * 2 + q * o * ip * 2 + 2.0 * q * b * 4
     with _Timed("pairwise_score", g.device, flops, nbytes):
         nat.check(
-            nat.lib().kf_pairwise_score_rows(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.tiled.data_ptr(), q,
-                                             g.data_ptr(), a.data_ptr(), b, r, o, i, ipp, int(append_ones), scale,
-                                             ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
-            "kf_pairwise_score_rows",
+            nat.lib().kf_pairwise_score_rows2(scores.data_ptr() + 4 * col_offset, scores.shape[1], p.tiled.data_ptr(), q,
+                                              g.data_ptr(), a.data_ptr(), b0, _ptr(g1), _ptr(a1), b1, r, o, i, ipp, int(append_ones),
+                                              scale, ws.data_ptr(), ws_bytes, nat.stream_ptr(g.device)),
+            "kf_pairwise_score_rows2",
         )
 
 

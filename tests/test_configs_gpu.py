@@ -538,3 +538,71 @@ def test_llama_projection_low_rank_queries_full_width(monkeypatch):
     print(f"rank-{rank} factors of query 0: error {mine / total ** 0.5:.4f} of ||P||, optimal {best / total ** 0.5:.4f}")
     assert mine <= 1.05 * best + 4e-3 * total ** 0.5, (mine, best)
 
+
+def test_train_micro_batches_are_scored_in_pairs(monkeypatch):
+    """PairwiseScoreTracker holds the hooked tensors of a small train micro-batch of a sequence layer until the next batch's hook
+    and scores both in one call (GPT-2: 2 x 128 sequences -> one 256-wide score GEMM, half the HBM stream of P per pair).  Five
+    batches of 4 (two pairs + one flushed alone at the end of the pass), a model whose middle layer runs on fp32 LayerNorm
+    outputs, bf16 preset: the scores must equal the unpaired run's up to the atomics' summation order, and pairs must have
+    been formed."""
+    from kronfluence_amd import FactorArguments, ScoreArguments, Task, ops, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    class Seq(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.norm, self.b, self.c = nn.Linear(64, 128), nn.LayerNorm(128), nn.Linear(128, 128), nn.Linear(128, 64, bias=False)
+
+        def forward(self, x):
+            return self.c(torch.tanh(self.b(self.norm(torch.tanh(self.a(x))))))
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            x, y = batch
+            return F.mse_loss(model(x).float(), y, reduction="sum")
+
+        def compute_measurement(self, batch, model):
+            return self.compute_train_loss(batch, model)
+
+    torch.manual_seed(3)
+    state, task = State(), T()
+    dev = state.device
+    model = prepare_model(Seq(), task).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    train = (torch.randn(20, 64, 64, generator=gen).to(dev), torch.randn(20, 64, 64, generator=gen).to(dev))
+    query = (torch.randn(6, 64, 64, generator=gen).to(dev), torch.randn(6, 64, 64, generator=gen).to(dev))
+    fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16, per_sample_gradient_dtype=torch.bfloat16,
+                            lambda_dtype=torch.bfloat16)
+    sargs = ScoreArguments(amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16,
+                           per_sample_gradient_dtype=torch.bfloat16, damping_factor=None, query_gradient_accumulation_steps=2)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 10), fargs)
+    eig = perform_eigendecomposition(cov, model, state, fargs)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 10), fargs, eig)
+    calls = {"paired": 0, "single": 0}
+    real = ops.pairwise_score_rows
+
+    def counting(*args, second=None, **kwargs):
+        calls["paired" if second is not None else "single"] += 1
+        return real(*args, second=second, **kwargs)
+
+    monkeypatch.setattr(ops, "pairwise_score_rows", counting)
+    monkeypatch.setattr(PairwiseScoreTracker, "PAIR_MIN_QUERIES", 1)
+
+    def run():
+        return compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query, 3), 3,
+                                                    ResidentLoader(train, 4), sargs, fargs, None)["all_modules"].double()
+
+    paired = run()
+    assert calls == {"paired": 6, "single": 3}, calls   # 3 layers x (2 pairs + 1 flushed batch)
+    monkeypatch.setattr(PairwiseScoreTracker, "PAIR_MAX_BATCH", 0)
+    calls.update(paired=0, single=0)
+    alone = run()
+    assert calls == {"paired": 0, "single": 15}, calls
+    assert paired.shape == (6, 20) and rel(paired, alone) <= 2e-3, rel(paired, alone)   # bf16-rounded scores: one ulp apart at most
+    assert PairwiseScoreTracker._pair_bytes_all_layers[0] == 0
+

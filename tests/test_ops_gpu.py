@@ -483,6 +483,25 @@ def test_pairwise_score_rows_v2(ops, q, b, r, o, i, bias):
     assert rel(scores, want) <= 4e-3, rel(scores, want)
 
 
+@pytest.mark.parametrize("q,b0,b1,r,o,i,bias", [(300, 5, 4, 64, 64, 128, True), (40, 128, 128, 64, 128, 72, True), (9, 3, 1, 512, 256, 264, False)])
+def test_pairwise_score_rows_two_segments(ops, q, b0, b1, r, o, i, bias):
+    """kf_pairwise_score_rows2: two train micro-batches through ONE call land in adjacent score columns and equal two separate
+    calls (same bf16 per-sample gradients; the split-K atomics order differs)."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    width = i + int(bias)
+    pad = (-width) % 8
+    tiled = TiledQueries(_rand(q, o, width, seed=7).to(torch.bfloat16).to(DEV), pad)
+    g0, a0 = _rand(b0, r, o, dtype=torch.bfloat16).to(DEV), _rand(b0, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    g1, a1 = _rand(b1, r, o, dtype=torch.bfloat16, seed=2).to(DEV), _rand(b1, r, i, dtype=torch.bfloat16, seed=3).to(DEV)
+    apart, together = torch.zeros(q, b0 + b1 + 3, device=DEV), torch.zeros(q, b0 + b1 + 3, device=DEV)
+    ops.pairwise_score_rows(apart, 1, tiled, g0, a0, bias, scale=0.5)
+    ops.pairwise_score_rows(apart, 1 + b0, tiled, g1, a1, bias, scale=0.5)
+    ops.pairwise_score_rows(together, 1, tiled, g0, a0, bias, scale=0.5, second=(g1, a1))
+    assert rel(together, apart) <= 1e-5, rel(together, apart)
+    assert float(together[:, 0].abs().max()) == 0.0 and float(together[:, 1 + b0 + b1:].abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("q,b", [(520, 700), (1000, 1000), (130, 1000), (1000, 100)])
 def test_score_gemm_long_k_loops(ops, q, b):
     """The score GEMM at ResNet-9 scale (D = 128 x 1152, ragged tiles, all three tile shapes, split-K chunks of 100+
