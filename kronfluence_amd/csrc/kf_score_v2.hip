@@ -620,7 +620,10 @@ inline int half_tile_engine() {
     return engine_generation() == 3 ? 4 : 2;
 }
 
-inline bool wide_tile_enabled() { const char* e = getenv("KF_WIDE_TILE"); return !(e && atoi(e) == 0); }
+// 512 x 128 / 128 x 512 tiles (score_gemm_v5_kernel): measured within 4 % of the 256 x 128 loop on the shapes that take them
+// (GPT-2: 614 vs 588 us per launch, profiles/r04_ab_kernel_stats.csv) -- both sit on the HBM stream of P there -- so they are
+// opt-in (KF_WIDE_TILE=1: measurements, tests)
+inline bool wide_tile_enabled() { const char* e = getenv("KF_WIDE_TILE"); return e && atoi(e) == 1; }
 
 inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A/B measurements, fallback)
     const char* e = getenv("KF_ENGINE");

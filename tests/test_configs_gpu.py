@@ -232,6 +232,68 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
     assert corr(total, sum(v.double() for v in per16.values())) >= 0.9
 
 
+LATE_LAYERS = ["layers.11.attn_out", "layers.11.intermediate", "layers.11.output", "pooler", "classifier"]
+
+
+def test_assembled_bert_late_layers_bf16_preset_with_full_rank_factors():
+    """The layers the test above can only print (BERT's last block, the one-row pooler, the 2-row classifier: with 24 train
+    sequences their Lambda is rank <= 24 and the bf16 preset's scores there are rounding noise) with factors fitted by the PRODUCT
+    on 2 048 sequences -- every Lambda coordinate populated, the heuristic damping 10x below the mean instead of 1e4x above most
+    entries.  The bench's bf16 preset end to end (bf16 eigenvectors, bf16 P, bf16 gradients) against the fp64 oracle fed the same
+    factors (eigenvectors rounded to bf16 as the preset does) on the tensors hooked during the product's own passes: rel_F and
+    correlation ASSERTED for all five layers."""
+    import bench
+    from kronfluence_amd import prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    state = State()
+    dev = state.device
+    spec = bench.WORKLOADS["bert_base"]
+    torch.manual_seed(0)
+    raw = spec["model"]()
+    task, make_data, _, _, _, _ = bench.workload_parts(spec, raw)
+    model = prepare_model(raw, task).to(dev)
+    by_name = {m.name: m for m in model.modules() if isinstance(m, TrackedModule)}
+    n_fit, n_train, n_query = 2048, 24, 4
+    fit, query = make_data(spec, n_fit, 1, dev), make_data(spec, n_query, 2, dev)
+    train = tuple(t[:n_train] for t in fit)
+    fargs = bench.factor_arguments(spec)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(fit, 256), fargs, cpu=False)
+    eig = perform_eigendecomposition(cov, model, state, fargs, cpu=False)
+    del cov
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(fit, 256), fargs, eig, cpu=False)
+    sargs = bench.score_arguments(spec, n_query, 1, n_query)
+    sargs.compute_per_module_scores = True
+    sargs.damping_factor = None
+    with Capture([by_name[n] for n in LATE_LAYERS]) as cap:
+        got = compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query, n_query), n_query,
+                                                   ResidentLoader(train, n_train // 2), sargs, fargs, None)
+    measured = {}
+    for mod in LATE_LAYERS:
+        m = by_name[mod]
+        bias = m.original_module.bias is not None
+        (xq, gq), trains = cap.held[mod][0], cap.held[mod][1:]
+        psg_q = ref.linear_per_sample_gradient(xq.to(gq.dtype).double().cpu(), gq.double().cpu(), bias)
+        lam_inv = ref.ekfac_inverse_lambda(lam["lambda_matrix"][mod].double().cpu(), lam["num_lambda_processed"][mod].cpu(), None,
+                                           torch.float64)
+        p = ref.ekfac_precondition(psg_q, eig["activation_eigenvectors"][mod].to(torch.bfloat16).double().cpu(),
+                                   eig["gradient_eigenvectors"][mod].to(torch.bfloat16).double().cpu(), lam_inv)
+        want = torch.cat([ref.linear_pairwise_score(p, xt.to(gt.dtype).double().cpu(), gt.double().cpu(), bias) for xt, gt in trains],
+                         dim=1)
+        a, b = got[mod].double().cpu().flatten(), want.flatten()
+        ac, bc = a - a.mean(), b - b.mean()
+        measured[mod] = (rel(got[mod], want), float((ac @ bc) / (ac.norm() * bc.norm())))
+    print("bert_base late layers, bf16 preset, factors fitted on 2 048 sequences: (rel_F, correlation)",
+          {k: (f"{e:.1e}", f"{c:.4f}") for k, (e, c) in measured.items()})
+    assert max(e for e, _ in measured.values()) <= 1e-1, measured
+    assert min(c for _, c in measured.values()) >= 0.97, measured
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # (c) eigensolver at transformer sizes
 # ------------------------------------------------------------------------------------------------------------------

@@ -6,6 +6,7 @@ by the kernels, so the same bound applies against the oracle fed the up-cast inp
 """
 
 import math
+import os
 
 import pytest
 import torch
@@ -803,15 +804,14 @@ def test_lambda_rows_engine(ops, b, r, o, i, bias):
 @pytest.mark.parametrize("engine", ["wide", "half", "round2"])
 def test_score_gemm_half_tile_shapes(ops, q, b, engine, monkeypatch):
     """Score GEMMs whose train batch or query count is half a 256-row tile (GPT-2's train batches of 128 sequences; few queries
-    against many samples) on the three engines that take them: "wide" = the default choice, 512 x 128 / 128 x 512 tiles on the
-    two-phase wave-role-split loop where they pad no more (csrc/kf_pingpong.h, ppw) and 256 x 128 / 128 x 256 otherwise;
-    "half" = always 256 x 128 / 128 x 256 on the loop for 64 x 64 wave tiles (csrc/kf_pingpong64.h); "round2" = the lock-step
-    loop.  Against torch on the SAME bf16 per-sample gradients; long split-K chunks, ragged tiles, repeated launches, and
+    against many samples) on the three engines that take them: "half" = the default, 256 x 128 / 128 x 256 tiles on the loop for
+    64 x 64 wave tiles (csrc/kf_pingpong64.h); "wide" = KF_WIDE_TILE=1, 512 x 128 / 128 x 512 tiles on the two-phase
+    wave-role-split loop where they pad no more (csrc/kf_pingpong.h, ppw); "round2" = the lock-step loop.  Against torch on the SAME bf16 per-sample gradients; long split-K chunks, ragged tiles, repeated launches, and
     1 / 2 / 3 / 5 k-tiles per item (prologue and tail paths)."""
     from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 
-    if engine == "half":
-        monkeypatch.setenv("KF_WIDE_TILE", "0")
+    if engine == "wide":
+        monkeypatch.setenv("KF_WIDE_TILE", "1")
     elif engine == "round2":
         monkeypatch.setenv("KF_HALF_TILE_ENGINE", "2")
     r, o, i = 16, 128, 1152
@@ -854,7 +854,11 @@ def test_wave_role_split_64_loop_race_screen(ops):
             if launch % 3 != 2:
                 noise[: (launch % 5 + 1) << 25].add_(1)
         scores = torch.zeros(q, b, device=DEV)
-        ops.pairwise_score(scores, 0, p, g, a, False)            # 512 x 128 tiles (ppw loop)
+        os.environ["KF_WIDE_TILE"] = "1"
+        try:
+            ops.pairwise_score(scores, 0, p, g, a, False)        # 512 x 128 tiles (ppw loop; opt-in)
+        finally:
+            os.environ.pop("KF_WIDE_TILE", None)
         scores640 = torch.zeros(640, b, device=DEV)
         ops.pairwise_score(scores640, 0, p640, g, a, False)      # 256 x 128 tiles (pp64 loop)
         lam = torch.zeros(768, 769, device=DEV)

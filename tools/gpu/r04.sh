@@ -57,6 +57,14 @@ except Exception as e:
 PY
     done
     ;;
+check3)
+    ( timeout 900 python -m pytest tests/test_configs_gpu.py -q -x -k "late_layers or pairs" -s --durations=5 ) > gpurun_out/r04_check3_tests.log 2>&1
+    tail -8 gpurun_out/r04_check3_tests.log
+    ( timeout 600 python -m pytest tests/test_ops_gpu.py -q -x -k "half_tile or race_screen" ) > gpurun_out/r04_check3_ops.log 2>&1
+    tail -3 gpurun_out/r04_check3_ops.log
+    ( timeout 1500 python bench.py ) > gpurun_out/r04_check3_bench_default.json 2> gpurun_out/r04_check3_bench_default.log
+    python tools/bench_digest.py gpurun_out/r04_check3_bench_default.json || tail -c 2000 gpurun_out/r04_check3_bench_default.log
+    ;;
 suite)
     ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r04_pytest_gpu.log 2>&1
     tail -15 gpurun_out/r04_pytest_gpu.log

@@ -36,7 +36,7 @@ def timed(fn, reps=5, warm=2):
     return s.elapsed_time(e) / reps
 
 
-ENGINES = {"round2": {"KF_HALF_TILE_ENGINE": "2"}, "half64": {"KF_WIDE_TILE": "0"}, "wide": {}}
+ENGINES = {"round2": {"KF_HALF_TILE_ENGINE": "2"}, "half64": {}, "wide": {"KF_WIDE_TILE": "1"}}
 
 
 def set_engine(name):
@@ -67,7 +67,7 @@ def score():
             line += f" {eng} {t:7.3f} ms {flops / t / 1e9:6.0f} TF/s |"
         d = max(float((outs[e] - outs["round2"]).norm() / outs["round2"].norm()) for e in ENGINES)
         print(f"{line} max rel diff {d:.1e}{'' if d < 1e-4 else '   <-- MISMATCH'}", flush=True)
-    set_engine("wide")
+    set_engine("half64")
 
 
 def lam():
