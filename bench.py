@@ -816,6 +816,8 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip targets.mnist_mlp / other_configs in the default run")
     ap.add_argument("--factor-reps", type=int, default=1)
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
+    ap.add_argument("--n-fit", type=int, default=None, help="fit the factors on the first N train samples only (default: all)")
+    ap.add_argument("--warm-n-train", type=int, default=None, help="warm-up steps score against the first N train samples only")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
                     "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
                     "907 -> 862 ms; nothing of the EK-FAC path is affected)")
@@ -837,7 +839,7 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     line = run_workload(args.workload, state, args.n_train, args.n_query, args.steps, args.warmup, args.factor_reps,
-                        cpu_baseline=not args.no_cpu_baseline)
+                        cpu_baseline=not args.no_cpu_baseline, n_fit=args.n_fit, warm_n_train=args.warm_n_train)
     default_run = (args.workload == "resnet9" and args.n_train is None and args.n_query is None and not args.no_extras
                    and os.environ.get("KF_BENCH_EXTRAS", "1") != "0")
     if default_run and world == 1:

@@ -167,10 +167,8 @@ class PairwiseScoreTracker(BaseTracker):
         q, o, k = left.shape
         ip = right.shape[2]
         b = g.shape[0]
-        gq, aq = g.reshape(b, o).float().contiguous(), a.reshape(b, -1).float()
-        if ones:
-            aq = torch.cat([aq, aq.new_ones(b, 1)], dim=-1)
-        aq = aq.contiguous()
+        gq, aq = g.reshape(b, o).contiguous(), a.reshape(b, -1).contiguous()   # any float dtype: the GEMM loaders convert
+        i = aq.shape[1]                                                         # (bias: the loader supplies the ones column)
         if self._low_rank_f32 is None or self._low_rank_f32[0] is not left:
             self._low_rank_f32 = (left, left.float().contiguous(), right.float().contiguous())
         _, lf, rf = self._low_rank_f32
@@ -180,7 +178,7 @@ class PairwiseScoreTracker(BaseTracker):
             lc, rc = lf[first:first + step], rf[first:first + step]
             qc = lc.shape[0]
             u = ops._bmm((qc, b, k), ops.view(gq, 0, o, 1, b, o), ops.view(lc, o * k, 1, k, k, o), qc, dev)          # g L_q
-            v = ops._bmm((qc, b, k), ops.view(aq, 0, ip, 1, b, ip), ops.view(rc, k * ip, ip, 1, k, ip), qc, dev)      # a' R_q^T
+            v = ops._bmm((qc, b, k), ops.view(aq, 0, i, 1, b, i, ones_k=ones), ops.view(rc, k * ip, ip, 1, k, ip), qc, dev)   # a' R_q^T
             block = torch.empty(qc * b, dtype=torch.float32, device=dev)
             ops.rowwise_dot(block, u.reshape(qc * b, k), v.reshape(qc * b, k), scale=scale, accumulate=False)
             scores[first:first + qc, offset:offset + b].add_(block.view(qc, b))
@@ -350,6 +348,24 @@ class PairwiseScoreTracker(BaseTracker):
             return True
         return False
 
+    # Score kernels on a second stream (see ``backward_hook``): one stream per process, shared by all layers -- their kernels
+    # accumulate into one score block with atomics, so they stay ordered among themselves.  KF_SCORE_SIDE_STREAM=0 keeps
+    # everything on the caller's stream.
+    _SIDE: dict = {}
+    _side_done = None   # event: this layer's score kernels of the previous train batch
+
+    @classmethod
+    def _side_stream(cls, device):
+        import os
+
+        if device is None or device.type != "cuda" or os.environ.get("KF_SCORE_SIDE_STREAM", "1") == "0":
+            return None
+        stream = cls._SIDE.get("stream")
+        if stream is None or stream.device != device:
+            stream = torch.cuda.Stream(device=device)
+            cls._SIDE["stream"] = stream
+        return stream
+
     # Train micro-batches of a sequence layer are scored IN PAIRS when they are small: the score GEMM reads the whole P of the
     # layer (Q O I' x 2 bytes: 1.2 - 4.8 GB per GPT-2 layer at 1 024 queries) once per launch, so at b = 128 sequences its
     # arithmetic intensity is 128 flop/byte -- HBM bound (measured 5.5 TB/s on P alone, profiles/README.md round 4), not MFMA
@@ -424,6 +440,27 @@ class PairwiseScoreTracker(BaseTracker):
         def backward_hook(output_gradient: torch.Tensor) -> None:
             activation = self._take_activation()
             self.cached_hooks.pop().remove()
+            side = self._side_stream(output_gradient.device) if module.score_sink is not None else None
+            if side is None:
+                score_batch(activation, output_gradient)
+                return
+            # The layer's score kernels go to a SECOND HIP stream: they depend on nothing autograd computes after this hook, so
+            # they run beside the remaining backward pass of the model (its normalisation / pooling / elementwise kernels
+            # leave the matrix cores idle, the score GEMM leaves HBM idle) instead of in line with it.  Ordering: the side
+            # stream waits for everything enqueued so far (the hooked tensors, the held queries); the hooked tensors are
+            # marked as in use on it (the caching allocator will not hand their memory out before those kernels are done);
+            # ``finalize_all_iterations`` makes the main stream wait for the side stream before anyone reads the score block.
+            main = torch.cuda.current_stream(output_gradient.device)
+            if self._side_done is not None:
+                main.wait_event(self._side_done)   # at most one batch of this layer in flight: bounds what the side stream holds
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                score_batch(activation, output_gradient)
+                self._side_done = side.record_event()
+            activation.record_stream(side)
+            output_gradient.record_stream(side)
+
+        def score_batch(activation: torch.Tensor, output_gradient: torch.Tensor) -> None:
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
             if preconditioned is None:
                 raise RuntimeError(f"Module '{module.name}' holds no preconditioned query gradient.")
@@ -503,7 +540,14 @@ class PairwiseScoreTracker(BaseTracker):
         """With ``aggregate_train_gradients`` the ``GradientTracker`` left the summed train gradient in storage:
         its dot product with every held query gradient is column 0 of the sink (reference ``pairwise_score.py:119-133``)."""
         module, storage = self.module, self.module.storage
-        self._flush_pair()   # a train micro-batch still waiting for a partner (odd number of batches)
+        side = self._SIDE.get("stream") if self._side_done is not None else None
+        if side is not None:
+            with torch.cuda.stream(side):
+                self._flush_pair()   # a train micro-batch still waiting for a partner (odd number of batches)
+            torch.cuda.current_stream(side.device).wait_stream(side)   # the score block is complete for whoever reads it next
+            self._side_done = None
+        else:
+            self._flush_pair()
         summed = storage[AGGREGATED_GRADIENT_NAME]
         if summed is not None and module.score_sink is not None:
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]

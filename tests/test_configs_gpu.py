@@ -290,8 +290,8 @@ def test_assembled_bert_late_layers_bf16_preset_with_full_rank_factors():
         measured[mod] = (rel(got[mod], want), float((ac @ bc) / (ac.norm() * bc.norm())))
     print("bert_base late layers, bf16 preset, factors fitted on 2 048 sequences: (rel_F, correlation)",
           {k: (f"{e:.1e}", f"{c:.4f}") for k, (e, c) in measured.items()})
-    assert max(e for e, _ in measured.values()) <= 1e-1, measured
-    assert min(c for _, c in measured.values()) >= 0.97, measured
+    assert max(e for e, _ in measured.values()) <= 8e-2, measured   # measured 4.7e-3 ... 4.2e-2
+    assert min(c for _, c in measured.values()) >= 0.99, measured   # measured >= 0.9991
 
 
 # ------------------------------------------------------------------------------------------------------------------

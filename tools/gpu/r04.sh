@@ -65,6 +65,17 @@ check3)
     ( timeout 1500 python bench.py ) > gpurun_out/r04_check3_bench_default.json 2> gpurun_out/r04_check3_bench_default.log
     python tools/bench_digest.py gpurun_out/r04_check3_bench_default.json || tail -c 2000 gpurun_out/r04_check3_bench_default.log
     ;;
+sidestream)
+    # A/B of the score kernels on a second stream (KF_SCORE_SIDE_STREAM=0: in line with the model's backward pass)
+    for side in 0 1; do
+        ( KF_SCORE_SIDE_STREAM=$side timeout 600 python bench.py --steps 3 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r04_side${side}_resnet9.json 2> gpurun_out/r04_side${side}_resnet9.log
+        ( KF_SCORE_SIDE_STREAM=$side timeout 600 python bench.py --workload gpt2_small --n-train 4096 --n-fit 1024 --warm-n-train 256 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r04_side${side}_gpt2.json 2> gpurun_out/r04_side${side}_gpt2.log
+        ( KF_SCORE_SIDE_STREAM=$side timeout 600 python bench.py --workload bert_base --n-train 16384 --n-fit 2048 --warm-n-train 1024 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r04_side${side}_bert.json 2> gpurun_out/r04_side${side}_bert.log
+        for w in resnet9 gpt2 bert; do echo "== side stream $side: $w"; python tools/bench_digest.py gpurun_out/r04_side${side}_$w.json | head -3 || tail -c 1500 gpurun_out/r04_side${side}_$w.log; done
+    done
+    ( timeout 600 python -m pytest tests/test_configs_gpu.py tests/test_pipeline_gpu.py -q -x -k "pairs or goldens or late_layers" ) > gpurun_out/r04_side_tests.log 2>&1
+    tail -3 gpurun_out/r04_side_tests.log
+    ;;
 suite)
     ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r04_pytest_gpu.log 2>&1
     tail -15 gpurun_out/r04_pytest_gpu.log
