@@ -353,17 +353,32 @@ class PairwiseScoreTracker(BaseTracker):
     # everything on the caller's stream.
     _SIDE: dict = {}
     _side_done = None   # event: this layer's score kernels of the previous train batch
+    _use_side = None    # this layer's decision for the current train pass (sticky: its P is built on the stream that reads it)
+    SIDE_STREAM_MIN_FREE = 0.5
 
-    @classmethod
-    def _side_stream(cls, device):
+    def _side_stream(self, device):
+        """The second stream, or ``None``.  A second stream is a second pool of the caching allocator: measured on the MI355X
+        (profiles/README.md, round 4) it buys ResNet-9 +3.3 % (8.9 GiB in use) and COSTS BERT-base 2x / runs GPT-2-small out of
+        memory (174 - 250 GiB in use: the workspaces of the score kernels no longer reuse the blocks of the main pool).  So it is
+        taken only while more than half of the device memory is free at the layer's first hook of a pass;
+        KF_SCORE_SIDE_STREAM=0 / 1 forces it off / on."""
         import os
 
-        if device is None or device.type != "cuda" or os.environ.get("KF_SCORE_SIDE_STREAM", "1") == "0":
+        if device is None or device.type != "cuda":
             return None
-        stream = cls._SIDE.get("stream")
+        if self._use_side is None:
+            forced = os.environ.get("KF_SCORE_SIDE_STREAM")
+            if forced in ("0", "1"):
+                self._use_side = forced == "1"
+            else:
+                free, total = torch.cuda.mem_get_info(device)
+                self._use_side = free > self.SIDE_STREAM_MIN_FREE * total
+        if not self._use_side:
+            return None
+        stream = self._SIDE.get("stream")
         if stream is None or stream.device != device:
             stream = torch.cuda.Stream(device=device)
-            cls._SIDE["stream"] = stream
+            PairwiseScoreTracker._SIDE["stream"] = stream
         return stream
 
     # Train micro-batches of a sequence layer are scored IN PAIRS when they are small: the score GEMM reads the whole P of the
@@ -548,6 +563,7 @@ class PairwiseScoreTracker(BaseTracker):
             self._side_done = None
         else:
             self._flush_pair()
+        self._use_side = None
         summed = storage[AGGREGATED_GRADIENT_NAME]
         if summed is not None and module.score_sink is not None:
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]

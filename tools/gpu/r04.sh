@@ -95,6 +95,21 @@ record)
     ( timeout 1500 python bench.py ) > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.log
     tail -c 3000 gpurun_out/r04_bench_default.json
     ;;
+pmc_gpt2)
+    # the transformer kernels under the counters: three PMC passes + a kernel trace of a bounded GPT-2-small run
+    G2="python $GRAFT_REPO_ROOT/bench.py --workload gpt2_small --n-train 512 --n-fit 256 --steps 1 --warmup 0 --no-cpu-baseline --factor-reps 0"
+    ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace_g2" -- $G2 ) > gpurun_out/r04_trace_g2.log 2>&1
+    find gpurun_out/r04_trace_g2 -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_gpt2_n512_kernel_stats.csv \;
+    rm -rf gpurun_out/r04_trace_g2
+    for spec in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        set -- $spec; tag="$1"; shift
+        ( cd /tmp && timeout 500 rocprofv3 --pmc "$@" --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_pmcg2_$tag" -- $G2 ) > "gpurun_out/r04_pmcg2_$tag.log" 2>&1
+    done
+    ( python tools/pmc_summary.py gpt2_small profiles/pmc_gpt2_small.json gpurun_out/r04_pmcg2_fetch gpurun_out/r04_pmcg2_write gpurun_out/r04_pmcg2_mfma ) > gpurun_out/r04_pmcg2_summary.log 2>&1
+    cp profiles/pmc_gpt2_small.json gpurun_out/r04_pmc_gpt2_small.json
+    find gpurun_out/r04_pmcg2_fetch gpurun_out/r04_pmcg2_write gpurun_out/r04_pmcg2_mfma -name "*.csv" -size +4M -delete
+    head -c 2500 gpurun_out/r04_pmcg2_summary.log
+    ;;
 traces)
     for w in bert_base:2048 gpt2_small:1024; do
         name="${w%%:*}"; n="${w##*:}"

@@ -23,7 +23,7 @@ import sys
 from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SCORE_GEMM = ("score_gemm_v2_kernel", "score_gemm_v3_kernel")
+SCORE_GEMM = ("score_gemm_v2_kernel", "score_gemm_v3_kernel", "score_gemm_v4_kernel", "score_gemm_v5_kernel")
 PSG = ("psg_gemm_v2_kernel", "psg_gemm_v3_kernel", "psg_gemm_pp_kernel")
 # instantiations of the persistent gradient kernel that serve OTHER entry points: <1, .> rows for the dense-form Lambda, <2, .> the
 # query-side preconditioner
@@ -71,20 +71,20 @@ def score_call_bytes(kernels: dict, calls: int) -> float:
 
 
 def lambda_call_bytes(kernels: dict):
-    """-> (HBM bytes per kf_lambda_accum / kf_lambda_conv2d_accum call, calls, MFMA utilisation per Lambda kernel).  A factored call is one lambda_bf16_kernel / lambda_kernel launch; a dense call (Conv2d, R > O) is one
+    """-> (HBM bytes per kf_lambda_accum / kf_lambda_rows_accum / kf_lambda_conv2d_accum call, calls, MFMA utilisation per Lambda kernel).  A factored call is one lambda_rows_kernel / lambda_bf16_kernel / lambda_kernel launch; a dense call (Conv2d, R > O) is one
     conv_pad_phases_kernel + psg_gemm_v3_kernel<1> (rows ordered (o', n)) + rotate_gemm_v3_kernel<1> (sum-of-squares GEMM)."""
     dense = [e for n, e in kernels.items() if n.startswith("rotate_gemm_v3_kernel<1")]
-    parts = [e for n, e in kernels.items() if n.startswith(("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "rotate_gemm_v3_kernel<1",
-                                                             "psg_gemm_v3_kernel<1"))]
+    parts = [e for n, e in kernels.items() if n.startswith(("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "lambda_rows_kernel",
+                                                             "rotate_gemm_v3_kernel<1", "psg_gemm_v3_kernel<1"))]
     calls = sum(e["launches"] for n, e in kernels.items()
-                if n.startswith(("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "rotate_gemm_v3_kernel<1")))
+                if n.startswith(("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "lambda_rows_kernel", "rotate_gemm_v3_kernel<1")))
     if not calls:
         return None, 0, None
     total = sum(e["launches"] * (e.get("hbm_read_bytes", 0.0) + e.get("hbm_write_bytes", 0.0)) for e in parts)
     pad = next((e for n, e in kernels.items() if n.startswith("conv_pad_phases_kernel")), None)
     if pad is not None and dense:
         total += sum(e["launches"] for e in dense) * (pad.get("hbm_read_bytes", 0.0) + pad.get("hbm_write_bytes", 0.0))
-    names = ("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "rotate_gemm_v3_kernel<1", "psg_gemm_v3_kernel<1")
+    names = ("lambda_bf16_kernel", "kf::lambda_bf16_kernel", "lambda_kernel", "lambda_rows_kernel", "rotate_gemm_v3_kernel<1", "psg_gemm_v3_kernel<1")
     util = {n: e.get("mfma_util") for n, e in kernels.items() if n.startswith(names) and e.get("mfma_util") is not None}
     return total / calls, calls, util
 
