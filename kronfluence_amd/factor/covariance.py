@@ -14,7 +14,7 @@ from torch.utils import data
 from kronfluence_amd.arguments import FactorArguments
 from kronfluence_amd.module.tracked_module import ModuleMode
 from kronfluence_amd.module.utils import (
-    get_tracked_module_names, load_factors, set_attention_mask, set_gradient_scale, set_mode, synchronize_factors,
+    get_tracked_module_names, load_factors, set_attention_mask, set_gradient_scale, set_mode, set_side_stream, synchronize_factors,
     update_factor_args,
 )
 from kronfluence_amd.task import Task
@@ -73,18 +73,22 @@ def _fit_covariance_matrices_with_loader_impl(model: nn.Module, state: State, ta
     scale = _loss_scale(factor_args)
     if scale != 1.0:
         set_gradient_scale(model, 1.0 / scale)
-    for batch in loader:
-        batch = send_to_device(batch, state.device)
-        attention_mask = task.get_attention_mask(batch=batch)
-        if attention_mask is not None:
-            set_attention_mask(model, attention_mask)
-        with no_sync(model, state):
-            model.zero_grad(set_to_none=True)
-            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=factor_args.amp_dtype):
-                loss = task.compute_train_loss(batch=batch, model=model, sample=not factor_args.use_empirical_fisher)
-            (loss * scale if scale != 1.0 else loss).backward()
-        num_data_processed.add_(find_batch_size(batch))
-        del loss
+    set_side_stream(model, tracked_module_names, True)   # the hooks' kernels may run beside the model's passes ...
+    try:
+        for batch in loader:
+            batch = send_to_device(batch, state.device)
+            attention_mask = task.get_attention_mask(batch=batch)
+            if attention_mask is not None:
+                set_attention_mask(model, attention_mask)
+            with no_sync(model, state):
+                model.zero_grad(set_to_none=True)
+                with autocast(device_type=state.device.type, enabled=enable_amp, dtype=factor_args.amp_dtype):
+                    loss = task.compute_train_loss(batch=batch, model=model, sample=not factor_args.use_empirical_fisher)
+                (loss * scale if scale != 1.0 else loss).backward()
+            num_data_processed.add_(find_batch_size(batch))
+            del loss
+    finally:
+        set_side_stream(model, tracked_module_names, False)   # ... and are joined before the factors are read
     if state.use_distributed:
         synchronize_factors(model, COVARIANCE_FACTOR_NAMES, tracked_module_names, state.device, extra=[num_data_processed])
     saved: FACTOR_TYPE = {}

@@ -20,7 +20,7 @@ from kronfluence_amd.arguments import FactorArguments
 from kronfluence_amd.factor.covariance import _loss_scale
 from kronfluence_amd.module.tracked_module import ModuleMode
 from kronfluence_amd.module.utils import (
-    finalize_iteration, get_tracked_module_names, load_factors, set_factors, set_gradient_scale, set_mode,
+    finalize_iteration, get_tracked_module_names, load_factors, set_factors, set_gradient_scale, set_mode, set_side_stream,
     synchronize_factors, update_factor_args,
 )
 from kronfluence_amd.task import Task
@@ -35,7 +35,9 @@ from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
 from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
-EIGH_STREAMS = 8  # concurrent eigenproblems (HIP streams / host threads) per rank: the in-LDS solve of a round is latency
+import os as _os
+
+EIGH_STREAMS = int(_os.environ.get("KF_EIGH_STREAMS", "8"))  # concurrent eigenproblems (HIP streams / host threads) per rank: the in-LDS solve of a round is latency
                   # bound on a few dozen CUs, the other problems' streaming kernels fill the rest of the chip meanwhile
 
 
@@ -195,17 +197,21 @@ def _fit_lambda_matrices_with_loader_impl(model: nn.Module, state: State, task: 
     scale = _loss_scale(factor_args)
     if scale != 1.0:
         set_gradient_scale(model, 1.0 / scale)
-    for batch in loader:
-        batch = send_to_device(batch, state.device)
-        with no_sync(model, state):
-            model.zero_grad(set_to_none=True)
-            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=factor_args.amp_dtype):
-                loss = task.compute_train_loss(batch=batch, model=model, sample=not factor_args.use_empirical_fisher)
-            (loss * scale if scale != 1.0 else loss).backward()
-        if factor_args.has_shared_parameters:
-            finalize_iteration(model, tracked_module_names)
-        num_data_processed.add_(find_batch_size(batch))
-        del loss
+    set_side_stream(model, tracked_module_names, not factor_args.has_shared_parameters)   # see fit_covariance_matrices_with_loader
+    try:
+        for batch in loader:
+            batch = send_to_device(batch, state.device)
+            with no_sync(model, state):
+                model.zero_grad(set_to_none=True)
+                with autocast(device_type=state.device.type, enabled=enable_amp, dtype=factor_args.amp_dtype):
+                    loss = task.compute_train_loss(batch=batch, model=model, sample=not factor_args.use_empirical_fisher)
+                (loss * scale if scale != 1.0 else loss).backward()
+            if factor_args.has_shared_parameters:
+                finalize_iteration(model, tracked_module_names)
+            num_data_processed.add_(find_batch_size(batch))
+            del loss
+    finally:
+        set_side_stream(model, tracked_module_names, False)
     if state.use_distributed:
         synchronize_factors(model, LAMBDA_FACTOR_NAMES, tracked_module_names, state.device, extra=[num_data_processed])
     saved: FACTOR_TYPE = {}

@@ -101,6 +101,10 @@ class TrackedModule(nn.Module):
         # all-gather of a freshly preconditioned block from the backward hook (the loop calls ``synchronize`` after every query
         # batch).  Every other user of PRECONDITION_GRADIENT mode (self-influence with measurement, ...) exchanges nothing.
         self.async_query_gather: bool = False
+        # True only inside the stage loops of this package: the trackers may launch their hooks' kernels on a second stream
+        # (BaseTracker._run_beside) -- the loops join it before the results are read.  Direct users of the module API read
+        # ``storage`` right after backward(): everything stays on their stream.
+        self.side_stream_ok: bool = False
         self.storage: Dict[str, Any] = {}
         for key in (COVARIANCE_FACTOR_NAMES + EIGENDECOMPOSITION_FACTOR_NAMES + LAMBDA_FACTOR_NAMES
                     + [AGGREGATED_GRADIENT_NAME, PRECONDITIONED_GRADIENT_NAME,

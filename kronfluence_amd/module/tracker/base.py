@@ -109,6 +109,76 @@ class BaseTracker:
     def release_memory(self) -> None:
         """Free everything the mode keeps in ``module.storage``."""
 
+    # -- a second HIP stream for the hooks' kernels (OPT-IN: KF_SIDE_STREAM=1 or "auto") -----------------------------------
+    # The kernels a hook launches depend on nothing the model computes after the hook, so they can run BESIDE the rest of the
+    # model's pass (its normalisation / pooling / elementwise kernels leave the matrix cores idle, the EK-FAC GEMMs leave HBM
+    # idle) instead of in line with it.  One stream per process, shared by all layers and modes (kernels that accumulate into
+    # the same buffers stay ordered among themselves).  Measured on the MI355X (profiles/README.md, round 4): the ResNet-9
+    # pairwise stage gains 1.6 - 3.3 % (8.9 GiB in use); BERT-base LOSES 2x and GPT-2-small runs out of memory with 174 - 250
+    # GiB in use -- a second stream is a second pool of the caching allocator, the workspaces of the score kernels no longer
+    # reuse the blocks of the main pool -- and every overlapped kernel runs slower than alone, so the event-timed rooflines of
+    # bench.py no longer describe the kernels.  Hence off by default; "1" takes it always, "auto" only while more than half of
+    # the device memory is free at a layer's first hook of a pass (sticky for that pass).  Only the stage loops opt in
+    # (``TrackedModule.side_stream_ok``): they join the stream before anyone reads the results.  The hooked tensors are kept
+    # referenced until the layer's next call: autograd accumulates later gradient contributions IN PLACE into a buffer it
+    # alone owns (the output gradient of a projection feeding a residual sum is that sum's gradient), which would race with
+    # kernels that have not run yet.
+    _SIDE: dict = {}
+    _side_done = None   # event: this layer's kernels of the previous hook call on the side stream
+    _side_keep = None   # the hooked tensors of that call
+    _use_side = None    # this layer's decision for the current pass
+    SIDE_STREAM_MIN_FREE = 0.5
+
+    def _side_stream(self, device):
+        import os
+
+        if device is None or device.type != "cuda" or not getattr(self.module, "side_stream_ok", False):
+            return None
+        if self._use_side is None:
+            mode = os.environ.get("KF_SIDE_STREAM", "0")
+            if mode == "auto":
+                free, total = torch.cuda.mem_get_info(device)
+                self._use_side = free > self.SIDE_STREAM_MIN_FREE * total
+            else:
+                self._use_side = mode == "1"
+        if not self._use_side:
+            return None
+        stream = BaseTracker._SIDE.get("stream")
+        if stream is None or stream.device != device:
+            stream = torch.cuda.Stream(device=device)
+            BaseTracker._SIDE["stream"] = stream
+        return stream
+
+    def _run_beside(self, device, hooked, work) -> None:
+        """Runs ``work()`` (the kernels of one hook call) on the side stream when this layer uses it, else in line.  Ordering:
+        the side stream waits for everything enqueued so far (the hooked tensors, the factors); the main stream waits for this
+        layer's PREVIOUS call (at most one call per layer in flight: bounds what the side stream keeps alive); the ``hooked``
+        tensors are marked as in use on the side stream so that the allocator does not hand their memory out early."""
+        side = self._side_stream(device)
+        if side is None:
+            work()
+            return
+        main = torch.cuda.current_stream(device)
+        if self._side_done is not None:
+            main.wait_event(self._side_done)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            work()
+            self._side_done = side.record_event()
+        for tensor in hooked:
+            if tensor.is_cuda:
+                tensor.record_stream(side)
+        self._side_keep = tuple(hooked)
+
+    def _join_side(self) -> None:
+        """End of a pass: the caller's stream waits for the side stream; the decision is taken anew next pass."""
+        side = BaseTracker._SIDE.get("stream") if self._side_done is not None else None
+        if side is not None:
+            torch.cuda.current_stream(side.device).wait_stream(side)
+            self._side_done = None
+        self._side_keep = None
+        self._use_side = None
+
     # -- shared plumbing ---------------------------------------------------------------------------------------
     def release_hooks(self) -> None:
         self.clear_all_cache()

@@ -62,22 +62,36 @@ class CovarianceTracker(BaseTracker):
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
             del mod
-            cov, count = module.accumulate_activation_covariance(
-                storage[ACTIVATION_COVARIANCE_MATRIX_NAME], storage[NUM_ACTIVATION_COVARIANCE_PROCESSED],
-                _to_covariance_dtype(inputs[0].detach(), module.factor_args.activation_covariance_dtype))
-            storage[ACTIVATION_COVARIANCE_MATRIX_NAME] = cov
-            storage[NUM_ACTIVATION_COVARIANCE_PROCESSED] = count
+            hooked = inputs[0].detach()
+
+            def update() -> None:
+                cov, count = module.accumulate_activation_covariance(
+                    storage[ACTIVATION_COVARIANCE_MATRIX_NAME], storage[NUM_ACTIVATION_COVARIANCE_PROCESSED],
+                    _to_covariance_dtype(hooked, module.factor_args.activation_covariance_dtype))
+                storage[ACTIVATION_COVARIANCE_MATRIX_NAME] = cov
+                storage[NUM_ACTIVATION_COVARIANCE_PROCESSED] = count
+
+            # beside the rest of the forward pass when the stage loop allows it and memory is plentiful (BaseTracker._run_beside);
+            # the batch's attention mask is read by the same kernels and freed by the stage loop: kept alive for them too
+            mask = module.attention_mask
+            self._run_beside(hooked.device, (hooked,) if mask is None else (hooked, mask), update)
             self.cached_hooks.append(outputs.register_hook(backward_hook))
 
         @torch.no_grad()
         def backward_hook(output_gradient: torch.Tensor) -> None:
             self.cached_hooks.pop().remove()
             alpha = module.gradient_scale**2.0 if module.gradient_scale != 1.0 else 1.0  # factor.py:90-92
-            cov, count = module.accumulate_gradient_covariance(
-                storage[GRADIENT_COVARIANCE_MATRIX_NAME], storage[NUM_GRADIENT_COVARIANCE_PROCESSED],
-                _to_covariance_dtype(output_gradient.detach(), module.factor_args.gradient_covariance_dtype), alpha)
-            storage[GRADIENT_COVARIANCE_MATRIX_NAME] = cov
-            storage[NUM_GRADIENT_COVARIANCE_PROCESSED] = count
+            hooked = output_gradient.detach()
+
+            def update() -> None:
+                cov, count = module.accumulate_gradient_covariance(
+                    storage[GRADIENT_COVARIANCE_MATRIX_NAME], storage[NUM_GRADIENT_COVARIANCE_PROCESSED],
+                    _to_covariance_dtype(hooked, module.factor_args.gradient_covariance_dtype), alpha)
+                storage[GRADIENT_COVARIANCE_MATRIX_NAME] = cov
+                storage[NUM_GRADIENT_COVARIANCE_PROCESSED] = count
+
+            mask = module.attention_mask
+            self._run_beside(hooked.device, (hooked,) if mask is None else (hooked, mask), update)
 
         self.registered_hooks.append(module.register_forward_hook(forward_hook))
 
@@ -253,13 +267,17 @@ class LambdaTracker(BaseTracker):
                 weight = module.original_module.weight
                 o, ip = weight.shape[0], weight[0].numel() + int(module.has_bias)
                 rows = output_gradient.numel() // (output_gradient.shape[0] * o)
-                # "lambda_update": the whole Lambda update of this hook (rotations included) against F_lambda
-                with ops._Timed("lambda_update", output_gradient.device,
-                                output_gradient.shape[0] * self.algorithmic_flops(rows, o, ip),
-                                float(output_gradient.numel() + activation.numel()) * output_gradient.element_size()):
-                    if not self._update_conv_dense(activation, output_gradient.detach()):
-                        g, a, ones = module.gradient_factors(activation, output_gradient.detach())
-                        self._update_from_factors(g, a, ones)
+                hooked = output_gradient.detach()
+
+                def update() -> None:
+                    # "lambda_update": the whole Lambda update of this hook (rotations included) against F_lambda
+                    with ops._Timed("lambda_update", hooked.device, hooked.shape[0] * self.algorithmic_flops(rows, o, ip),
+                                    float(hooked.numel() + activation.numel()) * hooked.element_size()):
+                        if not self._update_conv_dense(activation, hooked):
+                            g, a, ones = module.gradient_factors(activation, hooked)
+                            self._update_from_factors(g, a, ones)
+
+                self._run_beside(hooked.device, (activation, hooked), update)
             else:
                 self._update_from_gradient(module.compute_per_sample_gradient(activation, output_gradient.detach()))
 

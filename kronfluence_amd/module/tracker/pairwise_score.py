@@ -348,39 +348,6 @@ class PairwiseScoreTracker(BaseTracker):
             return True
         return False
 
-    # Score kernels on a second stream (see ``backward_hook``): one stream per process, shared by all layers -- their kernels
-    # accumulate into one score block with atomics, so they stay ordered among themselves.  KF_SCORE_SIDE_STREAM=0 keeps
-    # everything on the caller's stream.
-    _SIDE: dict = {}
-    _side_done = None   # event: this layer's score kernels of the previous train batch
-    _use_side = None    # this layer's decision for the current train pass (sticky: its P is built on the stream that reads it)
-    SIDE_STREAM_MIN_FREE = 0.5
-
-    def _side_stream(self, device):
-        """The second stream, or ``None``.  A second stream is a second pool of the caching allocator: measured on the MI355X
-        (profiles/README.md, round 4) it buys ResNet-9 +3.3 % (8.9 GiB in use) and COSTS BERT-base 2x / runs GPT-2-small out of
-        memory (174 - 250 GiB in use: the workspaces of the score kernels no longer reuse the blocks of the main pool).  So it is
-        taken only while more than half of the device memory is free at the layer's first hook of a pass;
-        KF_SCORE_SIDE_STREAM=0 / 1 forces it off / on."""
-        import os
-
-        if device is None or device.type != "cuda":
-            return None
-        if self._use_side is None:
-            forced = os.environ.get("KF_SCORE_SIDE_STREAM")
-            if forced in ("0", "1"):
-                self._use_side = forced == "1"
-            else:
-                free, total = torch.cuda.mem_get_info(device)
-                self._use_side = free > self.SIDE_STREAM_MIN_FREE * total
-        if not self._use_side:
-            return None
-        stream = self._SIDE.get("stream")
-        if stream is None or stream.device != device:
-            stream = torch.cuda.Stream(device=device)
-            PairwiseScoreTracker._SIDE["stream"] = stream
-        return stream
-
     # Train micro-batches of a sequence layer are scored IN PAIRS when they are small: the score GEMM reads the whole P of the
     # layer (Q O I' x 2 bytes: 1.2 - 4.8 GB per GPT-2 layer at 1 024 queries) once per launch, so at b = 128 sequences its
     # arithmetic intensity is 128 flop/byte -- HBM bound (measured 5.5 TB/s on P alone, profiles/README.md round 4), not MFMA
@@ -455,25 +422,12 @@ class PairwiseScoreTracker(BaseTracker):
         def backward_hook(output_gradient: torch.Tensor) -> None:
             activation = self._take_activation()
             self.cached_hooks.pop().remove()
-            side = self._side_stream(output_gradient.device) if module.score_sink is not None else None
-            if side is None:
+            if module.score_sink is None:   # direct use of the module API: the caller reads storage right after backward()
                 score_batch(activation, output_gradient)
                 return
-            # The layer's score kernels go to a SECOND HIP stream: they depend on nothing autograd computes after this hook, so
-            # they run beside the remaining backward pass of the model (its normalisation / pooling / elementwise kernels
-            # leave the matrix cores idle, the score GEMM leaves HBM idle) instead of in line with it.  Ordering: the side
-            # stream waits for everything enqueued so far (the hooked tensors, the held queries); the hooked tensors are
-            # marked as in use on it (the caching allocator will not hand their memory out before those kernels are done);
-            # ``finalize_all_iterations`` makes the main stream wait for the side stream before anyone reads the score block.
-            main = torch.cuda.current_stream(output_gradient.device)
-            if self._side_done is not None:
-                main.wait_event(self._side_done)   # at most one batch of this layer in flight: bounds what the side stream holds
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                score_batch(activation, output_gradient)
-                self._side_done = side.record_event()
-            activation.record_stream(side)
-            output_gradient.record_stream(side)
+            # the layer's score kernels run beside the rest of the model's backward pass when memory allows (BaseTracker._run_beside);
+            # ``finalize_all_iterations`` joins the side stream before anyone reads the score block
+            self._run_beside(output_gradient.device, (activation, output_gradient), lambda: score_batch(activation, output_gradient))
 
         def score_batch(activation: torch.Tensor, output_gradient: torch.Tensor) -> None:
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
@@ -559,11 +513,9 @@ class PairwiseScoreTracker(BaseTracker):
         if side is not None:
             with torch.cuda.stream(side):
                 self._flush_pair()   # a train micro-batch still waiting for a partner (odd number of batches)
-            torch.cuda.current_stream(side.device).wait_stream(side)   # the score block is complete for whoever reads it next
-            self._side_done = None
         else:
             self._flush_pair()
-        self._use_side = None
+        self._join_side()            # the score block is complete for whoever reads it next
         summed = storage[AGGREGATED_GRADIENT_NAME]
         if summed is not None and module.score_sink is not None:
             preconditioned = storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]

@@ -218,6 +218,16 @@ def set_async_query_gather(model: nn.Module, tracked_module_names: Optional[List
         m.async_query_gather = enabled
 
 
+def set_side_stream(model: nn.Module, tracked_module_names: Optional[List[str]], enabled: bool) -> None:
+    """Stage loops only: lets the trackers run their hooks' kernels beside the model's pass (``BaseTracker._run_beside``);
+    switching it off joins the side stream first, so whatever the hooks accumulated is complete for the caller's stream."""
+    for m in _tracked(model, tracked_module_names):
+        if not enabled:
+            for tracker in m._trackers.values():
+                tracker._join_side()
+        m.side_stream_ok = enabled
+
+
 def truncate(model: nn.Module, tracked_module_names: List[str], keep_size: int) -> None:
     for m in _tracked(model, tracked_module_names):
         m.truncate(keep_size=keep_size)

@@ -18,7 +18,7 @@ from kronfluence_amd.arguments import FactorArguments, ScoreArguments
 from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
 from kronfluence_amd.module.tracker.pairwise_score import ScoreSink
 from kronfluence_amd.module.utils import (
-    finalize_all_iterations, finalize_iteration, set_mode, set_score_sink, synchronize_modules,
+    finalize_all_iterations, finalize_iteration, set_mode, set_score_sink, set_side_stream, synchronize_modules,
 )
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.comm import exchange
@@ -61,22 +61,26 @@ def compute_dot_products_with_loader(model: nn.Module, task: Task, state: State,
     }
     enable_amp = score_args.amp_dtype is not None
     offset = 0
-    for batch in train_loader:
-        batch = send_to_device(batch, state.device)
-        for m in modules:
-            m.score_sink = (sinks[m.name if score_args.compute_per_module_scores else ALL_MODULE_NAME], offset)
-        with no_sync(model, state):
-            model.zero_grad(set_to_none=True)
-            with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
-                loss = task.compute_train_loss(batch=batch, model=model, sample=False)
-            (loss * loss_scale if loss_scale != 1.0 else loss).backward()
-        if factor_args.has_shared_parameters:
-            finalize_iteration(model, tracked_module_names)
-        offset += find_batch_size(batch)
-        del loss
-    model.zero_grad(set_to_none=True)
-    set_score_sink(model, None, tracked_module_names)
-    finalize_all_iterations(model, tracked_module_names)
+    set_side_stream(model, tracked_module_names, True)   # the score kernels may run beside the model's backward pass
+    try:
+        for batch in train_loader:
+            batch = send_to_device(batch, state.device)
+            for m in modules:
+                m.score_sink = (sinks[m.name if score_args.compute_per_module_scores else ALL_MODULE_NAME], offset)
+            with no_sync(model, state):
+                model.zero_grad(set_to_none=True)
+                with autocast(device_type=state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                    loss = task.compute_train_loss(batch=batch, model=model, sample=False)
+                (loss * loss_scale if loss_scale != 1.0 else loss).backward()
+            if factor_args.has_shared_parameters:
+                finalize_iteration(model, tracked_module_names)
+            offset += find_batch_size(batch)
+            del loss
+        model.zero_grad(set_to_none=True)
+        set_score_sink(model, None, tracked_module_names)
+        finalize_all_iterations(model, tracked_module_names)   # flushes held micro-batches, joins the side stream
+    finally:
+        set_side_stream(model, tracked_module_names, False)
     set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=False)
 
     total_scores: SCORE_TYPE = {}

@@ -454,3 +454,51 @@ def test_bf16_sequence_linear_with_bias_is_padded_not_demoted(tmp_path):
         PairwiseScoreTracker.PAD_PATCH_AXIS = True
         PairwiseScoreTracker._fast_layout = original
     assert rel(padded, plain) <= 2e-3, rel(padded, plain)
+
+
+@pytest.mark.parametrize("kind", ["conv8", "seq_mse", "mlp"])
+def test_side_stream_execution_changes_nothing(kind, monkeypatch):
+    """The stage loops let the trackers launch their hooks' kernels on a second HIP stream beside the model's own passes
+    (BaseTracker._run_beside: taken while memory is plentiful, joined before results are read).  Forced on and forced off, all
+    three stages must produce the same factors and scores (up to the order of fp32 atomics)."""
+    from kronfluence_amd import FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.module.tracker.base import BaseTracker
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    state = State()
+    dev = state.device
+    task = make_task(kind)
+    model = prepare_model(fx.make_model(kind), task).to(dev)
+    train = tuple(t.to(dev) for t in fx.make_data(kind, 48, seed=1))
+    query = tuple(t.to(dev) for t in fx.make_data(kind, 6, seed=2))
+    fargs, sargs = FactorArguments(use_empirical_fisher=True), ScoreArguments(damping_factor=None)
+    used = []
+    real = BaseTracker._run_beside
+
+    def spying(self, device, hooked, work):
+        used.append(self._side_stream(device) is not None)
+        return real(self, device, hooked, work)
+
+    monkeypatch.setattr(BaseTracker, "_run_beside", spying)
+    out = {}
+    for side in ("0", "1"):
+        monkeypatch.setenv("KF_SIDE_STREAM", side)
+        used.clear()
+        _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 16), fargs)
+        eig = perform_eigendecomposition(cov, model, state, fargs)
+        _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 16), fargs, eig if side == "0" else out["0"][1])
+        scores = compute_pairwise_scores_with_loaders({**(eig if side == "0" else out["0"][1]), **lam}, model, state, task,
+                                                      ResidentLoader(query, 3), 3, ResidentLoader(train, 12), sargs, fargs, None)["all_modules"]
+        assert used and all(u == (side == "1") for u in used), (side, used[:5])
+        out[side] = (cov, eig, lam, scores)
+    for name in ("activation_covariance", "gradient_covariance"):
+        for module, tensor in out["0"][0][name].items():
+            assert rel(out["1"][0][name][module], tensor) <= 1e-6, (name, module)
+    for module, tensor in out["0"][2]["lambda_matrix"].items():
+        assert rel(out["1"][2]["lambda_matrix"][module], tensor) <= 1e-5, module
+    assert rel(out["1"][3], out["0"][3]) <= 1e-5
+

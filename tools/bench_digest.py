@@ -18,8 +18,9 @@ def show(name, r, indent=""):
     for key in ("roofline", "roofline_cov", "roofline_cov_f32", "roofline_lambda", "roofline_lambda_update"):
         v = r.get(key)
         if v:
-            extra = {k: round(v[k], 3) for k in ("kernel_share_of_region", "model_share_of_region", "precondition_share_of_region",
-                                                 "hbm_frac_of_8TBps", "mfma_util") if v.get(k) is not None}
+            extra = {k: (round(v[k], 3) if isinstance(v[k], (int, float)) else v[k])
+                     for k in ("kernel_share_of_region", "model_share_of_region", "precondition_share_of_region",
+                               "hbm_frac_of_8TBps", "mfma_util") if v.get(k) is not None}
             print(f"{indent}  {key}: {v['achieved']:.0f} {v['unit']} = {v['frac']:.3f} of peak, {v['launches']} launches x "
                   f"{v['avg_launch_ms']:.3f} ms, traffic {v.get('traffic')}  {extra}")
 

@@ -97,7 +97,8 @@ record)
     ;;
 pmc_gpt2)
     # the transformer kernels under the counters: three PMC passes + a kernel trace of a bounded GPT-2-small run
-    G2="python $GRAFT_REPO_ROOT/bench.py --workload gpt2_small --n-train 512 --n-fit 256 --steps 1 --warmup 0 --no-cpu-baseline --factor-reps 0"
+    export KF_EIGH_STREAMS=1   # one host thread launches kernels: rocprofv3 segfaulted twice with the eigen stage's eight
+    G2="python $GRAFT_REPO_ROOT/bench.py --workload gpt2_small --n-train 512 --n-fit 256 --steps 1 --warmup 1 --warm-n-train 128 --no-cpu-baseline --factor-reps 0"
     ( cd /tmp && timeout 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace_g2" -- $G2 ) > gpurun_out/r04_trace_g2.log 2>&1
     find gpurun_out/r04_trace_g2 -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_gpt2_n512_kernel_stats.csv \;
     rm -rf gpurun_out/r04_trace_g2
