@@ -111,6 +111,11 @@ pmc_gpt2)
     find gpurun_out/r04_pmcg2_fetch gpurun_out/r04_pmcg2_write gpurun_out/r04_pmcg2_mfma -name "*.csv" -size +4M -delete
     head -c 2500 gpurun_out/r04_pmcg2_summary.log
     ;;
+gpt2_full)
+    # configs[3] at its full train size on ONE GPU (the 8-GPU configuration's per-rank shard is an eighth of this): 100 000 x 1 024
+    ( timeout 1500 python bench.py --workload gpt2_small --n-train 100000 --n-fit 2048 --warm-n-train 512 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r04_bench_gpt2_full_100k.json 2> gpurun_out/r04_bench_gpt2_full_100k.log
+    python tools/bench_digest.py gpurun_out/r04_bench_gpt2_full_100k.json || tail -c 2000 gpurun_out/r04_bench_gpt2_full_100k.log
+    ;;
 traces)
     for w in bert_base:2048 gpt2_small:1024; do
         name="${w%%:*}"; n="${w##*:}"
