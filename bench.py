@@ -179,10 +179,11 @@ class LlamaSlice(nn.Module):
     """``blocks`` Llama-3-8B decoder blocks between a (reduced-vocabulary, untracked) embedding and head: the slice of
     configs[4] one GPU's worth of layers stands for.  Tracked: the seven projections of every block ("Linear layers only")."""
 
-    def __init__(self, blocks: int = 1, width: int = 4096, vocab: int = 32000) -> None:
+    def __init__(self, blocks: int = 1, width: int = 4096, vocab: int = 32000, heads: int = 32, kv_heads: int = 8,
+                 inter: int = 14336) -> None:
         super().__init__()
         self.embed = nn.Embedding(vocab, width)
-        self.layers = nn.ModuleList(_LlamaBlock(width) for _ in range(blocks))
+        self.layers = nn.ModuleList(_LlamaBlock(width, heads, kv_heads, inter) for _ in range(blocks))
         self.norm = nn.RMSNorm(width, eps=1e-5)
         self.lm_head = nn.Linear(width, vocab, bias=False)
 

@@ -668,3 +668,59 @@ def test_train_micro_batches_are_scored_in_pairs(monkeypatch):
     assert paired.shape == (6, 20) and rel(paired, alone) <= 2e-3, rel(paired, alone)   # bf16-rounded scores: one ulp apart at most
     assert PairwiseScoreTracker._pair_bytes_all_layers[0] == 0
 
+
+def test_llama_blocks_reduced_width_all_stages_vs_oracle():
+    """C5 as a MULTI-LAYER slice: two Llama decoder blocks (RMSNorm, grouped-query causal attention with 4 heads / 2 KV heads,
+    SwiGLU; the 14 bias-free projections tracked, "Linear layers only") at 1/16 width, T = 64, through all three stages of the
+    product in fp32 against the CPU oracle in fp64 on the same weights and tokens: covariances of all 14 layers, Lambda (oracle
+    fed the product's eigenvectors) and the summed pairwise scores (oracle fed the product's factors, heuristic damping)."""
+    import bench
+    from kronfluence_amd import FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    def build():
+        torch.manual_seed(0)
+        return bench.LlamaSlice(blocks=2, width=256, vocab=512, heads=4, kv_heads=2, inter=896)
+
+    state = State()
+    dev = state.device
+    raw = build()
+    names = raw.tracked_names()
+    assert len(names) == 14
+    task = bench.make_lm_task(names)
+    model = prepare_model(raw, task).to(dev)
+    gen = torch.Generator().manual_seed(1)
+    n_train, n_query, t = 32, 4, 64
+    train = (torch.randint(0, 512, (n_train, t), generator=gen),)
+    query = (torch.randint(0, 512, (n_query, t), generator=gen),)
+    train_d, query_d = (train[0].to(dev),), (query[0].to(dev),)
+    fargs, sargs = FactorArguments(use_empirical_fisher=True), ScoreArguments(damping_factor=None)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train_d, 8), fargs)
+    eig = perform_eigendecomposition(cov, model, state, fargs)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train_d, 8), fargs, eig)
+    scores = compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query_d, 2), 2,
+                                                  ResidentLoader(train_d, 8), sargs, fargs, None)["all_modules"]
+
+    engine = ref.OracleEngine(build().double(), module_names=names)
+    chunks = lambda data, bs: [tuple(x[i:i + bs] for x in data) for i in range(0, data[0].shape[0], bs)]   # noqa: E731
+    ocov = engine.fit_covariance(chunks(train, 8), bench.lm_loss)
+    worst = 0.0
+    for key in ("activation_covariance", "gradient_covariance"):
+        for module, want in ocov[key].items():
+            worst = max(worst, rel(cov[key][module], want))
+            assert rel(cov[key][module], want) <= 2e-5, (key, module)
+        for module, want in ocov[f"num_{key}_processed"].items():
+            assert int(cov[f"num_{key}_processed"][module]) == int(want)
+    eig64 = {k: {m: v.double() for m, v in d.items()} for k, d in eig.items()}
+    olam = engine.fit_lambda(chunks(train, 8), bench.lm_loss, eig64)
+    lam_err = max(rel(lam["lambda_matrix"][m], olam["lambda_matrix"][m]) for m in names)
+    lam64 = {"lambda_matrix": {m: v.double() for m, v in lam["lambda_matrix"].items()}, "num_lambda_processed": lam["num_lambda_processed"]}
+    want = engine.pairwise_scores(chunks(query, 2), chunks(train, 8), bench.lm_loss, bench.lm_loss, eig64, lam64, None)
+    err = rel(scores, want)
+    print(f"two Llama blocks at 1/16 width: covariances {worst:.1e}, Lambda {lam_err:.1e}, scores {err:.1e} (rel_F vs fp64 oracle)")
+    assert lam_err <= 2e-4 and scores.shape == (n_query, n_train) and err <= 2e-4, (lam_err, err)
+

@@ -76,6 +76,10 @@ sidestream)
     ( timeout 600 python -m pytest tests/test_configs_gpu.py tests/test_pipeline_gpu.py -q -x -k "pairs or goldens or late_layers" ) > gpurun_out/r04_side_tests.log 2>&1
     tail -3 gpurun_out/r04_side_tests.log
     ;;
+check4)
+    ( timeout 900 python -m pytest tests/test_configs_gpu.py -q -x -k "reduced_width" -s --durations=3 ) > gpurun_out/r04_check4_llama.log 2>&1
+    tail -6 gpurun_out/r04_check4_llama.log
+    ;;
 suite)
     ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r04_pytest_gpu.log 2>&1
     tail -15 gpurun_out/r04_pytest_gpu.log
