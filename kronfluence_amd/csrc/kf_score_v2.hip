@@ -1460,7 +1460,8 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     // contractions (>= 512 k-steps per tile pair: the convolutions) want ~2000 items -- 0.70 -> 0.64 ms (3x3 128 -> 128),
     // 0.72 -> 0.60 ms (256 -> 256 on 8 x 8) against ~1000; short ones (BERT / GPT-2 batches: 128 k-steps) want ~500, their
     // 64 KB staging epilogue per item is no longer small against the k-loop.
-    const int64_t target = steps >= 512 ? 2048 : 512;
+    int64_t target = steps >= 512 ? 2048 : 512;
+    if (const char* e = getenv("KF_COV_ITEMS")) target = std::max<int64_t>(1, atoll(e));   // measurements only
     const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(target, pairs), steps / 8}));
     c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
     const int64_t zblocks = cdiv(c.batch, c.zchunk);

@@ -307,6 +307,19 @@ def test_cpu_tensors_fail_loudly(ops):
 
     with pytest.raises(KfError):
         ops.eigh(torch.eye(3), 1.0)
+    # the round-4 entry points refuse host tensors and malformed operands just as loudly
+    g, a = torch.zeros(2, 64, 128, dtype=torch.bfloat16), torch.zeros(2, 64, 64, dtype=torch.bfloat16)
+    with pytest.raises(KfError):
+        ops.rotate_rows_transposed(g, torch.zeros(128, 128, dtype=torch.bfloat16))
+    with pytest.raises(KfError):
+        ops.lambda_rows_accum(torch.zeros(128, 64), g.transpose(1, 2).contiguous(), a.transpose(1, 2).contiguous())
+    with pytest.raises(KfError):
+        ops.lowrank_rows_dot(torch.zeros(4, 2), 0, torch.zeros(128, 32, dtype=torch.bfloat16), torch.zeros(128, 32, dtype=torch.bfloat16), 2, 64, 4, 8)
+    with pytest.raises(KfError):   # on the device, but the rows are not whole 64-deep k-tiles
+        ops.lambda_rows_accum(torch.zeros(128, 64, device=DEV), torch.zeros(2, 128, 40, dtype=torch.bfloat16, device=DEV),
+                              torch.zeros(2, 64, 40, dtype=torch.bfloat16, device=DEV))
+    with pytest.raises(KfError):   # contraction width of the rotation not a multiple of 64
+        ops.rotate_rows_transposed(torch.zeros(2, 64, 72, dtype=torch.bfloat16, device=DEV), torch.zeros(72, 72, dtype=torch.bfloat16, device=DEV))
 
 
 # ---- bf16 MFMA engine ------------------------------------------------------------------------------
