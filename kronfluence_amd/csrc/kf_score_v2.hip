@@ -1424,7 +1424,8 @@ inline int cov_engine(int64_t n_rows, int64_t steps) {  // 2 = 128-row tiles / 4
     // rows, 4000 k-steps: 1.56 -> 1.20 ms; 1152 rows: 0.70 -> 0.65 ms; 2304 rows, 1000 k-steps: 0.61 -> 0.52 ms), but loses when
     // the contraction is short (transformer batches of 128 k-steps: the 64 K staging atomics of a 256 x 256 tile weigh more
     // than its k-loop) or the extra MFMA work exceeds a third
-    return ((t3 * (t3 + 1) / 2) * 4 * 100 <= (t2 * (t2 + 1) / 2) * 134 && steps >= 512) ? 3 : 2;
+    // (round 4: also for very wide factors whatever the contraction length -- 14 336 rows, 64 k-steps: 2.02 -> 1.79 ms)
+    return ((t3 * (t3 + 1) / 2) * 4 * 100 <= (t2 * (t2 + 1) / 2) * 134 && (steps >= 512 || t3 >= 48)) ? 3 : 2;
 }
 
 int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
@@ -1456,13 +1457,17 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.tiles = static_cast<int>(cdiv(c.N, 128));
     c.np = c.tiles * 128;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = static_cast<int64_t>(c.batch) * (c.K >> 6);
-    // work items = tile pairs x sample ranges, each at least 8 k-steps long.  Measured (profiles/r02_cov_bench.log): long
-    // contractions (>= 512 k-steps per tile pair: the convolutions) want ~2000 items -- 0.70 -> 0.64 ms (3x3 128 -> 128),
-    // 0.72 -> 0.60 ms (256 -> 256 on 8 x 8) against ~1000; short ones (BERT / GPT-2 batches: 128 k-steps) want ~500, their
-    // 64 KB staging epilogue per item is no longer small against the k-loop.
+    // work items = tile pairs x sample ranges.  Measured (profiles/r02_cov_bench.log): long contractions (>= 512 k-steps per
+    // tile pair: the convolutions) want ~2000 items -- 0.70 -> 0.64 ms (3x3 128 -> 128), 0.72 -> 0.60 ms (256 -> 256 on 8 x 8)
+    // against ~1000; short ones want ~500.  Round 4 (profiles/r04_cov_items_ab.log): an item must also be LONG enough for its 64 KB
+    // staging epilogue -- at d = 768 (28 tile pairs: every BERT / GPT-2 attention-side factor) the best split is 16 sample
+    // ranges whatever the batch: 32 k-steps per item at 512 steps per pair (140 -> 85 us), 64 at 1 024 (188 -> 128 us), 16 at
+    // 128 (56 -> 49 us); the old floor of 8 k-steps per item cut those batches into 1 792 items of 8 k-steps.
     int64_t target = steps >= 512 ? 2048 : 512;
     if (const char* e = getenv("KF_COV_ITEMS")) target = std::max<int64_t>(1, atoll(e));   // measurements only
-    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(target, pairs), steps / 8}));
+    int64_t min_ksteps = std::max<int64_t>(16, std::min<int64_t>(64, steps / 16));
+    if (const char* e = getenv("KF_COV_MIN_KSTEPS")) min_ksteps = std::max<int64_t>(1, atoll(e));   // measurements only
+    const int64_t zsplit = std::max<int64_t>(1, std::min<int64_t>({static_cast<int64_t>(c.batch), cdiv(target, pairs), steps / min_ksteps}));
     c.zchunk = static_cast<int>(cdiv(c.batch, zsplit));
     const int64_t zblocks = cdiv(c.batch, c.zchunk);
     c.zblocks = static_cast<int>(zblocks);

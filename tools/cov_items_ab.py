@@ -9,10 +9,9 @@ import torch
 from kronfluence_amd import ops
 
 DEV = "cuda:0"
-SEQS = [("bert 768 T128 b256", 256, 128, 768, True), ("bert 3072 T128 b256", 256, 128, 3072, True), ("gpt2 768 T512 b64", 64, 512, 768, True),
-        ("gpt2 2304 T512 b64 (grad)", 64, 512, 2304, False), ("gpt2 3072 T512 b64", 64, 512, 3072, True), ("llama 4096 T512 b8", 8, 512, 4096, False),
-        ("llama 14336 T512 b8", 8, 512, 14336, False)]
-
+SEQS = [("bert 768 T128 b256", 256, 128, 768, True), ("bert 768 T128 b64", 64, 128, 768, True), ("bert 768 T128 b512", 512, 128, 768, True),
+        ("gpt2 768 T512 b64", 64, 512, 768, True), ("gpt2 768 T512 b16", 16, 512, 768, True), ("gpt2 768 T512 b128", 128, 512, 768, True),
+        ("1536 T128 b256", 256, 128, 1536, True), ("1536 T512 b64", 64, 512, 1536, False), ("llama 1024 T512 b8 (grad)", 8, 512, 1024, False)]
 
 def timed(fn, reps=10):
     for _ in range(2):
@@ -34,10 +33,8 @@ for name, bb, t_len, d_in, bias in SEQS:
     cov = torch.zeros(d, d, device=DEV)
     flops = float(bb * t_len) * d * (d + 1)
     line = f"{name:30s}"
-    for label, env in [("default", {}), ("v2/256", {"KF_COV_ENGINE": "2", "KF_COV_ITEMS": "256"}), ("v2/512", {"KF_COV_ENGINE": "2", "KF_COV_ITEMS": "512"}),
-                       ("v2/1024", {"KF_COV_ENGINE": "2", "KF_COV_ITEMS": "1024"}), ("v2/2048", {"KF_COV_ENGINE": "2", "KF_COV_ITEMS": "2048"}),
-                       ("v3", {"KF_COV_ENGINE": "3"})]:
-        for k in ("KF_COV_ENGINE", "KF_COV_ITEMS"):
+    for label, env in [("default", {})] + [(f"k>={m}", {"KF_COV_ENGINE": "2", "KF_COV_MIN_KSTEPS": str(m)}) for m in (8, 16, 32, 48, 64)] + [("v3", {"KF_COV_ENGINE": "3"})]:
+        for k in ("KF_COV_ENGINE", "KF_COV_ITEMS", "KF_COV_MIN_KSTEPS"):
             os.environ.pop(k, None)
         os.environ.update(env)
         t = timed(lambda: ops.linear_activation_cov(cov, count, x, None, bias))
