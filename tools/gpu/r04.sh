@@ -2,8 +2,14 @@
 # The GPU command lines of round 4, one sub-command each:  gpurun --timeout S -- 'bash tools/gpu/r04.sh <what>'
 #   check1    the new kernels: targeted GPU tests (Lambda rows engine, half / wide score tiles, race screens, eigensolver on product
 #             covariances), then tools/r04_ab.py under rocprofv3 --kernel-trace --stats (score, lambda) and its eigh part
+#   check2    low-rank kernels / C5 low-rank test + bounded benches of llama_block, gpt2_small, bert_base
+#   check3    pairing + late-layer tests, half-tile tests, one default bench
+#   check4    the multi-layer Llama slice test
+#   sidestream  A/B of the hooks' kernels on a second stream (KF_SIDE_STREAM) on three workloads
 #   suite     the full GPU suite + smoke
 #   record    kernel trace + the three PMC passes of the bench command (-> profiles/pmc_resnet9.json), default bench line
+#   pmc_gpt2  kernel trace (+ PMC passes: they segfault inside rocprofv3 on this workload) of a bounded GPT-2-small run
+#   gpt2_full configs[3] at its full train size on one GPU
 #   traces    per-kernel totals of one BERT-base and one GPT-2-small step at bounded sizes
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
