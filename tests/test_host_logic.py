@@ -195,3 +195,28 @@ def test_argument_defaults_and_presets_equal_the_references():
         module = mf if tag == "factor" else ms
         got = eval(f"module.{call}", {"module": module})  # noqa: S307 -- keys are our own fixture's function calls
         assert plain(got) == want, key
+
+
+def test_low_rank_plan_picks_the_cheaper_exact_order():
+    """``PairwiseScoreTracker._low_rank_plan``: the reference lets opt_einsum choose the contraction order of
+    "qik,qko,b...i,b...o->qb" per call (module/linear.py:83-99); here the choice is a bytes + flops estimate of the same two exact
+    orders.  Shapes only -- no arithmetic, so it runs on the CPU."""
+    from types import SimpleNamespace as T
+
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+
+    tracker = PairwiseScoreTracker.__new__(PairwiseScoreTracker)
+
+    def plan(q, o, i, k, b, r, ones, cuda=True):
+        ip = i + int(ones)
+        return tracker._low_rank_plan(T(shape=(q, o, k)), T(shape=(q, k, ip)), T(shape=(b, r, o), is_cuda=cuda), T(shape=(b, r, i)), ones)
+
+    assert plan(100, 1024, 1024, 32, 250, 1, True) == "factored"          # one row per sample: always
+    assert plan(872, 768, 768, 64, 512, 128, True) == "expand"             # BERT: narrow layer, large batch, expansion cached
+    assert plan(1024, 768, 3072, 64, 128, 512, True) == "expand"           # GPT-2: 2.4 M-element blocks against 128 x 512 rows
+    assert plan(1000, 14336, 4096, 64, 16, 512, False) == "factored"       # Llama-3-8B up projection, 16 sequences
+    assert plan(1000, 4096, 14336, 64, 8, 512, False) == "factored"        # ... down projection
+    assert plan(1000, 14336, 4096, 64, 256, 512, False) == "expand"        # the same layer against 256 sequences: flops win
+    assert plan(1000, 14340, 4096, 64, 16, 512, False) == "expand"         # O not a multiple of 8: the GEMM path does not apply
+    assert plan(1000, 14336, 4096, 64, 16, 512, False, cuda=False) == "expand"
+

@@ -262,3 +262,53 @@ def test_low_rank_query_gradients_match_reference(kind, tmp_path, engine):
                                                                        query_gradient_accumulation_steps=2,
                                                                        module_partitions=2))["all_modules"]
     assert rel(again, got) <= _tol(engine, 1e-5, 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("held_in_eigenbasis", [True, False])
+def test_query_batches_of_mixed_layout_accumulate(held_in_eigenbasis):
+    """``PreconditionTracker.accumulate_iterations`` with query batches laid out differently within one accumulation window (a
+    one-row batch -- held in the eigenbasis, fp32, unpadded -- among sequence batches -- parameter space, zero-padded -- or the other
+    way round): the later block is brought to the held layout (``Q_G^T P Q_A`` / ``Q_G M Q_A^T``, padding), as the reference accepts
+    such mixes (module/tracker/precondition.py:203-240)."""
+    from kronfluence_amd import Task, prepare_model
+    from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
+    from kronfluence_amd.utils.constants import (ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, ACTIVATION_EIGENVECTORS_NAME,
+                                                 GRADIENT_EIGENVECTORS_NAME, PRECONDITIONED_GRADIENT_NAME)
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return model(batch[0]).sum()
+
+        def compute_measurement(self, batch, model):
+            return model(batch[0]).sum()
+
+    dev = "cuda:0"
+    model = prepare_model(torch.nn.Sequential(torch.nn.Linear(15, 8)), T()).to(dev)
+    m = [x for x in model.modules() if isinstance(x, TrackedModule)][0]
+    m.current_mode = ModuleMode.PRECONDITION_GRADIENT
+    gen = torch.Generator().manual_seed(0)
+    q_a = torch.linalg.qr(torch.randn(16, 16, generator=gen, dtype=torch.float64))[0]
+    q_g = torch.linalg.qr(torch.randn(8, 8, generator=gen, dtype=torch.float64))[0]
+    m.storage[ACTIVATION_EIGENVECTORS_NAME], m.storage[GRADIENT_EIGENVECTORS_NAME] = q_a.float().to(dev), q_g.float().to(dev)
+    first, second = torch.randn(3, 8, 16, generator=gen), torch.randn(2, 8, 16, generator=gen)
+    pad = 0 if held_in_eigenbasis else 8
+    # first batch defines the held layout
+    m.storage[PRECONDITIONED_GRADIENT_NAME] = torch.nn.functional.pad(first, (0, pad)).to(dev)
+    m.queries_in_eigenbasis, m.query_padding = held_in_eigenbasis, pad
+    m.accumulate_iterations()
+    # second batch arrives in the other layout
+    other_pad = 8 if held_in_eigenbasis else 0
+    m.storage[PRECONDITIONED_GRADIENT_NAME] = torch.nn.functional.pad(second, (0, other_pad)).to(dev)
+    m.queries_in_eigenbasis, m.query_padding = not held_in_eigenbasis, other_pad
+    m.accumulate_iterations()
+    held = m.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME].dense().double().cpu()
+    assert m.queries_in_eigenbasis == held_in_eigenbasis and m.query_padding == pad and held.shape == (5, 8, 16 + pad)
+    if held_in_eigenbasis:
+        want = q_g.t() @ second.double() @ q_a
+    else:
+        want = q_g @ second.double() @ q_a.t()
+    assert torch.equal(held[:3, :, :16], first.double())
+    assert float((held[3:, :, :16] - want).norm() / want.norm()) <= 1e-5
+    assert float(held[..., 16:].abs().max()) == 0.0 if pad else True
+
