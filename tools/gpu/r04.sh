@@ -127,6 +127,7 @@ gpt2_full)
     python tools/bench_digest.py gpurun_out/r04_bench_gpt2_full_100k.json || tail -c 2000 gpurun_out/r04_bench_gpt2_full_100k.log
     ;;
 traces)
+    export KF_EIGH_STREAMS=1   # rocprofv3 segfaults when eight host threads launch the eigensolver's kernels at once
     for w in bert_base:2048 gpt2_small:1024; do
         name="${w%%:*}"; n="${w##*:}"
         ( cd /tmp && timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace_$name" -- \
