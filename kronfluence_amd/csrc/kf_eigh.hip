@@ -326,6 +326,26 @@ __global__ __launch_bounds__(256) void eigh_solve_kernel(const double* __restric
         G[r * LP + c] = 0.5 * (H[r * LP + c] + H[c * LP + r]);
     }
     __syncthreads();
+    // Early out (round 4): if no pair of THIS pass's set -- cross-block pairs, or the pairs inside the two blocks -- exceeds the
+    // rotation threshold on the Gram matrix as it arrived, no round below would rotate anything (G does not change without a
+    // rotation), so the 32 rounds x 2 barriers are skipped: exact, and it is the common case in the quadratic phase of the
+    // convergence and in the whole confirmation sweep.  (The in-LDS solve is latency bound -- 78 us per launch, 56 % of the
+    // eigensolver's kernel time at d = 3073, profiles/r04_bert_base_n2048_kernel_stats.csv.)
+    {
+        int need = 0;
+        for (int e = tid; e < KP * KP; e += 256) {
+            const int r = e / KP, c = e % KP;
+            const bool in_set = cross ? (r < KB && c >= KB) : (r < c && (r / KB) == (c / KB));
+            if (in_set) {
+                const double a = G[r * LP + r], b = G[c * LP + c], g = G[r * LP + c];
+                need |= (g * g > tol * tol * a * b && a > null2 && b > null2) ? 1 : 0;
+            }
+        }
+        if (!__syncthreads_or(need)) {
+            if (tid == 0) pair_flag[pair] = 0;
+            return;
+        }
+    }
     const int k = tid & 31, rg = tid >> 5;  // column pass: rotation k, rows rg + 8 j
     const int rounds = cross ? KB : KB - 1;
     int did = 0;

@@ -261,7 +261,8 @@ class PreconditionTracker(BaseTracker):
     def _change_basis(self, block: torch.Tensor, into_eigenbasis: bool) -> torch.Tensor:
         """``Q_G^T P Q_A`` (parameter space -> eigenbasis) or ``Q_G M Q_A^T`` (back) for a ``[q, O, I']`` block, fp32."""
         storage = self.module.storage
-        q_a, q_g = storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
+        q_a = storage[ACTIVATION_EIGENVECTORS_NAME].to(dtype=torch.float32).contiguous()
+        q_g = storage[GRADIENT_EIGENVECTORS_NAME].to(dtype=torch.float32).contiguous()
         block = block.to(torch.float32).contiguous()
         q, o, ip = block.shape
         t1 = torch.empty((q * o, ip), dtype=torch.float32, device=block.device)
