@@ -724,3 +724,58 @@ def test_llama_blocks_reduced_width_all_stages_vs_oracle():
     print(f"two Llama blocks at 1/16 width: covariances {worst:.1e}, Lambda {lam_err:.1e}, scores {err:.1e} (rel_F vs fp64 oracle)")
     assert lam_err <= 2e-4 and scores.shape == (n_query, n_train) and err <= 2e-4, (lam_err, err)
 
+
+def test_low_rank_contraction_orders_agree(monkeypatch):
+    """The two exact orders of the reference's low-rank contraction "qik,qko,b...i,b...o->qb" (module/linear.py:83-99) -- expand
+    ``L_q R_q`` and contract densely, or contract the factors with the rows of the batch -- on one sequence model, fp32 factors and
+    fp32 score dtypes, plan forced either way: same scores up to the bf16 rounding of the factored order's two row products, and
+    both within the low-rank approximation's own error of the full-rank scores."""
+    from kronfluence_amd import FactorArguments, ScoreArguments, Task, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    class Seq(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a, self.b = nn.Linear(64, 128), nn.Linear(128, 64, bias=False)
+
+        def forward(self, x):
+            return self.b(torch.tanh(self.a(x)))
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            x, y = batch
+            return F.mse_loss(model(x), y, reduction="sum")
+
+        def compute_measurement(self, batch, model):
+            return self.compute_train_loss(batch, model)
+
+    torch.manual_seed(11)
+    state, task = State(), T()
+    dev = state.device
+    model = prepare_model(Seq(), task).to(dev)
+    gen = torch.Generator().manual_seed(5)
+    train = (torch.randn(24, 64, 64, generator=gen).to(dev), torch.randn(24, 64, 64, generator=gen).to(dev))
+    query = (torch.randn(5, 64, 64, generator=gen).to(dev), torch.randn(5, 64, 64, generator=gen).to(dev))
+    fargs = FactorArguments(use_empirical_fisher=True)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 12), fargs)
+    eig = perform_eigendecomposition(cov, model, state, fargs)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 12), fargs, eig)
+
+    def run(rank, plan=None):
+        if plan is not None:
+            monkeypatch.setattr(PairwiseScoreTracker, "_low_rank_plan", lambda self, *a: plan)
+        sargs = ScoreArguments(damping_factor=None, query_gradient_low_rank=rank)
+        return compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query, 5), 5,
+                                                    ResidentLoader(train, 8), sargs, fargs, None)["all_modules"].double()
+
+    full = run(None)
+    expand, factored = run(48, "expand"), run(48, "factored")
+    agree, approx = rel(factored, expand), rel(expand, full)
+    print(f"low-rank 48 of 64: factored vs expanded order {agree:.1e}; expanded vs full rank {approx:.1e}")
+    assert agree <= 2e-2, (agree, approx)   # (the rank-48 approximation itself is only reported: its error is the data's, not the kernels')
+
