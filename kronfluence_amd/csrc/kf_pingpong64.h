@@ -7,9 +7,11 @@
 // accumulators of v_mfma_f32_32x32x16_bf16 (64 registers), 8 waves form a TA x TB tile (256 x 128: 4 x 2 waves, or
 // 128 x 256: 2 x 4), and ONE k-tile (64 deep) is ONE phase:
 //
-//     L(t)  16 ds_read_b128 (2 A blocks + 2 B blocks x 4 k-slabs) of k-tile t, the 6 LDS-DMA requests of k-tile t + 2,
-//           s_waitcnt vmcnt(6) (this wave's pieces of k-tile t + 1 have landed), lgkmcnt(0)
-//     M(t)  16 back-to-back MFMAs at raised priority (+ the caller's per-tile hook: the Lambda fold)
+//     L(t)  16 ds_read_b128 (2 A blocks + 2 B blocks x 4 k-slabs) of k-tile t, LREQ of the 6 LDS-DMA requests of k-tile t + 2,
+//           s_waitcnt vmcnt(LREQ) (this wave's pieces of k-tile t + 1 have landed), lgkmcnt(0)
+//     M(t)  16 MFMAs at raised priority in four groups, the other 6 - LREQ requests between the groups (+ the caller's per-tile
+//           hook: the Lambda fold).  LREQ = 6 is the plain form the ordering argument below is written for; the Lambda kernel
+//           runs LREQ = 0 (measured fastest), see the note at `mainloop`.
 //
 // separated by raw s_barriers; waves 4-7 ("Y", on the same four SIMDs as waves 0-3, "X") run one barrier behind, so per SIMD
 // one wave is in L while the other is in M (cdna_hip_programming.md section 5, T3-T5).
@@ -81,10 +83,20 @@ struct PlainCtl {
 // acc[i][jn] (i: 32-row blocks of the wave's 64 A rows, jn: 32-column blocks of its 64 B rows) (+)= A B^T over k-tiles [0, nt).
 // walk_a(t) / walk_b(t): element offset of k-tile t relative to Sources::p.  `wave` must be wave-uniform.  All 512 threads;
 // sm: Geo::SMEM_BYTES of LDS.  On return every wave has finished reading LDS.
-template <int TA, int TB, class WalkA, class WalkB, class Ctl>
+// LREQ: how many of the NA + NB requests of k-tile t + 2 are issued in L(t); the rest ride between the MFMA groups of M(t)
+// (an LDS-DMA request costs ~60 cycles of issue among bare MFMAs but 100-185 inside a segment that already carries 16
+// ds_read_b128, MI355X_MICROARCH.md).  Ordering with LREQ < NA + NB: the late requests are issued in M(t) -- X in S_2t+1, Y in
+// S_2t+2, still after every read of the stage they overwrite (L(t - 1)) -- and are covered by the issuing wave's counted wait at
+// the end of ITS L(t + 1) (vmcnt(LREQ): only the early requests of k-tile t + 3 may still be in flight), i.e. before the barrier
+// that opens the first segment reading k-tile t + 2.
+template <int TA, int TB, int LREQ, class WalkA, class WalkB, class Ctl>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], unsigned char* sm, const Sources<TA, TB>& src, int nt, int wave,
                                          int lane, WalkA walk_a, WalkB walk_b, Ctl& ctl) {
     using G = Geo<TA, TB>;
+    static_assert(LREQ >= 0 && LREQ <= G::NA + G::NB, "requests issued in the L segment");
+    constexpr int NREQ = G::NA + G::NB, LATE = NREQ - LREQ;
+    // late requests after MFMA groups kk = 0, 1, 2: as even as possible
+    constexpr int LATE0 = (LATE + 2) / 3, LATE1 = (LATE - LATE0 + 1) / 2, LATE2 = LATE - LATE0 - LATE1;
     const int wm = wave / G::WB, wn = wave % G::WB, role = wave >> 2;
     const int lr = lane & 31, hi = lane >> 5, sw = (lr >> 1) & 7;
     int co[4];
@@ -93,13 +105,16 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], unsigned char* sm,
     const unsigned char* frag_a = sm + (wm * 64 + lr) * 128;
     const unsigned char* frag_b = sm + G::A_BYTES + (wn * 64 + lr) * 128;
 
-    auto issue = [&](int stage, int64_t oa, int64_t ob) {
+    auto issue_range = [&](int stage, int64_t oa, int64_t ob, int first, int count) {   // requests [first, first + count)
         unsigned char* base = sm + stage * G::STAGE_BYTES;
 #pragma unroll
-        for (int r = 0; r < G::NA; ++r) glds16(src.p[r] + oa, base + (r * 8 + wave) * 1024);
-#pragma unroll
-        for (int r = 0; r < G::NB; ++r) glds16(src.p[G::NA + r] + ob, base + G::A_BYTES + (r * 8 + wave) * 1024);
+        for (int r = 0; r < NREQ; ++r) {
+            if (r < first || r >= first + count) continue;
+            if (r < G::NA) glds16(src.p[r] + oa, base + (r * 8 + wave) * 1024);
+            else glds16(src.p[r] + ob, base + G::A_BYTES + ((r - G::NA) * 8 + wave) * 1024);
+        }
     };
+    auto issue = [&](int stage, int64_t oa, int64_t ob) { issue_range(stage, oa, ob, 0, NREQ); };
     bf16x8 a[2][4], b[2][4];
     auto read_frags = [&](int stage) {
 #pragma unroll
@@ -125,30 +140,40 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[2][2], unsigned char* sm,
         int64_t oa = 0, ob = 0;   // walks first: an offset read from an LDS table is then the oldest LDS request
         if (more2) { oa = walk_a(t + 2); ob = walk_b(t + 2); }
         read_frags(rd);
-        if (more2) { issue(wr, oa, ob); pp::wait_vmcnt<G::NA + G::NB>(); }   // in flight: k-tile t + 2 only
-        else pp::wait_vmcnt<0>();                                            // k-tile t + 1 (if any) has landed
+        if (more2) { issue_range(wr, oa, ob, 0, LREQ); pp::wait_vmcnt<LREQ>(); }   // in flight: the early requests of k-tile t + 2 only
+        else pp::wait_vmcnt<0>();                                                  // k-tile t + 1 (if any) has landed
         pp::wait_lds_reads();
         pp::barrier();
         __builtin_amdgcn_s_setprio(1);
+        // four groups of four MFMAs (k-slabs); the late requests of k-tile t + 2 ride between them
+        auto late = [&](int first, int count) {
+            if (count > 0 && more2) {
+                __builtin_amdgcn_sched_barrier(0);
+                issue_range(wr, oa, ob, first, count);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
         if (ctl.first(t)) {
             const f32x16 zero = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jn][0], zero, 0, 0, 0);
-#pragma unroll
-            for (int kk = 1; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[jn][kk], acc[i][jn], 0, 0, 0);
         } else {
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][0], b[jn][0], acc[i][jn], 0, 0, 0);
+        }
+        late(LREQ, LATE0);
 #pragma unroll
-                    for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[jn][kk], acc[i][jn], 0, 0, 0);
+        for (int kk = 1; kk < 4; ++kk) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jn = 0; jn < 2; ++jn) acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][kk], b[jn][kk], acc[i][jn], 0, 0, 0);
+            if (kk == 1) late(LREQ + LATE0, LATE1);
+            if (kk == 2) late(LREQ + LATE0 + LATE1, LATE2);
         }
         __builtin_amdgcn_s_setprio(0);
         ctl.done(t, acc);

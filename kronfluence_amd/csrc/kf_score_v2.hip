@@ -374,7 +374,7 @@ __global__ __launch_bounds__(pp64::THREADS) void score_gemm_v4_kernel(ScoreV2Arg
     f32x16 acc[2][2];
     zero_acc(acc);
     pp64::PlainCtl ctl;
-    pp64::mainloop<TA, TB>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; }, ctl);
+    pp64::mainloop<TA, TB, 6>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; }, ctl);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -466,6 +466,7 @@ struct LambdaFold {
     }
 };
 
+template <int LREQ>
 __global__ __launch_bounds__(pp64::THREADS) void lambda_rows_kernel(LambdaRowsArgs a) {
     using G = pp64::Geo<256, 128>;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -495,7 +496,7 @@ __global__ __launch_bounds__(pp64::THREADS) void lambda_rows_kernel(LambdaRowsAr
     zero_acc(acc);
     zero_acc(sum);
     LambdaFold ctl{sum, 0, a.KS};
-    pp64::mainloop<256, 128>(acc, sm, src, (z_end - z_begin) * a.KS, wave, lane,
+    pp64::mainloop<256, 128, LREQ>(acc, sm, src, (z_end - z_begin) * a.KS, wave, lane,
                              [&](int t) { int zq, ks; split(t, zq, ks); return zq * stride_g + ks * 64; },
                              [&](int t) { int zq, ks; split(t, zq, ks); return zq * stride_a + ks * 64; }, ctl);
 #pragma unroll
@@ -1492,7 +1493,11 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v5_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PPW_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v5_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, PPW_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
@@ -1962,8 +1967,18 @@ int kf_lambda_rows_accum(float* Lambda, int64_t ld_lambda, const void* GtT, cons
     a.zblocks = static_cast<int>(zblocks);
     const int64_t blocks = 8 * cdiv(zblocks * tiles, 8);
     if (blocks >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
-    hipLaunchKernelGGL(lambda_rows_kernel, dim3(static_cast<unsigned>(blocks)), dim3(pp64::THREADS), PP64_SMEM,
-                       as_stream(stream), a);
+    // LDS-DMA requests of a k-tile issued in the L segment, the rest between the MFMA groups of the M segment.  Measured
+    // (profiles/r04_lreq_ab.log): ALL of them in M is the fastest on every shape -- 768 x 3073 809 -> 929 TFLOP/s, 3072 x 769
+    // 802 -> 854, Llama 4096^2 995 -> 1 041 -- the L segment (16 fragment reads + 6 requests at 100-185 cycles each) was
+    // longer than the M segment it alternates with.  KF_PP64_LREQ = 6 / 4 / 3 / 2: measurements.
+    int lreq = 0;
+    if (const char* e = getenv("KF_PP64_LREQ")) lreq = atoi(e);
+    const dim3 grid(static_cast<unsigned>(blocks)), block(pp64::THREADS);
+    if (lreq == 4) hipLaunchKernelGGL(lambda_rows_kernel<4>, grid, block, PP64_SMEM, as_stream(stream), a);
+    else if (lreq == 3) hipLaunchKernelGGL(lambda_rows_kernel<3>, grid, block, PP64_SMEM, as_stream(stream), a);
+    else if (lreq == 2) hipLaunchKernelGGL(lambda_rows_kernel<2>, grid, block, PP64_SMEM, as_stream(stream), a);
+    else if (lreq == 0) hipLaunchKernelGGL(lambda_rows_kernel<0>, grid, block, PP64_SMEM, as_stream(stream), a);
+    else hipLaunchKernelGGL(lambda_rows_kernel<6>, grid, block, PP64_SMEM, as_stream(stream), a);
     return launch_status();
 }
 
