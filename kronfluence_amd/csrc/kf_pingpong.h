@@ -43,6 +43,21 @@
 //        L(P+1) of the other group: L(2t) writes buffer (t+1)&1 while tile t (buffer t&1) is being read; L(2t+1) writes A0 /
 //        B0 of buffer t&1 while L(2t+1) reads only A1 of it and L(2t+2) reads the other buffer.
 // Nothing else orders an LDS-DMA against a ds_read (MI355X_MICROARCH.md, "Two waves per SIMD", item 7).
+//
+// ISSUE != 0 (round 4): the requests ride BETWEEN THE MFMA GROUPS of the M segments instead of in the L segments (an LDS-DMA
+// request costs ~60 cycles of issue among bare MFMAs but 100-185 inside a segment that already carries 8-16 ds_read_b128; the
+// same move paid 3-15 % on the loop of kf_pingpong64.h).  A request issued in M(P) lands while the OTHER group runs L(P) and
+// L(P + 1), and it must be waited for at the end of an L segment one phase before its first read, at least two segments
+// after its issue -- which fixes the schedule:
+//     M(2t)    A1(t+1)                        (2 requests; its rows were last read in L(2t-1))
+//     M(2t+1)  A0(t+2), B0(t+2), B1(t+2)      (6 requests; last read in L(2t)).   ISSUE == 2: A0(t+2) stays in L(2t+1).
+//   RAW  end of L(2t): A1(t) (issued in M(2t-2)) must be there for L(2t+1) -> in flight: A0, B0, B1 of t+1 = 6 (vmcnt(6)).
+//        End of L(2t+1): A0, B0, B1 of t+1 (issued in L / M(2t-1)) must be there for L(2t+2) -> in flight: A1(t+1), and with
+//        ISSUE == 2 the A0(t+2) just issued = 2 / 4 (vmcnt(2) / vmcnt(4)).  Each wait is >= 3 segments after the issue.
+//   WAR  M(P) of X is S_2P+1, of Y S_2P+2: later than L(P), so every read the request overwrites has returned as argued above;
+//        what is read meanwhile -- L(P) of Y in S_2P+1, L(P+1) of X in S_2P+2 -- is, for M(2t): tile t phase 0 / phase 1 (buffer
+//        t & 1; the request writes buffer (t+1) & 1), for M(2t+1): A1 of tile t and tile t+1 (the other buffer); the request
+//        writes A0 / B0 / B1 of buffer t & 1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -104,9 +119,12 @@ __device__ __forceinline__ void make_sources(Sources& s, int wave, int lane, Row
 // walk_a(t) / walk_b(t): element offset of k-tile t relative to Sources::p (any per-lane value; evaluated once per piece).
 // `wave` must be wave-uniform (readfirstlane'd).  All 512 threads; sm: SMEM_BYTES of LDS.  On return every wave has
 // finished reading LDS (the buffers may be reused after one more barrier).
-template <class WalkA, class WalkB>
+// ISSUE: where the LDS-DMA requests are issued -- 0: in the L segments (round 3), 1: between the MFMA groups of the M segments,
+// 2: as 1 with A0 left in L(2t+1) (the segment with 8 fragment reads); see the header.
+template <int ISSUE = 0, class WalkA, class WalkB>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane,
                                          WalkA walk_a, WalkB walk_b) {
+    static_assert(ISSUE >= 0 && ISSUE <= 2, "request schedule");
     const int wm = wave >> 2, wn = wave & 3;
     const int lr = lane & 31, hi = lane >> 5, sw = (lr >> 1) & 7;
     int co[4];
@@ -151,10 +169,30 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
         __builtin_amdgcn_s_setprio(0);                                                                                 \
     } while (0)
 
-    // prologue: k-tile 0 complete, A0 / B0 of k-tile 1 on their way
+    // one MFMA group = the four products of k-slab KK
+#define KF_PP_GROUP(HALF, KK)                                                                                          \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                      \
+        _Pragma("unroll") for (int jn = 0; jn < 2; ++jn)                                                               \
+            acc[(HALF) * 2 + i][jn] =                                                                                  \
+                __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][KK], b[jn][KK], acc[(HALF) * 2 + i][jn], 0, 0, 0)
+    // a piece issued between two MFMA groups, pinned there
+    auto ride = [&](bool on, int piece, int t, int64_t off) {
+        if (on) {
+            __builtin_amdgcn_sched_barrier(0);
+            issue_at(piece, t, off);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    // prologue: k-tile 0 complete, A0 / B0 (ISSUE != 0: and B1) of k-tile 1 on their way
     issue_piece(0, 0); issue_piece(2, 0); issue_piece(3, 0); issue_piece(1, 0);
-    if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); wait_vmcnt<6>(); }   // in flight: A1(0), A0(1), B0(1)
-    else wait_vmcnt<2>();                                                     // in flight: A1(0)
+    if constexpr (ISSUE == 0) {
+        if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); wait_vmcnt<6>(); }   // in flight: A1(0), A0(1), B0(1)
+        else wait_vmcnt<2>();                                                     // in flight: A1(0)
+    } else {
+        if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); issue_piece(3, 1); wait_vmcnt<8>(); }   // A1(0), A0 B0 B1(1)
+        else wait_vmcnt<2>();
+    }
     barrier();
     if (wm == 1) barrier();   // Y runs half a phase behind X from here on (wave-uniform branch)
 
@@ -182,13 +220,64 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
         barrier();                                                                                                     \
     } while (0)
 
+    // the same k-tile with the requests in the M segments (ISSUE 1 / 2): M(2t) carries A1(t+1), M(2t+1) (A0,) B0, B1 of t+2
+#define KF_PP_TILE_M(T, MORE1, MORE2)                                                                                  \
+    do {                                                                                                               \
+        const int t_ = (T), buf_ = t_ & 1;                                                                             \
+        int64_t oa_ = 0, ob_ = 0;                                                                                      \
+        if (MORE1) oa_ = walk_a(t_ + 1);                                                                               \
+        read_a(0, buf_);                                                                                               \
+        read_b(buf_);                                                                                                  \
+        if (MORE1) wait_vmcnt<6>();   /* A1(t) landed; in flight: A0, B0, B1 of t+1 */                                 \
+        else wait_vmcnt<0>();                                                                                          \
+        wait_lds_reads();                                                                                              \
+        barrier();                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        KF_PP_GROUP(0, 0);                                                                                             \
+        ride(MORE1, 1, t_ + 1, oa_);                                                                                   \
+        KF_PP_GROUP(0, 1);                                                                                             \
+        KF_PP_GROUP(0, 2);                                                                                             \
+        KF_PP_GROUP(0, 3);                                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+        barrier();                                                                                                     \
+        if (MORE2) { oa_ = walk_a(t_ + 2); ob_ = walk_b(t_ + 2); }                                                     \
+        read_a(1, buf_);                                                                                               \
+        if (ISSUE == 2 && (MORE2)) issue_at(0, t_ + 2, oa_);                                                           \
+        if (MORE1) {   /* A0, B0, B1 of t+1 landed; in flight: A1(t+1) (+ the A0(t+2) just issued) */                  \
+            if (ISSUE == 2 && (MORE2)) wait_vmcnt<4>();                                                                \
+            else wait_vmcnt<2>();                                                                                      \
+        }                                                                                                              \
+        wait_lds_reads();                                                                                              \
+        barrier();                                                                                                     \
+        __builtin_amdgcn_s_setprio(1);                                                                                 \
+        KF_PP_GROUP(1, 0);                                                                                             \
+        ride((MORE2) && ISSUE == 1, 0, t_ + 2, oa_);                                                                   \
+        ride((MORE2) && ISSUE == 2, 2, t_ + 2, ob_);                                                                   \
+        KF_PP_GROUP(1, 1);                                                                                             \
+        ride((MORE2) && ISSUE == 1, 2, t_ + 2, ob_);                                                                   \
+        ride((MORE2) && ISSUE == 2, 3, t_ + 2, ob_);                                                                   \
+        KF_PP_GROUP(1, 2);                                                                                             \
+        ride((MORE2) && ISSUE == 1, 3, t_ + 2, ob_);                                                                   \
+        KF_PP_GROUP(1, 3);                                                                                             \
+        __builtin_amdgcn_s_setprio(0);                                                                                 \
+        barrier();                                                                                                     \
+    } while (0)
+
     int t = 0;
-    for (; t + 2 < nt; ++t) KF_PP_TILE(t, true, true);
-    if (t + 1 < nt) { KF_PP_TILE(t, true, false); ++t; }
-    KF_PP_TILE(t, false, false);
+    if constexpr (ISSUE == 0) {
+        for (; t + 2 < nt; ++t) KF_PP_TILE(t, true, true);
+        if (t + 1 < nt) { KF_PP_TILE(t, true, false); ++t; }
+        KF_PP_TILE(t, false, false);
+    } else {
+        for (; t + 2 < nt; ++t) KF_PP_TILE_M(t, true, true);
+        if (t + 1 < nt) { KF_PP_TILE_M(t, true, false); ++t; }
+        KF_PP_TILE_M(t, false, false);
+    }
     if (wm == 0) barrier();   // X waits for Y's last segment: barrier counts match, all LDS reads are done
 #undef KF_PP_TILE
+#undef KF_PP_TILE_M
 #undef KF_PP_MFMA
+#undef KF_PP_GROUP
 }
 
 }  // namespace pp

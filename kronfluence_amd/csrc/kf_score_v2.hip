@@ -24,6 +24,7 @@
 // address of the DMA and to the ds_read_b128 fragment address alike, which makes the fragment reads
 // (lane l: row l & 31, k-octet l >> 5) bank-conflict free (cdna_hip_programming.md T2, rule 21).
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(SV2_THREADS) void rotate_gemm_v2_kernel(RotateArgs 
 // phase apart, counted vmcnt, raw barriers).  Work decomposition, operand layouts and epilogues are those of the v2 kernels
 // above, which stay as the 256 x 128 / 128 x 256 shapes and as the KF_ENGINE=2 fallback.
 // ------------------------------------------------------------------------------------------------
+template <int ISSUE>
 __global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args 
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pp::mainloop(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; });
+    pp::mainloop<ISSUE>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int t) { return t * kt_a; }, [&](int t) { return t * kt_b; });
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -526,7 +528,7 @@ struct RotateV3Args {
 
 // EPI 0: bf16 result through LDS.  EPI 1: the Lambda reduction of the dense (per-sample-gradient) form -- see
 // kf_lambda_conv2d_accum: rows = (o, sample), so a 256-row tile spans at most two values of o when group_rows >= 256.
-template <int EPI>
+template <int EPI, int ISSUE>
 __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Args v) {
     const RotateArgs& a = v.r;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
@@ -550,7 +552,7 @@ __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Arg
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pp::mainloop(acc, sm, src, a.KT, wave, lane, [](int t) { return t * 64; }, [](int t) { return t * 64; });
+    pp::mainloop<ISSUE>(acc, sm, src, a.KT, wave, lane, [](int t) { return t * 64; }, [](int t) { return t * 64; });
     if constexpr (EPI == 1) {
         const int first = m0 / v.group_rows;                          // group of the tile's first row
         const int limit = min(256, a.M - m0);                         // rows of the tile that exist
@@ -625,6 +627,23 @@ inline int half_tile_engine() {
 // (GPT-2: 614 vs 588 us per launch, profiles/r04_ab_kernel_stats.csv) -- both sit on the HBM stream of P there -- so they are
 // opt-in (KF_WIDE_TILE=1: measurements, tests)
 inline bool wide_tile_enabled() { const char* e = getenv("KF_WIDE_TILE"); return e && atoi(e) == 1; }
+
+// Where the 256 x 256 loop issues its LDS-DMA requests (kf_pingpong.h, ISSUE): 0 = in the L segments (round 3), 1 = between the
+// MFMA groups of the M segments, 2 = as 1 with A0 left in the short L segment.  KF_PP_ISSUE overrides (read per call: A/B
+// measurements in one process, race screens on every schedule).
+constexpr int PP_ISSUE_DEFAULT = 1;
+inline int pp_issue() {
+    const char* e = getenv("KF_PP_ISSUE");
+    return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : PP_ISSUE_DEFAULT;
+}
+template <class F>
+inline void with_pp_issue(F&& launch) {
+    switch (pp_issue()) {
+    case 0: launch(std::integral_constant<int, 0>{}); break;
+    case 2: launch(std::integral_constant<int, 2>{}); break;
+    default: launch(std::integral_constant<int, 1>{}); break;
+    }
+}
 
 inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A/B measurements, fallback)
     const char* e = getenv("KF_ENGINE");
@@ -1028,6 +1047,7 @@ struct PsgPpArgs {
     int M, N, KT, batch, tiles_m, tiles_n, n_end;
 };
 
+template <int ISSUE>
 __global__ __launch_bounds__(pp::THREADS) void psg_gemm_pp_kernel(PsgPpArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
@@ -1054,7 +1074,7 @@ __global__ __launch_bounds__(pp::THREADS) void psg_gemm_pp_kernel(PsgPpArgs a) {
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pp::mainloop(acc, sm, src, a.KT, wave, lane, [](int t) { return t * 64; }, [](int t) { return t * 64; });
+    pp::mainloop<ISSUE>(acc, sm, src, a.KT, wave, lane, [](int t) { return t * 64; }, [](int t) { return t * 64; });
     __syncthreads();   // every wave is done with the stage buffers: the epilogue reuses them
     const int hi = lane >> 5;
 #pragma unroll
@@ -1324,6 +1344,7 @@ __global__ __launch_bounds__(NTHREADS) void cov_gemm_v2_kernel(CovV2Args a) {
 constexpr int COV_KTAB_STEPS = 128;                       // k-steps per sample the offset table holds (4 KB)
 constexpr int COV_V3_SMEM = pp::SMEM_BYTES + COV_KTAB_STEPS * 8 * 4;
 
+template <int ISSUE>
 __global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
@@ -1380,7 +1401,7 @@ __global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pp::mainloop(acc, sm, src, (z_end - z_begin) * ksteps, wave, lane, walk, walk);
+    pp::mainloop<ISSUE>(acc, sm, src, (z_end - z_begin) * ksteps, wave, lane, walk, walk);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -1447,7 +1468,7 @@ int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.plain_store = zblocks == 1;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
     if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-    hipLaunchKernelGGL(cov_gemm_v3_kernel, grid, dim3(pp::THREADS), COV_V3_SMEM, st, c);
+    with_pp_issue([&](auto iss) { hipLaunchKernelGGL((cov_gemm_v3_kernel<decltype(iss)::value>), grid, dim3(pp::THREADS), COV_V3_SMEM, st, c); });
     f.stage = c.stage; f.np = c.np; f.tile_shift = 8;
     hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();
@@ -1490,7 +1511,9 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<256, 128, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v2_kernel<128, 256, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 384 * 128) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 512 * 128) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<256, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v4_kernel<128, 256>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
@@ -1500,15 +1523,23 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(lambda_rows_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PP64_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v5_kernel<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, PPW_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(score_gemm_v5_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, PPW_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(rotate_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>((rotate_gemm_v3_kernel<0, 0>)), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>((rotate_gemm_v3_kernel<0, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>((rotate_gemm_v3_kernel<0, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>((rotate_gemm_v3_kernel<1, 0>)), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>((rotate_gemm_v3_kernel<1, 1>)), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>((rotate_gemm_v3_kernel<1, 2>)), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
@@ -1543,7 +1574,8 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     ksplit = cdiv(s.KT, kchunk);
     s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(ksplit * tiles, 8)));
-    if (shape == 0 && engine_generation() == 3) hipLaunchKernelGGL(score_gemm_v3_kernel, grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, s);
+    if (shape == 0 && engine_generation() == 3)
+        with_pp_issue([&](auto iss) { hipLaunchKernelGGL((score_gemm_v3_kernel<decltype(iss)::value>), grid, dim3(pp::THREADS), pp::SMEM_BYTES, st, s); });
     else if (shape == 0) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 256, 2>), grid, dim3(SV2_THREADS), 2 * 512 * 128, st, s);
     else if (shape == 3) hipLaunchKernelGGL((score_gemm_v5_kernel<4, 2>), grid, dim3(pp::THREADS), PPW_SMEM, st, s);
     else if (shape == 4) hipLaunchKernelGGL((score_gemm_v5_kernel<1, 8>), grid, dim3(pp::THREADS), PPW_SMEM, st, s);
@@ -1568,7 +1600,9 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
         g.tiles_m = p.M / 256; g.tiles_n = static_cast<int>(cdiv(n_end, 256)); g.n_end = n_end;
         const int64_t items = static_cast<int64_t>(g.batch) * g.tiles_m * g.tiles_n;
         if (items >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
-        hipLaunchKernelGGL(psg_gemm_pp_kernel, dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pp::THREADS), pp::SMEM_BYTES, st, g);
+        with_pp_issue([&](auto iss) {
+            hipLaunchKernelGGL((psg_gemm_pp_kernel<decltype(iss)::value>), dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pp::THREADS), pp::SMEM_BYTES, st, g);
+        });
         if (n_end == p.N) return launch_status();
         p.n_begin = n_end;
     }
@@ -1622,7 +1656,9 @@ int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void*
     if (engine_generation() == 3) {
         RotateV3Args v{};
         v.r = r;
-        hipLaunchKernelGGL(rotate_gemm_v3_kernel<0>, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, as_stream(stream), v);
+        with_pp_issue([&](auto iss) {
+            hipLaunchKernelGGL((rotate_gemm_v3_kernel<0, decltype(iss)::value>), dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, as_stream(stream), v);
+        });
         return launch_status();
     }
     hipLaunchKernelGGL(rotate_gemm_v2_kernel, dim3(static_cast<unsigned>(blocks)), dim3(SV2_THREADS), 2 * 512 * 128, as_stream(stream), r);
@@ -1668,7 +1704,7 @@ int launch_rotate_blocked(uint16_t* C, const uint16_t* A, int64_t lda, const uin
     v.col_add = col_add; v.col_add_m = col_add_m; v.c_inner = c_inner; v.c_outer = c_outer;
     v.n_major = 1;   // the few m-tiles (eigenvectors: L2 resident) of one n-tile run back to back: the big operand is read once
     const int64_t blocks = 8 * cdiv(static_cast<int64_t>(v.r.tiles_m) * v.r.tiles_n, 8);
-    hipLaunchKernelGGL(rotate_gemm_v3_kernel<0>, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v);
+    with_pp_issue([&](auto iss) { hipLaunchKernelGGL((rotate_gemm_v3_kernel<0, decltype(iss)::value>), dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v); });
     return launch_status();
 }
 struct PrecondPlan { int64_t W64, gt, at, rot, qa, tt, qg, total; };
@@ -1862,7 +1898,7 @@ int kf_lambda_conv2d_accum(float* Lambda, int64_t ld_lambda, const void* Gt_nchw
     v.r.alpha = scale; v.r.row_add = nullptr; v.r.row_add_n = 0;
     v.sumsq = Lambda; v.ld_sumsq = ld_lambda; v.group_rows = static_cast<int>(b);
     const int64_t blocks = 8 * cdiv(static_cast<int64_t>(v.r.tiles_m) * v.r.tiles_n, 8);
-    hipLaunchKernelGGL(rotate_gemm_v3_kernel<1>, dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v);
+    with_pp_issue([&](auto iss) { hipLaunchKernelGGL((rotate_gemm_v3_kernel<1, decltype(iss)::value>), dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v); });
     return launch_status();
 }
 

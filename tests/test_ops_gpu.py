@@ -533,13 +533,31 @@ def test_score_gemm_long_k_loops(ops, q, b):
         assert rel(scores, want) <= 1e-5, rel(scores, want)
 
 
-def test_wave_role_split_loop_race_screen(ops):
+@pytest.fixture
+def pp_issue():
+    """Sets ``KF_PP_ISSUE`` (request schedule of the 256 x 256 loop, read per call) for a test and restores it."""
+    before = os.environ.get("KF_PP_ISSUE")
+
+    def choose(value):
+        if value is None:
+            os.environ.pop("KF_PP_ISSUE", None)
+        else:
+            os.environ["KF_PP_ISSUE"] = str(value)
+
+    yield choose
+    choose(before)
+
+
+@pytest.mark.parametrize("issue", [0, 1, 2])
+def test_wave_role_split_loop_race_screen(ops, pp_issue, issue):
     """The round-3 main loop (csrc/kf_pingpong.h) orders its LDS-DMA requests against fragment reads with counted ``vmcnt`` and raw
-    barriers only: a mistake there shows up as RARE wrong tiles.  Screen: the 256 x 256 score GEMM, the bf16-output rotation and
+    barriers only: a mistake there shows up as RARE wrong tiles.  Screen, for every request schedule (``ISSUE`` 0: requests in the
+    L segments, 1 / 2: between the MFMA groups): the 256 x 256 score GEMM, the bf16-output rotation and
     the 256-row covariance kernel launched 60 times each on the same operands while another stream keeps HBM busy; every
     result must match the first launch to fp32 summation-order noise (a stale 64-deep k-tile is >= 1e-4 of the result)."""
     from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 
+    pp_issue(issue)
     q, b, r, o, i = 1000, 1000, 16, 128, 1152
     p = TiledQueries(_rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV), 0)
     g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
@@ -568,6 +586,58 @@ def test_wave_role_split_loop_race_screen(ops):
                 worst = float((value - first[key]).abs().max() / first[key].abs().max())
                 assert worst <= (0.0 if key == "rotate" else 1e-5), (key, launch, worst)
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("issue", [1, 2])
+def test_request_schedules_of_the_256_loop_agree(ops, pp_issue, issue):
+    """``KF_PP_ISSUE`` only moves LDS-DMA requests inside the main loop of csrc/kf_pingpong.h: every kernel on it must give what the
+    round-3 schedule gives -- BIT FOR BIT where no atomics are involved (rotations: bf16 output, one workgroup per tile; per-sample
+    gradients of a sequence layer) and to fp32 atomic-order noise elsewhere -- for loops of 1, 2, 3, 5 and many k-tiles (prologue
+    and the two tail forms of the loop), ragged last tiles, the covariance kernel's LDS offset table and the dense-form Lambda."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    def run():
+        out = {}
+        for d in (64, 128, 192, 320, 1152):                       # rotations: 1, 2, 3, 5, 18 k-tiles; 547 x 2 tiles, both ragged
+            x = _rand(140000, d, dtype=torch.bfloat16, seed=d).to(DEV)
+            q_t = (_rand(264, d, seed=d + 1) / d ** 0.5).to(torch.bfloat16).to(DEV)
+            out[f"rotate{d}"] = ops.rotate_bf16(x, q_t, _rand(264, seed=2).to(DEV))
+        for o, i in ((8, 64), (16, 192), (128, 1152)):              # score GEMM: 8, 48 and 2 304 k-tiles before the split
+            p = TiledQueries(_rand(700, o, i, seed=7).to(torch.bfloat16).to(DEV), 0)
+            g, a = _rand(600, 4, o, dtype=torch.bfloat16).to(DEV), _rand(600, 4, i, dtype=torch.bfloat16, seed=1).to(DEV)
+            scores = torch.zeros(700, 600, device=DEV)
+            ops.pairwise_score(scores, 0, p, g, a, False)
+            out[f"score{o}x{i}"] = scores
+        for t_len in (256, 512):                                     # sequence layer: gradients on the 256 x 256 loop (4 / 8 k-tiles)
+            p = TiledQueries(_rand(300, 256, 264, seed=9).to(torch.bfloat16).to(DEV), 0)
+            g = _rand(256, t_len, 256, dtype=torch.bfloat16, seed=3).to(DEV)
+            a = _rand(256, t_len, 256, dtype=torch.bfloat16, seed=4).to(DEV)   # I' = 257, padded to 264 columns of P
+            scores = torch.zeros(300, 256, device=DEV)
+            ops.pairwise_score_rows(scores, 0, p, g, a, True)
+            out[f"rows{t_len}"] = scores
+        conv = nn.Conv2d(64, 32, 5, stride=2, padding=2, bias=False)   # I' = 1600: the 256-row covariance kernel, offset table
+        xc = _rand(300, 64, 32, 32, dtype=torch.bfloat16, seed=5).to(DEV)
+        cov, cnt = torch.zeros(1600, 1600, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        ops.conv2d_cov_accum(cov, cnt, xc, conv, ops.conv2d_cov_geometry(xc, conv))
+        out["cov"] = cov
+        rows = _rand(64, 512, 1536, dtype=torch.bfloat16, seed=6).to(DEV)   # rows of a sequence layer wide enough for the 256-row kernel
+        cov_rows, cnt = torch.zeros(1536, 1536, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        ops.linear_activation_cov(cov_rows, cnt, rows, None, False)
+        out["cov_rows"] = cov_rows
+        torch.cuda.synchronize()
+        return out
+
+    pp_issue(0)
+    want = run()
+    pp_issue(issue)
+    got = run()
+    for key, value in got.items():
+        if key.startswith("rotate"):
+            assert torch.equal(value, want[key]), key
+        else:
+            scale = float(want[key].abs().max())
+            assert scale > 0, key
+            assert float((value - want[key]).abs().max()) <= 1e-5 * scale, key
 
 
 @pytest.mark.parametrize("n,d,m,bias", [(40000, 1152, 1152, False), (33000, 1600, 1608, True), (70001, 256, 2304, False)])

@@ -51,3 +51,38 @@ def test_committed_pmc_summary_matches_the_hash_function_of_bench():
     # names the summary is built from must exist in the profile it was built from
     assert any(name.startswith("score_gemm_v3_kernel") for name in summary["kernels"])
     assert any(name.startswith("psg_gemm_v3_kernel<0") for name in summary["kernels"])
+
+
+def test_request_schedules_of_the_256_loop_are_ordered():
+    """kf_pingpong.h, ISSUE 0 / 1 / 2: every fragment read sees its k-tile landed (RAW) and is over before the next occupant of
+    its LDS rows is requested (WAR), for every loop length -- the header's ordering argument as an interval model -- and the
+    model does reject a wait that is one piece short and a request issued one segment early."""
+    model = _load("pp_schedule_check", os.path.join(ROOT, "tools", "pp_schedule_check.py"))
+
+    for issue in (0, 1, 2):
+        for nt in range(1, 10):
+            errors, slack = model.check(issue, nt)
+            assert not errors, (issue, nt, errors[:3])
+            assert slack is None or slack >= 2   # never waited for in (or right after) the issuing segment
+    real = model.program
+
+    def short_wait(issue, nt):   # end of L(2t+1): vmcnt(2) -> vmcnt(4) leaves B1(t+1) in flight
+        segs = real(issue, nt)
+        return [(k, r, i, 4 if (k == "L" and w == 2) else w) for k, r, i, w in segs]
+
+    def early_a1(issue, nt):     # A1(t+1) moved from M(2t) into M(2t-1): the other group is still reading A1(t-1) there
+        segs = [list(s) for s in real(issue, nt)]
+        for idx in range(len(segs) - 1, 1, -1):
+            moved = [q for q in segs[idx][2] if q[0] == "A1"]
+            if segs[idx][0] == "M" and moved and idx - 2 >= 1 and segs[idx - 2][0] == "M":
+                segs[idx][2] = [q for q in segs[idx][2] if q[0] != "A1"]
+                segs[idx - 2][2] = moved + segs[idx - 2][2]
+        return [tuple(s) for s in segs]
+
+    for mutant, kind in ((short_wait, "RAW"), (early_a1, "WAR")):
+        model.program = mutant
+        try:
+            errors, _ = model.check(1, 6)
+        finally:
+            model.program = real
+        assert any(e.startswith(kind) for e in errors), (kind, errors[:3])

@@ -8,6 +8,8 @@
 #   sidestream  A/B of the hooks' kernels on a second stream (KF_SIDE_STREAM) on three workloads
 #   suite     the full GPU suite + smoke
 #   record    kernel trace + the three PMC passes of the bench command (-> profiles/pmc_resnet9.json), default bench line
+#   issue     request schedules of the 256 x 256 loop: agreement tests, A/B, and (if the compiled default wins) the record
+#   rerecord  kernel trace + PMC passes + headline bench line of the sources as they are
 #   pmc_gpt2  kernel trace (+ PMC passes: they segfault inside rocprofv3 on this workload) of a bounded GPT-2-small run
 #   gpt2_full configs[3] at its full train size on one GPU
 #   traces    per-kernel totals of one BERT-base and one GPT-2-small step at bounded sizes
@@ -104,6 +106,58 @@ record)
     find gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma -name "*.csv" -size +4M -delete
     ( timeout 1500 python bench.py ) > gpurun_out/r04_bench_default.json 2> gpurun_out/r04_bench_default.log
     tail -c 3000 gpurun_out/r04_bench_default.json
+    ;;
+issue)
+    # request schedules of the 256 x 256 loop (KF_PP_ISSUE): 1. they agree with the round-3 schedule and pass the race screen,
+    # 2. A/B of the three under the kernel trace, 3. when the compiled default is the fastest (within 1 %): the record of the
+    # final sources -- kernel trace + PMC passes + headline bench line (the other configs take 4 more minutes: not re-run)
+    ( timeout 400 python -m pytest tests/test_ops_gpu.py -q -x -k "request_schedules or wave_role_split_loop_race_screen or lambda_conv2d_dense or rotate_bf16_tall" --durations=5 ) > gpurun_out/r04_issue_tests.log 2>&1
+    tail -4 gpurun_out/r04_issue_tests.log
+    grep -Eq "^[0-9]+ passed" gpurun_out/r04_issue_tests.log || { echo "tests not green: stop"; exit 0; }
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_issue_trace" -- python "$GRAFT_REPO_ROOT/tools/issue_ab.py" "$GRAFT_REPO_ROOT/gpurun_out/r04_issue_ab.json" ) > gpurun_out/r04_issue_ab.log 2>&1
+    find gpurun_out/r04_issue_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_issue_ab_kernel_stats.csv \;
+    rm -rf gpurun_out/r04_issue_trace
+    grep -v "^W0\|rocprof" gpurun_out/r04_issue_ab.log | tail -22
+    go=$(python - <<'PY'
+import json, re
+try:
+    d = json.load(open("gpurun_out/r04_issue_ab.json"))
+    default = int(re.search(r"PP_ISSUE_DEFAULT = (\d)", open("kronfluence_amd/csrc/kf_score_v2.hip").read()).group(1))
+    t = {int(k): v for k, v in d["totals_ms"].items()}
+    print("go" if d["all_equal"] and t[default] <= 1.01 * min(t.values()) else "stop")
+except Exception as exc:
+    print("stop", exc)
+PY
+)
+    echo "decision: $go"
+    [ "$go" = "go" ] || exit 0
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace" -- $CMD ) > gpurun_out/r04_trace.log 2>&1
+    find gpurun_out/r04_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_resnet9_n4000_kernel_stats.csv \;
+    rm -rf gpurun_out/r04_trace
+    pmc fetch FETCH_SIZE
+    pmc write WRITE_SIZE
+    pmc mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+    ( python tools/pmc_summary.py resnet9 profiles/pmc_resnet9.json gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma ) > gpurun_out/r04_pmc_summary.log 2>&1
+    cp profiles/pmc_resnet9.json gpurun_out/r04_pmc_resnet9.json
+    find gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma -name "*.csv" -size +4M -delete
+    ( timeout 400 python bench.py --no-extras ) > gpurun_out/r04_bench_headline.json 2> gpurun_out/r04_bench_headline.log
+    python tools/bench_digest.py gpurun_out/r04_bench_headline.json || tail -c 1500 gpurun_out/r04_bench_headline.log
+    ;;
+rerecord)
+    # kernel trace + PMC passes + headline bench line of the sources as they are (after a change of the compiled default)
+    ( timeout 200 python -m pytest tests/test_ops_gpu.py -q -x -k "wave_role_split_loop_race_screen" ) > gpurun_out/r04_rerecord_tests.log 2>&1
+    tail -2 gpurun_out/r04_rerecord_tests.log
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$GRAFT_REPO_ROOT/gpurun_out/r04_trace" -- $CMD ) > gpurun_out/r04_trace.log 2>&1
+    find gpurun_out/r04_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r04_resnet9_n4000_kernel_stats.csv \;
+    rm -rf gpurun_out/r04_trace
+    pmc fetch FETCH_SIZE
+    pmc write WRITE_SIZE
+    pmc mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE
+    ( python tools/pmc_summary.py resnet9 profiles/pmc_resnet9.json gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma ) > gpurun_out/r04_pmc_summary.log 2>&1
+    cp profiles/pmc_resnet9.json gpurun_out/r04_pmc_resnet9.json
+    find gpurun_out/r04_pmc_fetch gpurun_out/r04_pmc_write gpurun_out/r04_pmc_mfma -name "*.csv" -size +4M -delete
+    ( timeout 400 python bench.py --no-extras ) > gpurun_out/r04_bench_headline.json 2> gpurun_out/r04_bench_headline.log
+    python tools/bench_digest.py gpurun_out/r04_bench_headline.json || tail -c 1500 gpurun_out/r04_bench_headline.log
     ;;
 pmc_gpt2)
     # the transformer kernels under the counters: three PMC passes + a kernel trace of a bounded GPT-2-small run
