@@ -376,13 +376,19 @@ class PairwiseScoreTracker(BaseTracker):
                 return
             self._flush_pair(tiled)
         nbytes = (g.numel() + a.numel()) * 2
-        budget = self.PAIR_HOLD_FRACTION * torch.cuda.get_device_properties(g.device).total_memory if g.is_cuda else 0
+        budget = self._pair_budget(g.device)
         if (self.module.score_sink is not None and b <= self.PAIR_MAX_BATCH and tiled.shape[0] >= self.PAIR_MIN_QUERIES
                 and self._pair_bytes_all_layers[0] + nbytes <= budget):
             self._pair_held = (scores, offset, g, a, (g._version, a._version), ones, scale, nbytes)
             self._pair_bytes_all_layers[0] += nbytes
             return
         ops.pairwise_score_rows(scores, offset, tiled, g, a, ones, scale=scale)
+
+    def _pair_budget(self, device: torch.device) -> float:
+        """Bytes of hooked tensors all layers together may hold across a batch boundary."""
+        if device.type != "cuda":
+            return 0.0
+        return self.PAIR_HOLD_FRACTION * torch.cuda.get_device_properties(device).total_memory
 
     def _check_held_versions(self, g, a, versions) -> None:
         if (g._version, a._version) != versions:
@@ -405,8 +411,9 @@ class PairwiseScoreTracker(BaseTracker):
         self._drop_held()
         if tiled is None:
             tiled = self.module.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
-        if isinstance(tiled, TiledQueries):
-            ops.pairwise_score_rows(scores, offset, tiled, g, a, ones, scale=scale)
+        if not isinstance(tiled, TiledQueries):   # the queries this batch was hooked against are gone: never drop scores silently
+            raise RuntimeError(f"Module '{self.module.name}' holds a train micro-batch to score but no tiled query gradients.")
+        ops.pairwise_score_rows(scores, offset, tiled, g, a, ones, scale=scale)
 
     def register_hooks(self) -> None:
         module = self.module

@@ -220,3 +220,78 @@ def test_low_rank_plan_picks_the_cheaper_exact_order():
     assert plan(1000, 14340, 4096, 64, 16, 512, False) == "expand"         # O not a multiple of 8: the GEMM path does not apply
     assert plan(1000, 14336, 4096, 64, 16, 512, False, cuda=False) == "expand"
 
+
+
+def test_train_micro_batches_pair_up_flush_and_guard(monkeypatch):
+    """``PairwiseScoreTracker._score_rows_paired`` (host logic only; the kernels are replaced by a recorder): a small train
+    micro-batch of a sequence layer is held until the same layer's next batch and both go through ONE call; an odd batch, a
+    batch that does not continue the held one's score columns and a large batch are scored alone; an in-place change of a held
+    tensor is an error; the byte account returns to zero."""
+    from types import SimpleNamespace as T
+
+    from kronfluence_amd import ops
+    from kronfluence_amd.module.tracker import pairwise_score as ps
+
+    calls = []
+
+    def record(scores, offset, tiled, g, a, ones, scale=1.0, second=None):
+        calls.append((offset, g.shape[0], None if second is None else second[0].shape[0]))
+
+    monkeypatch.setattr(ops, "pairwise_score_rows", record)
+    tracker = ps.PairwiseScoreTracker.__new__(ps.PairwiseScoreTracker)
+    tracker.module = T(score_sink=(object(), 0), name="layer", storage={})
+    monkeypatch.setattr(tracker, "_pair_budget", lambda device: 1 << 30)
+    account = ps.PairwiseScoreTracker._pair_bytes_all_layers
+    assert account[0] == 0
+    def queries(q):
+        held = ps.TiledQueries.__new__(ps.TiledQueries)
+        held.num_queries, held.rows, held.width = q, 64, 72
+        return held
+
+    tiled = queries(1024)
+    scores = torch.zeros(1024, 1000)
+
+    def batch(n, seed):
+        gen = torch.Generator().manual_seed(seed)
+        return torch.randn(n, 64, 64, generator=gen).bfloat16(), torch.randn(n, 64, 64, generator=gen).bfloat16()
+
+    g0, a0 = batch(128, 0)
+    g1, a1 = batch(128, 1)
+    g2, a2 = batch(96, 2)
+    tracker._score_rows_paired(scores, 0, tiled, g0, a0, True, 1.0)
+    assert calls == [] and account[0] == (g0.numel() + a0.numel()) * 2          # held, nothing launched
+    tracker._score_rows_paired(scores, 128, tiled, g1, a1, True, 1.0)
+    assert calls == [(0, 128, 128)] and account[0] == 0 and tracker._pair_held is None   # one call for both
+    tracker._score_rows_paired(scores, 256, tiled, g2, a2, True, 1.0)              # odd batch: held ...
+    assert len(calls) == 1
+    tracker.module.storage[ps.ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = tiled
+    tracker._flush_pair()                                                           # ... until the end of the pass
+    assert calls[-1] == (256, 96, None) and account[0] == 0
+    tracker._score_rows_paired(scores, 352, tiled, g2, a2, True, 1.0)
+    tracker.module.storage[ps.ACCUMULATED_PRECONDITIONED_GRADIENT_NAME] = None
+    with pytest.raises(RuntimeError, match="no tiled query gradients"):             # never dropped silently
+        tracker._flush_pair()
+    assert account[0] == 0
+
+    calls.clear()
+    tracker._score_rows_paired(scores, 0, tiled, g0, a0, True, 1.0)
+    tracker._score_rows_paired(scores, 500, tiled, g1, a1, True, 1.0)              # not the next columns: the held one goes alone
+    assert calls == [(0, 128, None)] and tracker._pair_held[1] == 500
+    tracker._score_rows_paired(scores, 628, tiled, g2, a2, False, 1.0)             # other bias setting: no pair either
+    assert calls == [(0, 128, None), (500, 128, None)] and tracker._pair_held[1] == 628
+    tracker._drop_held()
+    assert account[0] == 0
+
+    calls.clear()
+    big_g, big_a = batch(ps.PairwiseScoreTracker.PAIR_MAX_BATCH + 1, 3)
+    tracker._score_rows_paired(scores, 0, tiled, big_g, big_a, True, 1.0)          # fills a 256-row tile on its own
+    few = queries(ps.PairwiseScoreTracker.PAIR_MIN_QUERIES - 1)
+    tracker._score_rows_paired(scores, 0, few, g0, a0, True, 1.0)                  # few queries: P is small, nothing to save
+    assert calls == [(0, big_g.shape[0], None), (0, 128, None)] and tracker._pair_held is None
+
+    tracker._score_rows_paired(scores, 0, tiled, g0, a0, True, 1.0)
+    g0.add_(1)                                                                      # someone writes into a held tensor
+    with pytest.raises(RuntimeError, match="modified in place"):
+        tracker._score_rows_paired(scores, 128, tiled, g1, a1, True, 1.0)
+    tracker._drop_held()
+    assert account[0] == 0
