@@ -4,6 +4,8 @@ import importlib.util
 import json
 import os
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -86,3 +88,19 @@ def test_request_schedules_of_the_256_loop_are_ordered():
         finally:
             model.program = real
         assert any(e.startswith(kind) for e in errors), (kind, errors[:3])
+
+
+def test_tn_operand_index_arithmetic_replays_on_the_host(tmp_path):
+    """tools/next (prepared for the next round, not part of the library): the LDS image, LDS-DMA lane mapping and transposing-read
+    addresses of the K-major operand path are plain functions (kf_tn_map.h); tn_map_check.cpp replays them with g++ -- every chunk
+    of a piece written once where the image says, every fragment the MFMA operand layout under the assumed lane semantics of
+    ds_read_b64_tr_b16, all 64 banks per 32-lane half."""
+    import shutil
+    import subprocess
+
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "tn_map_check"
+    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tools", "next", "tn_map_check.cpp"), "-o", str(exe)], check=True)
+    done = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert done.returncode == 0 and done.stdout.strip() == "ok", done.stdout[-500:]
