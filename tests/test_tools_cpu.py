@@ -104,3 +104,15 @@ def test_tn_operand_index_arithmetic_replays_on_the_host(tmp_path):
     subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tools", "next", "tn_map_check.cpp"), "-o", str(exe)], check=True)
     done = subprocess.run([str(exe)], capture_output=True, text=True)
     assert done.returncode == 0 and done.stdout.strip() == "ok", done.stdout[-500:]
+    # ... and it is a check: a read address without the swizzle, a DMA mapping with two k rows swapped -> rejected
+    header = open(os.path.join(ROOT, "tools", "next", "kf_tn_map.h")).read()
+    mutants = [("((((fl0 >> 5) ^ (s >> 2)) & 3) << 6)", "(((fl0 >> 5) & 3) << 6)"),
+               ("return 4 * (wave + 8 * h) + (lane >> 4);", "return 4 * (wave + 8 * h) + ((lane >> 4) ^ 1);")]
+    for index, (old, new) in enumerate(mutants):
+        assert header.count(old) == 1
+        work = tmp_path / f"mutant{index}"
+        work.mkdir()
+        (work / "kf_tn_map.h").write_text(header.replace(old, new))
+        shutil.copy(os.path.join(ROOT, "tools", "next", "tn_map_check.cpp"), work / "tn_map_check.cpp")
+        subprocess.run(["g++", "-std=c++17", "-O1", str(work / "tn_map_check.cpp"), "-o", str(work / "check")], check=True)
+        assert subprocess.run([str(work / "check")], capture_output=True).returncode == 1, index
