@@ -4,7 +4,20 @@ reference's ``kronfluence/arguments.py:38-274`` (they are part of the public API
 
 Dtype fields select the dtype results are EXPORTED in.  On MI355X every accumulation happens in
 fp32 (fp64 for the eigensolver and the Lambda reciprocal) irrespective of these fields, which is at
-least the reference's precision.
+least the reference's precision.  Fields that only choose an intermediate precision or a memory
+strategy of the reference's implementation are accepted, serialised and honoured as follows:
+
+    eigendecomposition_dtype           the eigensolver is fp64 (kf_eigh_f64) whatever is asked: the reference's default, and at
+                                       least as accurate as its float32 option; results are exported in the factor's dtype
+    per_sample_gradient_dtype          per-sample gradients are formed from the hooked tensors as they arrive (bf16 under
+                                       autocast, else fp32) with fp32 accumulation; they are rounded to bf16 only where the
+                                       reference's bf16 presets round them too (bf16 ``score_dtype`` / ``lambda_dtype``)
+    query_gradient_svd_dtype           the low-rank factorisation (range finder + kf_eigh_small_batched) works in fp32 / fp64
+    use_iterative_lambda_aggregation   honoured where a batch of rotated per-sample gradients would otherwise be materialised
+                                       (post-processed / shared-parameter gradients, LambdaTracker._update_from_gradient);
+                                       the factored paths never materialise them
+    offload_activations_to_cpu         honoured (BaseTracker._cache_activation): the hooked input waits for its gradient in
+                                       host memory; FactorArguments' flag for the Lambda stage, ScoreArguments' for the score stages
 """
 
 from dataclasses import asdict, dataclass, fields

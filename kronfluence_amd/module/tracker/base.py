@@ -196,12 +196,23 @@ class BaseTracker:
             "`FactorArguments.has_shared_parameters` so that activations are stacked per use."
         )
 
+    def _offload_activations(self) -> bool:
+        """Whether this stage's arguments ask for cached activations in host memory: the score-stage trackers read
+        ``ScoreArguments.offload_activations_to_cpu``, ``LambdaTracker`` overrides this with ``FactorArguments``'."""
+        return bool(self.module.score_args.offload_activations_to_cpu)
+
     def _cache_activation(self, activation: torch.Tensor) -> None:
         """Forward hook side: one slot, or a LIFO stack when the module's parameters are shared between uses.
         The hooked input is held by reference (``.detach()``, no copy -- reference ``tracker/pairwise_score.py:58``)
         together with its version counter: all parameters are frozen, so autograd would NOT notice a later in-place
         write to this tensor; ``_take_activation`` does, and raises instead of scoring a corrupted activation."""
-        entry = (activation, activation._version)
+        if self._offload_activations() and activation.device.type != "cpu":
+            # ``offload_activations_to_cpu`` (reference tracker/factor.py:239, pairwise_score.py:59, ...): the hooked input waits
+            # for its gradient in host memory -- a COPY, so a later in-place write to the original cannot reach it; the
+            # entry remembers the device to come back to
+            entry = (activation.to("cpu"), None, activation.device)
+        else:
+            entry = (activation, activation._version, None)
         if not self.module.factor_args.has_shared_parameters:
             self.cached_activations = entry
         elif self.cached_activations is None:
@@ -221,7 +232,9 @@ class BaseTracker:
             entry = held
         if entry is None:
             self._raise_cache_not_found_exception()
-        activation, version = entry
+        activation, version, home = entry
+        if home is not None:
+            return activation.to(home)
         if activation._version != version:
             raise RuntimeError(
                 f"The input of module '{self.module.name}' was modified in place after its forward pass; the influence "

@@ -136,6 +136,9 @@ class LambdaTracker(BaseTracker):
     # written K-contiguous per sample + ``kf_lambda_rows_accum`` (round 4).  False selects the round-2 kernel (A/B, tests).
     ROWS_ENGINE = True
 
+    def _offload_activations(self) -> bool:
+        return bool(self.module.factor_args.offload_activations_to_cpu)   # reference tracker/factor.py:239
+
     @staticmethod
     def algorithmic_flops(r: int, o: int, ip: int) -> float:
         """F_lambda per sample: the cheaper of the dense and the factored exact formulations."""
@@ -229,6 +232,12 @@ class LambdaTracker(BaseTracker):
         """Materialised-gradient form (post-processed or shared-parameter gradients):
         ``Lambda += sum_b (Qg^T g_b Qa)^2`` with both rotations on the MFMA engine."""
         storage = self.module.storage
+        if self.module.factor_args.use_iterative_lambda_aggregation and per_sample_gradient.shape[0] > 1:
+            # reference tracker/factor.py:203-213: sample by sample, so that the rotated [b, O, I'] fp32 copies of this path never
+            # exist for the whole batch (the factored paths of ``_update_from_factors`` do not materialise them in the first place)
+            for sample in range(per_sample_gradient.shape[0]):
+                self._update_from_gradient(per_sample_gradient[sample:sample + 1])
+            return
         g = per_sample_gradient.to(torch.float32).contiguous()
         b, o, ip = g.shape
         if storage[LAMBDA_MATRIX_NAME] is None:

@@ -295,3 +295,52 @@ def test_train_micro_batches_pair_up_flush_and_guard(monkeypatch):
         tracker._score_rows_paired(scores, 128, tiled, g1, a1, True, 1.0)
     tracker._drop_held()
     assert account[0] == 0
+
+
+def test_offloaded_activations_wait_on_the_host_and_come_back():
+    """``BaseTracker._cache_activation`` / ``_take_activation`` with ``offload_activations_to_cpu``: the hooked input is copied to
+    host memory and returned on its device when the gradient arrives; the Lambda tracker reads FactorArguments' flag, the
+    score-stage trackers ScoreArguments'; without the flag the tensor is held by reference and version-checked."""
+    from types import SimpleNamespace as T
+
+    from kronfluence_amd.module.tracker.base import BaseTracker
+    from kronfluence_amd.module.tracker.factor import LambdaTracker
+
+    moves = []
+
+    class OnDevice:   # what the hooks touch of a device tensor
+        _version = 0
+
+        def __init__(self, where):
+            self.device = T(type=where)
+
+        def to(self, target):
+            where = target if isinstance(target, str) else target.type
+            moves.append(where)
+            return OnDevice(where)
+
+    def tracker(cls, factor_flag, score_flag):
+        t = cls.__new__(cls)
+        t.module = T(name="m", factor_args=T(has_shared_parameters=False, offload_activations_to_cpu=factor_flag),
+                     score_args=T(offload_activations_to_cpu=score_flag))
+        t.cached_activations = None
+        return t
+
+    t = tracker(BaseTracker, factor_flag=False, score_flag=True)      # a score-stage tracker
+    t._cache_activation(OnDevice("cuda"))
+    assert moves == ["cpu"] and t.cached_activations[0].device.type == "cpu"
+    assert t._take_activation().device.type == "cuda" and moves == ["cpu", "cuda"]
+    moves.clear()
+    t = tracker(BaseTracker, factor_flag=True, score_flag=False)      # FactorArguments' flag is not the score stage's
+    x = OnDevice("cuda")
+    t._cache_activation(x)
+    assert moves == [] and t._take_activation() is x
+    t = tracker(LambdaTracker, factor_flag=True, score_flag=False)    # ... it is the Lambda stage's
+    t._cache_activation(OnDevice("cuda"))
+    assert moves == ["cpu"] and t._take_activation().device.type == "cuda"
+    t = tracker(LambdaTracker, factor_flag=False, score_flag=True)
+    x = OnDevice("cuda")
+    t._cache_activation(x)
+    x._version = 1                                                     # held by reference: a later in-place write is caught
+    with pytest.raises(RuntimeError, match="modified in place"):
+        t._take_activation()

@@ -312,3 +312,29 @@ def test_query_batches_of_mixed_layout_accumulate(held_in_eigenbasis):
     assert float((held[3:, :, :16] - want).norm() / want.norm()) <= 1e-5
     assert float(held[..., 16:].abs().max()) == 0.0 if pad else True
 
+
+
+# ---- memory-strategy options of the reference: same results -----------------------------------------------------------
+@pytest.mark.parametrize("kind", ["mlp", "seq"])
+def test_memory_strategy_options_change_nothing(kind, tmp_path, engine):
+    """``offload_activations_to_cpu`` (FactorArguments for the Lambda stage, ScoreArguments for the score stages; reference
+    tracker/factor.py:239, pairwise_score.py:59) and ``use_iterative_lambda_aggregation`` (tracker/factor.py:203-213) choose where an
+    activation waits and how a batch is walked -- never what is computed."""
+    from kronfluence_amd import FactorArguments, ScoreArguments
+
+    spec, analyzer, train, query = build(kind, tmp_path)
+    results = []
+    for tag, frugal in (("plain", False), ("frugal", True)):
+        analyzer.fit_all_factors(f"f_{tag}", train, per_device_batch_size=spec.factor_batch,
+                                 factor_args=FactorArguments(use_empirical_fisher=True, has_shared_parameters=True,
+                                                             offload_activations_to_cpu=frugal, use_iterative_lambda_aggregation=frugal))
+        scores = analyzer.compute_pairwise_scores(f"s_{tag}", f"f_{tag}", query, train, per_device_query_batch_size=spec.query_batch,
+                                                  per_device_train_batch_size=spec.train_batch,
+                                                  score_args=ScoreArguments(damping_factor=None, offload_activations_to_cpu=frugal))
+        selfs = analyzer.compute_self_scores(f"self_{tag}", f"f_{tag}", train, per_device_train_batch_size=spec.train_batch,
+                                             score_args=ScoreArguments(damping_factor=None, offload_activations_to_cpu=frugal))
+        results.append((analyzer.load_lambda_matrices(f"f_{tag}")["lambda_matrix"], scores["all_modules"], selfs["all_modules"]))
+    (lam0, s0, d0), (lam1, s1, d1) = results
+    for module in lam0:   # fp32 storage summed sample by sample instead of batch by batch: rounding order only
+        assert rel(lam1[module], lam0[module]) <= _tol(engine, 1e-6, 2e-5), module
+    assert rel(s1, s0) <= _tol(engine, 1e-6, 1e-4) and rel(d1, d0) <= _tol(engine, 1e-6, 1e-4)   # GPU: two fits differ by atomic order
