@@ -16,4 +16,8 @@ def __getattr__(name):
         from kronfluence_amd import analyzer
 
         return getattr(analyzer, name)
+    if name == "utils":   # the reference exports its ``utils`` package at the top level
+        import importlib
+
+        return importlib.import_module("kronfluence_amd.utils")
     raise AttributeError(name)

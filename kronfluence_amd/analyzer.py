@@ -42,7 +42,7 @@ from kronfluence_amd.score.self import (
 from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import FACTOR_SAVE_PREFIX, FACTOR_TYPE, SCORE_SAVE_PREFIX, SCORE_TYPE
 from kronfluence_amd.utils.dataset import (
-    DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack, make_indices_partition,
+    DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack, find_executable_batch_size, make_indices_partition,
 )
 from kronfluence_amd.utils.exceptions import FactorsNotFoundError, TrackedModuleNotFoundError
 from kronfluence_amd.utils.save import load_file as load_safetensors
@@ -57,13 +57,6 @@ def prepare_model(model: nn.Module, task: Task) -> nn.Module:
     for tensor in list(model.parameters()) + list(model.buffers()):
         tensor.requires_grad = False
     return wrap_tracked_modules(model=model, task=task)
-
-
-def _is_out_of_memory(exc: Exception) -> bool:
-    if isinstance(exc, torch.cuda.OutOfMemoryError):
-        return True
-    text = str(exc).lower()
-    return isinstance(exc, RuntimeError) and ("out of memory" in text or "hiperroroutofmemory" in text)
 
 
 @dataclass
@@ -186,21 +179,14 @@ class Analyzer:
         if self.state.use_distributed:
             raise NotImplementedError("Automatic batch size search is not supported for multi-GPU setting. "
                                       "Please manually configure the batch size by passing in `per_device_batch_size`.")
-        batch_size = max(int(start), 0)
-        while True:
-            if batch_size == 0:
-                raise RuntimeError("No executable batch size found, reached zero.")
-            try:
-                self._reset_memory()
-                probe(batch_size)
-            except Exception as exc:  # noqa: BLE001 -- only memory exhaustion is retried
-                if not _is_out_of_memory(exc):
-                    raise
-                batch_size //= 2
-                continue
+        def attempt(batch_size: int) -> None:
             self._reset_memory()
-            self.logger.info(f"Executable batch size determined: {batch_size}.")
-            return batch_size
+            probe(batch_size)
+
+        batch_size = find_executable_batch_size(attempt, start)
+        self._reset_memory()
+        self.logger.info(f"Executable batch size determined: {batch_size}.")
+        return batch_size
 
     def _partition_plan(self, total_examples: int, data_partitions: int, module_partitions: int,
                         target_data_partitions, target_module_partitions) -> "_PartitionPlan":

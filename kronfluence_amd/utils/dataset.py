@@ -169,3 +169,29 @@ class ResidentLoader:
         n = len(self.sampler)
         for start in range(0, n, self.batch_size):
             yield tuple(t[start:start + self.batch_size] for t in self.tensors)
+
+
+def is_out_of_memory(exc: Exception) -> bool:
+    """Whether ``exc`` is the device running out of HBM (HIP reports it as ``torch.cuda.OutOfMemoryError`` or as a RuntimeError
+    naming hipErrorOutOfMemory)."""
+    if isinstance(exc, torch.cuda.OutOfMemoryError):
+        return True
+    text = str(exc).lower()
+    return isinstance(exc, RuntimeError) and ("out of memory" in text or "hiperroroutofmemory" in text)
+
+
+def find_executable_batch_size(func: Callable[[int], object], start_batch_size: int) -> int:
+    """Largest batch size, halving from ``start_batch_size``, for which ``func(batch_size)`` does not run out of device memory;
+    any other exception propagates, reaching zero raises (reference ``utils/dataset.py:66-101``)."""
+    batch_size = max(int(start_batch_size), 0)
+    while True:
+        if batch_size == 0:
+            raise RuntimeError("No executable batch size found, reached zero.")
+        try:
+            func(batch_size)
+        except Exception as exc:  # noqa: BLE001 -- only memory exhaustion is retried
+            if not is_out_of_memory(exc):
+                raise
+            batch_size //= 2
+            continue
+        return batch_size

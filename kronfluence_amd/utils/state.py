@@ -68,6 +68,15 @@ class State:
     def is_local_main_process(self) -> bool:
         return self.local_process_index == 0
 
+    @property
+    def is_last_process(self) -> bool:
+        return self.process_index == self.num_processes - 1
+
+    @property
+    def default_device(self) -> torch.device:
+        """The device a fresh ``State`` would compute on: the GPU when there is one."""
+        return torch.device("cuda") if torch.cuda.is_available() else torch.device("cpu")
+
     def wait_for_everyone(self) -> None:
         if self.use_distributed:
             dist.barrier()

@@ -263,3 +263,64 @@ def test_whole_stages_on_two_ranks_match_single_process(tmp_path, cpu_engine):
         want = analyzer.compute_self_scores(name, "f", train, per_device_train_batch_size=5,
                                             score_args=ScoreArguments(damping_factor=None, **kw))["all_modules"]
         assert close(got[name], want), name
+
+
+# ---- the reference's launch idiom: prepare_model -> apply_ddp -> Analyzer ---------------------------------------------------
+def _worker_without_group(rank: int, world: int, port: int, out_dir: str) -> None:
+    import cpu_engine
+    from torch.nn.parallel import DistributedDataParallel
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.utils.model import apply_ddp
+    from test_pipeline_gpu import make_task
+
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    cpu_engine.install_in_worker()
+    kind = "mlp"
+    spec = fx.FIXTURES[kind]
+    task = make_task(kind)
+    model = apply_ddp(prepare_model(fx.make_model(kind), task), local_rank=rank, rank=rank, world_size=world)   # creates the group
+    try:
+        assert isinstance(model, DistributedDataParallel) and dist.get_world_size() == world
+        analyzer = Analyzer("t", model, task, output_dir=out_dir, disable_tqdm=True)
+        assert analyzer.state.num_processes == world and analyzer.state.process_index == rank
+        assert analyzer.state.is_last_process == (rank == world - 1)
+        train = data.TensorDataset(*fx.make_data(kind, spec.n_train - 1, seed=1))
+        query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
+        analyzer.fit_all_factors("f", train, per_device_batch_size=7, factor_args=FactorArguments(use_empirical_fisher=True))
+        out = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=2, per_device_train_batch_size=5,
+                                               score_args=ScoreArguments(damping_factor=None))
+        if rank == 0:
+            torch.save(out["all_modules"], os.path.join(out_dir, "ddp_scores.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_apply_ddp_then_analyzer_on_two_ranks(tmp_path, cpu_engine):
+    """``utils.model.apply_ddp`` (reference utils/model.py:17-55) creates the process group and returns the replica container the
+    reference's multi-GPU scripts hand to the Analyzer; factor keys and scores are those of the unwrapped single-process run."""
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.utils.model import apply_fsdp
+    from test_pipeline_gpu import make_task
+
+    (tmp_path / "two").mkdir()
+    mp.spawn(_worker_without_group, args=(2, _free_port(), str(tmp_path / "two")), nprocs=2, join=True)
+    got = torch.load(tmp_path / "two" / "ddp_scores.pt")
+    kind = "mlp"
+    spec = fx.FIXTURES[kind]
+    task = make_task(kind)
+    analyzer = Analyzer("t", prepare_model(fx.make_model(kind), task), task, output_dir=str(tmp_path / "one"), disable_tqdm=True)
+    train = data.TensorDataset(*fx.make_data(kind, spec.n_train - 1, seed=1))
+    query = data.TensorDataset(*fx.make_data(kind, spec.n_query, seed=2))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=7, factor_args=FactorArguments(use_empirical_fisher=True))
+    want = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=2, per_device_train_batch_size=5,
+                                            score_args=ScoreArguments(damping_factor=None))["all_modules"]
+    assert got.shape == want.shape and float((got.double() - want.double()).abs().max() / want.abs().max()) <= 2e-5
+    one = set(os.listdir(analyzer.factors_output_dir("f")))
+    two = set(os.listdir(tmp_path / "two" / "t" / "factors_f"))
+    assert one == two   # same files; module names carry no "module." prefix
+    with pytest.raises(NotImplementedError, match="apply_ddp"):
+        apply_fsdp(None, 0, 0, 1)

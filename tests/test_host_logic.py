@@ -344,3 +344,45 @@ def test_offloaded_activations_wait_on_the_host_and_come_back():
     x._version = 1                                                     # held by reference: a later in-place write is caught
     with pytest.raises(RuntimeError, match="modified in place"):
         t._take_activation()
+
+
+def test_verify_models_equivalence_follows_the_reference_rules():
+    """utils/save.py:67-101: same keys, values equal within rtol 1.3e-6 / atol 1e-5 as fp32."""
+    from kronfluence_amd.utils.save import verify_models_equivalence
+
+    a = {"w": torch.arange(6.0).reshape(2, 3), "b": torch.ones(3, dtype=torch.float64)}
+    assert verify_models_equivalence(a, {k: v.clone() for k, v in a.items()})
+    assert verify_models_equivalence(a, {"w": a["w"] + 5e-6, "b": a["b"].to(torch.bfloat16)})
+    assert not verify_models_equivalence(a, {"w": a["w"] + 1e-3, "b": a["b"]})
+    assert not verify_models_equivalence(a, {"w": a["w"]})
+    assert not verify_models_equivalence(a, {"w": a["w"], "c": a["b"]})
+    assert not verify_models_equivalence(a, {"w": a["w"].reshape(3, 2), "b": a["b"]})
+
+
+def test_batch_size_search_halves_on_memory_exhaustion_only():
+    """``utils.dataset.find_executable_batch_size`` (reference utils/dataset.py:66-101), also what the Analyzer's automatic batch
+    size uses: halve on out-of-memory, propagate anything else, fail at zero."""
+    import kronfluence_amd
+    from kronfluence_amd.utils.dataset import find_executable_batch_size
+
+    assert kronfluence_amd.utils.dataset.find_executable_batch_size is find_executable_batch_size   # `utils` is exported
+    tried = []
+
+    def fits_below_600(batch_size):
+        tried.append(batch_size)
+        if batch_size >= 600:
+            raise RuntimeError("HIP out of memory. Tried to allocate 1.00 GiB")
+
+    assert find_executable_batch_size(fits_below_600, 4096) == 512 and tried == [4096, 2048, 1024, 512]
+
+    def broken(batch_size):
+        raise ValueError("not a memory problem")
+
+    with pytest.raises(ValueError):
+        find_executable_batch_size(broken, 8)
+
+    def never(batch_size):
+        raise torch.cuda.OutOfMemoryError("out of memory")
+
+    with pytest.raises(RuntimeError, match="reached zero"):
+        find_executable_batch_size(never, 4)
