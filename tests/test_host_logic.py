@@ -386,3 +386,37 @@ def test_batch_size_search_halves_on_memory_exhaustion_only():
 
     with pytest.raises(RuntimeError, match="reached zero"):
         find_executable_batch_size(never, 4)
+
+
+@pytest.mark.parametrize("q,o,ip,pad,conv,prepadded,blocks", [
+    (5, 8, 16, 0, 0, 0, 1),        # Linear, nothing to pad
+    (130, 16, 9, 7, 0, 0, 1),      # odd I' = 9 padded to 16; more queries than one conversion chunk (64)
+    (70, 16, 9, 0, 0, 7, 3),       # the bf16 preconditioner already appended the 7 zero columns; three query batches
+    (33, 8, 27, 0, 3, 0, 2),       # first conv layer: 3 channels x 9 taps, channels padded to 8 in (ky, kx, c) order
+    (9, 4, 144, 0, 16, 0, 1),      # 16 channels x 9 taps: nothing padded, only re-ordered
+])
+def test_k_tile_major_query_layout_is_a_faithful_relayout(q, o, ip, pad, conv, prepadded, blocks):
+    """``TiledQueries``: the held bf16 query gradients as ``[D' / 64, Q, 64]`` -- pure data movement, checked on the CPU: element
+    ``(query, o, column)`` sits at ``d = o * width + position`` with the patch axis of a convolution re-ordered ``(c, ky, kx)`` ->
+    ``(ky, kx, c_padded)``, appended columns / channels are zero, and ``dense()`` gives back the reference's ``[Q, O, I']``."""
+    from kronfluence_amd.module.tracker.base import QueryBlocks
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    gen = torch.Generator().manual_seed(q + ip)
+    want = torch.randn(q, o, ip, generator=gen).bfloat16()
+    held = torch.nn.functional.pad(want, (0, prepadded)) if prepadded else want
+    source = held if blocks == 1 else QueryBlocks(list(torch.tensor_split(held, blocks)))
+    tiled = TiledQueries(source, pad, conv_channels=conv, prepadded=prepadded)
+    width = tiled.shape[2]
+    assert tiled.shape[:2] == (q, o) and tiled.tiled.shape == (o * width // 64, q, 64) and tiled.tiled.dtype == torch.bfloat16
+    flat = tiled.tiled.transpose(0, 1).reshape(q, o, width)
+    if conv:
+        taps, cp = ip // conv, conv + (-conv) % 8
+        assert width == taps * cp
+        by_tap = flat.reshape(q, o, taps, cp)
+        assert torch.equal(by_tap[..., :conv], want.reshape(q, o, conv, taps).transpose(2, 3))   # (c, tap) -> (tap, c)
+        assert not by_tap[..., conv:].any()
+    else:
+        assert width == ip + pad + prepadded and width % 8 == 0
+        assert torch.equal(flat[..., :ip], want) and not flat[..., ip:].any()
+    assert torch.equal(tiled.dense(), want)
