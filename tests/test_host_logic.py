@@ -420,3 +420,41 @@ def test_k_tile_major_query_layout_is_a_faithful_relayout(q, o, ip, pad, conv, p
         assert width == ip + pad + prepadded and width % 8 == 0
         assert torch.equal(flat[..., :ip], want) and not flat[..., ip:].any()
     assert torch.equal(tiled.dense(), want)
+
+
+def test_conv_layout_helpers_are_exact_relayouts():
+    """Pure data movement behind the implicit-im2col kernels, on the CPU: ``ops.conv_patch_order_eigenvectors`` (``Q_A^T`` with the
+    patch axis re-ordered (c, ky, kx) -> (ky, kx, c_padded)) contracts a re-ordered patch exactly like ``Q_A`` contracts the
+    reference's patch; ``ops.conv_geometry`` resolves string paddings like module/conv2d.py:46-53; ``ops.k_tile_major``."""
+    from kronfluence_amd import ops
+    from kronfluence_amd.utils.exceptions import UnsupportableModuleError
+
+    channels, taps = 3, 9
+    ip = channels * taps                                                 # a bias-free convolution: I' = C * taps
+    gen = torch.Generator().manual_seed(0)
+    q_a = torch.randn(ip, ip, generator=gen, dtype=torch.float64)
+    perm = ops.conv_patch_order_eigenvectors(q_a, channels, taps)
+    cp = 8
+    assert perm.shape == (ip + (-ip) % 8, taps * cp) and perm.dtype == torch.bfloat16
+    patch = torch.randn(channels, taps, generator=gen, dtype=torch.float64)            # reference order (c, tap)
+    patch_k = torch.zeros(taps, cp, dtype=torch.float64)
+    patch_k[:, :channels] = patch.t()                                                    # kernel order (tap, c_padded)
+    want = q_a.to(torch.bfloat16).double().t() @ patch.reshape(-1)                      # (Q_A^T patch)[i'] in the reference's order
+    got = perm.double() @ patch_k.reshape(-1)
+    assert torch.allclose(got[:ip], want, atol=1e-12) and not got[ip:].any()
+
+    for padding, kernel, dilation, expect in (("same", (3, 5), (1, 1), (1, 2)), ("valid", (3, 3), (1, 1), (0, 0)),
+                                              ("same", (3, 3), (2, 2), (2, 2)), ((2, 1), (5, 3), (1, 1), (2, 1))):
+        conv = nn.Conv2d(4, 6, kernel, padding=padding, dilation=dilation)
+        geometry = ops.conv_geometry(conv)
+        assert geometry[4:6] == expect and geometry[:2] == kernel and geometry[6:] == dilation
+        x = torch.randn(2, 4, 11, 13)
+        h = (11 + 2 * geometry[4] - dilation[0] * (kernel[0] - 1) - 1) // 1 + 1
+        w = (13 + 2 * geometry[5] - dilation[1] * (kernel[1] - 1) - 1) // 1 + 1
+        assert conv(x).shape[2:] == (h, w)
+    with pytest.raises(UnsupportableModuleError):
+        ops.conv_geometry(nn.Conv2d(4, 6, (2, 3), padding="same"))        # even kernel: unequal padding, as in the reference
+
+    p = torch.arange(3 * 4 * 32, dtype=torch.float32).reshape(3, 4, 32)   # [rows, ...] with 128 elements per row
+    tiled = ops.k_tile_major(p)
+    assert tiled.shape == (2, 3, 64) and torch.equal(tiled.transpose(0, 1).reshape(3, 128), p.reshape(3, 128))
