@@ -1,0 +1,182 @@
+"""Differential fuzz of the HOST LOGIC against the real reference -- a development tool for the build container only (it imports
+/root/reference; nothing in tests/, bench.py or the product uses it).
+
+Both packages run in one process on the CPU in fp64: the reference as it is (with the two no-arithmetic shims of tests/golden/_shims),
+this engine with the HIP leaf operators replaced by the torch stand-ins of tests/cpu_engine.py.  Every round draws a random
+configuration -- fixture, strategy, damping, batch sizes, data / module partitions, query accumulation, per-module / per-token
+scores, query / train aggregation, self-influence with or without measurement -- runs both and compares every returned score
+tensor.  What is exercised is what the stand-ins do not replace: trackers, stage loops, partition plans, samplers, accumulation,
+aggregation, file layout, argument handling.
+
+    cd /tmp && PYTHONDONTWRITEBYTECODE=1 python /root/repo/tools/ref_diff_fuzz.py [rounds] [seed]
+"""
+import os
+import random
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden", "_shims"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+from torch.utils import data  # noqa: E402
+
+import cpu_engine  # noqa: E402
+import fixtures as fx  # noqa: E402
+import kronfluence as ref_pkg  # noqa: E402
+import kronfluence_amd as our_pkg  # noqa: E402
+from kronfluence.utils.dataset import DataLoaderKwargs as RefKwargs  # noqa: E402,F401
+
+
+def make_task(pkg, kind, modules=None, post_process=False):
+    loss, measure, mask = fx.train_loss(kind), fx.measurement(kind), fx.attention_mask(kind)
+
+    class FuzzTask(pkg.Task):
+        enable_post_process_per_sample_gradient = post_process
+
+        def compute_train_loss(self, batch, model, sample=False):
+            return loss(model, tuple(batch))
+
+        def compute_measurement(self, batch, model):
+            return measure(model, tuple(batch))
+
+        def get_attention_mask(self, batch):
+            return None if mask is None else mask(tuple(batch))
+
+        def get_influence_tracked_modules(self):
+            return modules
+
+        def post_process_per_sample_gradient(self, module_name, gradient):
+            # a module-dependent linear map of the gradient: scale, and flip the sign of the first output row
+            out = gradient * (0.5 + 0.25 * (len(module_name) % 3))
+            out[:, 0] = -out[:, 0]
+            return out
+
+    return FuzzTask()
+
+
+def layer_names(kind):
+    from torch import nn
+
+    return [name for name, module in fx.make_model(kind).named_modules() if isinstance(module, (nn.Linear, nn.Conv2d))]
+
+
+def draw(rng):
+    # ("shared" -- a module used twice per forward -- is a DELIBERATE divergence in scoring: the reference scores the last use only,
+    # this engine all uses, tests/test_pipeline_gpu.py checks that against autograd; add it here to see the difference)
+    kind = rng.choice(["mlp", "conv", "seq"])
+    spec = fx.SHARED_FIXTURE if kind == "shared" else fx.FIXTURES[kind]
+    cfg = dict(kind=kind, strategy=rng.choice(["ekfac", "ekfac", "kfac", "diagonal", "identity"]),
+               damping=rng.choice([None, 1e-3, 1e-2]),   # well conditioned: the stand-ins store fp32 (so does the engine), 1e-8 amplifies that
+               n_train=rng.randint(max(6, spec.n_train // 2), spec.n_train), n_query=rng.randint(2, spec.n_query),
+               factor_batch=rng.randint(2, 9), train_batch=rng.randint(1, 7), query_batch=rng.randint(1, 4),
+               cov_parts=rng.choice([1, 1, 2]), lam_parts=rng.choice([1, 1, 2]), cov_mod_parts=rng.choice([1, 2]),
+               lam_mod_parts=rng.choice([1, 2]), data_parts=rng.choice([1, 1, 2, 3]), mod_parts=rng.choice([1, 1, 2]),
+               accumulation=rng.choice([1, 1, 2, 3]), per_module=rng.random() < 0.3, per_token=False, agg_q=False, agg_t=False,
+               what=rng.choice(["pairwise", "pairwise", "pairwise", "self", "self_measurement"]),
+               modules=None, post_process=rng.random() < 0.25)
+    names = layer_names(kind)
+    if rng.random() < 0.35 and len(names) > 1:
+        cfg["modules"] = sorted(rng.sample(names, rng.randint(1, len(names) - 1)), key=names.index)
+    count = len(cfg["modules"] or names)   # partitions cannot outnumber the tracked modules
+    for key in ("cov_mod_parts", "lam_mod_parts", "mod_parts"):
+        cfg[key] = min(cfg[key], count)
+    mode = rng.random()
+    if cfg["what"] == "pairwise":
+        if mode < 0.15:
+            cfg["agg_q"] = True
+        elif mode < 0.3:
+            cfg["agg_t"] = True
+        elif mode < 0.4:
+            cfg["agg_q"] = cfg["agg_t"] = True
+        elif mode < 0.55 and kind == "seq":
+            cfg["per_token"] = True
+    return cfg
+
+
+def run(pkg, cfg, out_dir, ours):
+    kind = cfg["kind"]
+    task = make_task(pkg, kind, cfg.get("modules"), cfg.get("post_process", False))
+    model = pkg.prepare_model(fx.make_model(kind).double(), task)
+    train = data.TensorDataset(*fx.make_data(kind, cfg["n_train"], seed=1))
+    query = data.TensorDataset(*fx.make_data(kind, cfg["n_query"], seed=2))
+    kwargs = dict(disable_tqdm=True, output_dir=out_dir)
+    if not ours:
+        kwargs["cpu"] = True
+    analyzer = pkg.Analyzer("fuzz", model, task, **kwargs)
+    f64 = torch.float64
+    fargs = pkg.FactorArguments(strategy=cfg["strategy"], use_empirical_fisher=True, has_shared_parameters=kind == "shared",
+                                covariance_data_partitions=cfg["cov_parts"],
+                                lambda_data_partitions=cfg["lam_parts"], covariance_module_partitions=cfg["cov_mod_parts"],
+                                lambda_module_partitions=cfg["lam_mod_parts"], activation_covariance_dtype=f64,
+                                gradient_covariance_dtype=f64, per_sample_gradient_dtype=f64, lambda_dtype=f64)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=cfg["factor_batch"], factor_args=fargs)
+    sargs = pkg.ScoreArguments(damping_factor=cfg["damping"], data_partitions=cfg["data_parts"], module_partitions=cfg["mod_parts"],
+                               query_gradient_accumulation_steps=cfg["accumulation"], compute_per_module_scores=cfg["per_module"],
+                               compute_per_token_scores=cfg["per_token"], aggregate_query_gradients=cfg["agg_q"],
+                               aggregate_train_gradients=cfg["agg_t"],
+                               use_measurement_for_self_influence=cfg["what"] == "self_measurement",
+                               per_sample_gradient_dtype=f64, precondition_dtype=f64, score_dtype=f64)
+    if cfg["what"] == "pairwise":
+        analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=cfg["query_batch"],
+                                         per_device_train_batch_size=cfg["train_batch"], score_args=sargs)
+        out = analyzer.load_pairwise_scores("s")
+    else:
+        analyzer.compute_self_scores("s", "f", train, per_device_train_batch_size=cfg["train_batch"], score_args=sargs)
+        out = analyzer.load_self_scores("s")
+    return {k: v.double() for k, v in out.items()}
+
+
+class _Patch:
+    def __init__(self):
+        self.saved = []
+
+    def setattr(self, obj, name, value, raising=True):
+        del raising
+        self.saved.append((obj, name, getattr(obj, name, None)))
+        setattr(obj, name, value)
+
+
+def main():
+    rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    rng = random.Random(seed)
+    cpu_engine.install(_Patch())
+    bad = 0
+    for index in range(rounds):
+        cfg = draw(rng)
+        try:
+            with tempfile.TemporaryDirectory() as a, tempfile.TemporaryDirectory() as b:
+                want = run(ref_pkg, cfg, a, ours=False)
+                from kronfluence_amd.utils.state import State
+                State._reset_state()
+                got = run(our_pkg, cfg, b, ours=True)
+        except Exception as exc:  # noqa: BLE001 -- report and go on: a crash on one side only is a finding
+            bad += 1
+            print(f"[{index}] EXCEPTION {type(exc).__name__}: {str(exc)[:300]}\n      cfg {cfg}", flush=True)
+            continue
+        worst, where = 0.0, ""
+        if set(want) != set(got):
+            worst, where = float("inf"), f"keys {sorted(want)} vs {sorted(got)}"
+        else:
+            for key in want:
+                if want[key].shape != got[key].shape:
+                    worst, where = float("inf"), f"{key}: shape {tuple(want[key].shape)} vs {tuple(got[key].shape)}"
+                    break
+                err = float((got[key] - want[key]).norm() / want[key].norm().clamp_min(1e-300))
+                if err > worst:
+                    worst, where = err, key
+        flag = "" if worst <= 5e-5 else "   <-- MISMATCH"   # fp32 storage of the stand-ins, through an eigenbasis
+        bad += bool(flag)
+        print(f"[{index}] {cfg['kind']:4s} {cfg['strategy']:8s} {cfg['what']:16s} rel {worst:.1e} ({where}){flag}"
+              + (f"\n      cfg {cfg}" if flag else ""), flush=True)
+    print(f"{rounds} rounds, {bad} findings")
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
