@@ -139,7 +139,17 @@ def run(pkg, cfg, out_dir, ours):
     else:
         analyzer.compute_self_scores("s", "f", train, per_device_train_batch_size=cfg["train_batch"], score_args=sargs)
         out = analyzer.load_self_scores("s")
-    return {k: v.double() for k, v in out.items()}
+    result = {k: v.double() for k, v in out.items()}
+    # the factors as stored on disk (eigenvectors are defined up to sign / rotation in degenerate subspaces: not compared)
+    stored = dict(analyzer.load_all_factors("f"))
+    for loader in (analyzer.load_covariance_matrices, analyzer.load_lambda_matrices):
+        stored.update(loader("f") or {})
+    for factor_name, per_module in stored.items():
+        if "eigenvectors" in factor_name:
+            continue
+        for module_name, tensor in per_module.items():
+            result[f"factor/{factor_name}/{module_name}"] = tensor.double()
+    return result
 
 
 class _Patch:
