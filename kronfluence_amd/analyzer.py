@@ -78,7 +78,7 @@ class Analyzer:
                  log_level: Optional[int] = None, log_main_process_only: bool = True, profile: bool = False,
                  disable_tqdm: bool = False, output_dir: str = "./influence_results",
                  disable_model_save: bool = True) -> None:
-        del log_main_process_only, disable_model_save
+        del log_main_process_only
         self._require_gpu(cpu)
         self.name, self.task, self.disable_tqdm, self.profile = analysis_name, task, disable_tqdm, profile
         self.state = State(cpu=False)
@@ -93,11 +93,37 @@ class Analyzer:
         self.output_dir = Path(output_dir).joinpath(analysis_name).resolve()
         if self.state.is_main_process:
             os.makedirs(self.output_dir, exist_ok=True)
+        if self.state.is_main_process and not disable_model_save:
+            self._save_model()
         self._dataloader_params = DataLoaderKwargs()
         self.timings: Dict[str, float] = {}
         self.state.wait_for_everyone()
 
     # -- helpers -----------------------------------------------------------------------------------
+    def _save_model(self) -> None:
+        """``disable_model_save=False`` (reference analyzer.py:107-143): the first Analyzer of an output directory stores the model's
+        state dict as ``model.safetensors``; every later one compares its model with that file and refuses to go on with a
+        different one (factors and scores under this name belong to the stored model)."""
+        from safetensors.torch import save_file
+
+        from kronfluence_amd.utils.save import verify_models_equivalence
+
+        path = self.output_dir / "model.safetensors"
+        from torch.nn.parallel import DataParallel, DistributedDataParallel
+
+        model = self.model.module if isinstance(self.model, (DataParallel, DistributedDataParallel)) else self.model
+        state_dict = model.state_dict()
+        if path.exists():
+            if not verify_models_equivalence(load_safetensors(path), state_dict):
+                message = (f"Detected a difference between the current model and the one saved at `{path}`. "
+                           "Consider using a different `analysis_name` to avoid conflicts.")
+                self.logger.error(message)
+                raise ValueError(message)
+            self.logger.info(f"Found existing saved model at `{path}`.")
+            return
+        save_file({key: value.detach().to("cpu").clone().contiguous() for key, value in state_dict.items()}, str(path))
+        self.logger.info(f"Saved model at `{path}`.")
+
     @staticmethod
     def _require_gpu(cpu: bool) -> None:
         if cpu:

@@ -291,3 +291,27 @@ def test_in_place_write_to_a_hooked_activation_is_detected(tmp_path, cpu_engine)
     eig = perform_eigendecomposition(cov, model, state, fargs)
     with pytest.raises(RuntimeError, match="modified in place"):
         fit_lambda_matrices_with_loader(model, state, task, batches, fargs, eig)
+
+
+def test_model_save_guards_the_output_directory(tmp_path, cpu_engine):
+    """``Analyzer(disable_model_save=False)`` (reference analyzer.py:107-143): the first Analyzer of a directory stores the model, a
+    later one with the same model is accepted, with other weights refused; the default stores nothing."""
+    from kronfluence_amd import Analyzer, prepare_model
+    from test_pipeline_gpu import make_task
+
+    kind = "mlp"
+    task = make_task(kind)
+
+    def analyzer(name, seed, **kw):
+        return Analyzer(name, prepare_model(fx.make_model(kind, seed=seed), task), task, output_dir=str(tmp_path), disable_tqdm=True, **kw)
+
+    first = analyzer("guarded", 0, disable_model_save=False)
+    saved = first.output_dir / "model.safetensors"
+    assert saved.exists()
+    stamp = saved.stat().st_mtime_ns
+    analyzer("guarded", 0, disable_model_save=False)                   # the same weights: accepted, file untouched
+    assert saved.stat().st_mtime_ns == stamp
+    with pytest.raises(ValueError, match="different `analysis_name`"):
+        analyzer("guarded", 1, disable_model_save=False)               # other weights under the same name
+    analyzer("guarded", 1)                                             # the default does not look
+    assert not (analyzer("plain", 0).output_dir / "model.safetensors").exists()
