@@ -315,3 +315,33 @@ def test_model_save_guards_the_output_directory(tmp_path, cpu_engine):
         analyzer("guarded", 1, disable_model_save=False)               # other weights under the same name
     analyzer("guarded", 1)                                             # the default does not look
     assert not (analyzer("plain", 0).output_dir / "model.safetensors").exists()
+
+
+@pytest.mark.parametrize("with_measurement", [False, True])
+def test_self_scores_of_shared_modules_match_autograd(tmp_path, cpu_engine, with_measurement):
+    """A Linear used three times per forward, identity strategy (so that the expected value needs no factors): the self-influence
+    score of sample i is ``sum over parameters <grad m_i, grad L_i>`` with every use of the shared weight in both gradients
+    (``m = L`` without measurement).  The reference is exact without measurement and 13 % off with it."""
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from test_pipeline_gpu import make_task
+
+    kind, n = "shared", 12
+    task = make_task(kind)
+    analyzer = Analyzer("t", prepare_model(fx.make_model(kind).double(), task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    train_t = fx.make_data(kind, n, seed=1)
+    analyzer.fit_all_factors("f", data.TensorDataset(*train_t), per_device_batch_size=4,
+                             factor_args=FactorArguments(strategy="identity", has_shared_parameters=True))
+    got = analyzer.compute_self_scores("s", "f", data.TensorDataset(*train_t), per_device_train_batch_size=5,
+                                       score_args=ScoreArguments(use_measurement_for_self_influence=with_measurement))["all_modules"]
+    model = fx.make_model(kind).double()
+    loss, measure = fx.train_loss(kind), fx.measurement(kind)
+    params = [p for _, p in model.named_parameters()]
+    want = []
+    for i in range(n):
+        batch = tuple(t[i:i + 1] for t in train_t)
+        g_loss = torch.autograd.grad(loss(model, batch), params, allow_unused=True)
+        g_meas = torch.autograd.grad((measure if with_measurement else loss)(model, batch), params, allow_unused=True)
+        want.append(sum((a * b).sum() for a, b in zip(g_loss, g_meas) if a is not None and b is not None))
+    assert rel(got.flatten().double(), torch.stack(want)) <= 1e-6
