@@ -256,8 +256,10 @@ class Analyzer:
         return cls(**{k: (getattr(torch, v.split(".")[1]) if isinstance(v, str) and v.startswith("torch.") else v)
                       for k, v in load_json(path).items()})
 
-    def _stored_factor_args(self, factors_name: str) -> FactorArguments:
+    def _stored_factor_args(self, factors_name: str, aggregating: bool = False) -> FactorArguments:
         stored = self.load_factor_args(factors_name)
+        if stored is None and aggregating:   # the reference's aggregate_* raise ValueError here (factor_computer.py:361-368)
+            raise ValueError(f"Arguments for factors with name `{factors_name}` was not found when trying to aggregate factors.")
         if stored is None:
             raise FactorsNotFoundError(f"Factors with name `{factors_name}` not found at `{self.factors_output_dir(factors_name)}`.")
         return stored
@@ -265,7 +267,7 @@ class Analyzer:
     def _stored_score_args(self, scores_name: str) -> ScoreArguments:
         stored = self.load_score_args(scores_name)
         if stored is None:
-            raise ValueError(f"Arguments for scores with name `{scores_name}` were not found.")
+            raise ValueError(f"Arguments for scores with name `{scores_name}` was not found when trying to aggregate influence scores.")
         return stored
 
     @torch.no_grad()
@@ -295,10 +297,10 @@ class Analyzer:
     def _aggregate_scores(self, scores_name: str, exist_fnc, load_fnc, save_fnc, dim: int) -> Optional[SCORE_TYPE]:
         """Module partitions add, data partitions concatenate along the train axis -- or add, when the train
         gradients were aggregated (reference ``score_computer.py:77-139``)."""
+        score_args = self._stored_score_args(scores_name)   # ValueError when nothing was computed under this name, as the reference
         out = self.scores_output_dir(scores_name)
         if not out.exists():
             raise FileNotFoundError(f"Scores directory `{out}` not found when trying to aggregate scores.")
-        score_args = self._stored_score_args(scores_name)
         grid = [(i, j) for i in range(score_args.data_partitions) for j in range(score_args.module_partitions)]
         if not all(exist_fnc(out, partition=cell) for cell in grid):
             return None
@@ -403,7 +405,7 @@ class Analyzer:
 
     def aggregate_covariance_matrices(self, factors_name: str) -> None:
         """Aggregates the partitioned covariance files once all of them exist (reference ``factor_computer.py:350-378``)."""
-        factor_args = self._stored_factor_args(factors_name)
+        factor_args = self._stored_factor_args(factors_name, aggregating=True)
         self._aggregate_factors(factors_name, factor_args.covariance_data_partitions, factor_args.covariance_module_partitions,
                                 covariance_matrices_exist, load_covariance_matrices, save_covariance_matrices,
                                 metadata=factor_args.to_str_dict())
@@ -489,7 +491,7 @@ class Analyzer:
 
     def aggregate_lambda_matrices(self, factors_name: str) -> None:
         """Aggregates the partitioned Lambda files once all of them exist (reference ``factor_computer.py:704-732``)."""
-        factor_args = self._stored_factor_args(factors_name)
+        factor_args = self._stored_factor_args(factors_name, aggregating=True)
         self._aggregate_factors(factors_name, factor_args.lambda_data_partitions, factor_args.lambda_module_partitions,
                                 lambda_matrices_exist, load_lambda_matrices, save_lambda_matrices,
                                 metadata=factor_args.to_str_dict())
@@ -553,15 +555,20 @@ class Analyzer:
     def load_all_factors(self, factors_name: str) -> FACTOR_TYPE:
         """Everything the strategy needs for preconditioning (reference ``computer/computer.py:387-434``)."""
         stored = self.load_factor_args(factors_name)
-        strategy = stored.strategy if stored else "ekfac"
-        config = FactorConfig.CONFIGS[strategy]
+        if stored is None:
+            raise FileNotFoundError(f"Factors with name `{factors_name}` was not found at `{self.factors_output_dir(factors_name)}`.")
+        config = FactorConfig.CONFIGS[stored.strategy]
         loaded: FACTOR_TYPE = {}
-        if config.requires_covariance_matrices_for_precondition:
-            loaded.update(self.load_covariance_matrices(factors_name) or {})
-        if config.requires_eigendecomposition_for_precondition:
-            loaded.update(self.load_eigendecomposition(factors_name) or {})
-        if config.requires_lambda_matrices_for_precondition:
-            loaded.update(self.load_lambda_matrices(factors_name) or {})
+        for required, load, what in (
+                (config.requires_covariance_matrices_for_precondition, self.load_covariance_matrices, "covariance matrices"),
+                (config.requires_eigendecomposition_for_precondition, self.load_eigendecomposition, "Eigendecomposition results"),
+                (config.requires_lambda_matrices_for_precondition, self.load_lambda_matrices, "Lambda matrices")):
+            if not required:
+                continue
+            factors = load(factors_name)
+            if factors is None:
+                raise FactorsNotFoundError(f"Strategy `{stored.strategy}` requires {what}. However, the {what} were not found.")
+            loaded.update(factors)
         return loaded
 
     # -- scores ------------------------------------------------------------------------------------

@@ -34,10 +34,18 @@ class FactorStrategy:
     EKFAC = "ekfac"
 
 
+class UnknownFactorStrategyError(KeyError, NotImplementedError):
+    """An unregistered strategy name: a ``KeyError`` like the reference's plain dict lookup (``FactorConfig.CONFIGS[name]``), and a
+    ``NotImplementedError`` for callers that ask whether a strategy exists on this engine."""
+
+    def __str__(self) -> str:   # KeyError would print the repr of the message
+        return str(self.args[0]) if self.args else ""
+
+
 class _Registry(dict):
     def __missing__(self, key: str) -> "FactorConfig":
         known = ", ".join(sorted(self))
-        raise NotImplementedError(
+        raise UnknownFactorStrategyError(
             f"Factor strategy `{key}` is not part of the MI355X hot path (available: {known}). "
             "See SURVEY.md section 8(f) for the widening order."
         )

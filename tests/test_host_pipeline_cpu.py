@@ -345,3 +345,36 @@ def test_self_scores_of_shared_modules_match_autograd(tmp_path, cpu_engine, with
         g_meas = torch.autograd.grad((measure if with_measurement else loss)(model, batch), params, allow_unused=True)
         want.append(sum((a * b).sum() for a, b in zip(g_loss, g_meas) if a is not None and b is not None))
     assert rel(got.flatten().double(), torch.stack(want)) <= 1e-6
+
+
+def test_missing_results_raise_what_the_reference_raises(tmp_path, cpu_engine):
+    """Error behaviour compared with the reference side by side in the build container (not in this test): an unknown strategy is
+    a ``KeyError``; ``load_all_factors`` of an unknown name a ``FileNotFoundError``, of a name whose strategy lacks a factor group
+    a ``FactorsNotFoundError``; every ``aggregate_*`` of an unknown name a ``ValueError``; ``load_*`` of an unknown name ``None``."""
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, prepare_model
+    from kronfluence_amd.factor.config import FactorConfig
+    from kronfluence_amd.utils.exceptions import FactorsNotFoundError
+    from test_pipeline_gpu import make_task
+
+    kind = "mlp"
+    task = make_task(kind)
+    analyzer = Analyzer("t", prepare_model(fx.make_model(kind), task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    with pytest.raises(KeyError):
+        FactorConfig.CONFIGS["no-such-strategy"]
+    with pytest.raises(NotImplementedError, match="no-such-strategy"):
+        FactorConfig.CONFIGS["no-such-strategy"]
+    with pytest.raises(FileNotFoundError):
+        analyzer.load_all_factors("missing")
+    for aggregate in (analyzer.aggregate_pairwise_scores, analyzer.aggregate_self_scores, analyzer.aggregate_covariance_matrices,
+                      analyzer.aggregate_lambda_matrices):
+        with pytest.raises(ValueError):
+            aggregate("missing")
+    for load in (analyzer.load_pairwise_scores, analyzer.load_self_scores, analyzer.load_covariance_matrices,
+                 analyzer.load_eigendecomposition, analyzer.load_lambda_matrices, analyzer.load_factor_args, analyzer.load_score_args):
+        assert load("missing") is None
+    train = data.TensorDataset(*fx.make_data(kind, 12, seed=1))
+    analyzer.fit_covariance_matrices("partial", train, per_device_batch_size=4, factor_args=FactorArguments(use_empirical_fisher=True))
+    with pytest.raises(FactorsNotFoundError, match="Eigendecomposition"):
+        analyzer.load_all_factors("partial")                      # ekfac needs eigenvectors and Lambda too
