@@ -428,6 +428,13 @@ class Analyzer:
             raise FactorsNotFoundError(f"Covariance matrices not found at `{source}`. "
                                        f"To perform eigendecomposition, call `fit_covariance_matrices` first.")
         covariance = load_covariance_matrices(source)
+        if load_from_factors_name is not None:
+            # reference factor_computer.py:434-444: the borrowed covariances become part of THIS name (load_covariance_matrices of
+            # it returns them), together with the arguments they were fitted with
+            if self.state.is_main_process:
+                save_covariance_matrices(out, covariance)
+            self._save_arguments(out / "factor_loaded_covariance_arguments.json", self._stored_factor_args(load_from_factors_name), True)
+            self.state.wait_for_everyone()
         with self._timed("perform_eigendecomposition"):
             eigen = perform_eigendecomposition(covariance, self.model, self.state, factor_args)
         if self.state.is_main_process:
@@ -461,6 +468,12 @@ class Analyzer:
                 raise FactorsNotFoundError(f"Eigendecomposition results not found at `{source}`. "
                                            f"To fit Lambda matrices, call `perform_eigendecomposition` first.")
             eigen = load_eigendecomposition(source)
+            if load_from_factors_name is not None:   # reference factor_computer.py:563-573
+                if self.state.is_main_process:
+                    save_eigendecomposition(out, eigen)
+                self._save_arguments(out / "factor_loaded_eigendecomposition_arguments.json",
+                                     self._stored_factor_args(load_from_factors_name), True)
+                self.state.wait_for_everyone()
         batch_size = per_device_batch_size
         total = len(dataset) if factor_args.lambda_max_examples is None else min(factor_args.lambda_max_examples, len(dataset))
         plan = self._partition_plan(total, factor_args.lambda_data_partitions, factor_args.lambda_module_partitions,
@@ -598,6 +611,7 @@ class Analyzer:
                                 "disabling `compute_per_token_scores`.")
             score_args = dataclasses.replace(score_args, compute_per_token_scores=False)
         self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
+        self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)   # which factors these scores used
         loaded = self.load_all_factors(factors_name)
         if not loaded and FactorConfig.CONFIGS[factor_args.strategy].requires_lambda_matrices_for_precondition:
             raise FactorsNotFoundError(f"Factors with name `{factors_name}` are incomplete.")
@@ -685,6 +699,7 @@ class Analyzer:
             score_args = dataclasses.replace(score_args, query_gradient_low_rank=None, aggregate_query_gradients=False,
                                              aggregate_train_gradients=False, compute_per_token_scores=False)
         self._save_arguments(out / "score_arguments.json", score_args, overwrite_output_dir)
+        self._save_arguments(out / "factor_arguments.json", factor_args, overwrite_output_dir)
         loaded = self.load_all_factors(factors_name)
         params = (dataloader_kwargs or self._dataloader_params).to_dict()
         train_batch = per_device_train_batch_size

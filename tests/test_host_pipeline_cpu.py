@@ -378,3 +378,33 @@ def test_missing_results_raise_what_the_reference_raises(tmp_path, cpu_engine):
     analyzer.fit_covariance_matrices("partial", train, per_device_batch_size=4, factor_args=FactorArguments(use_empirical_fisher=True))
     with pytest.raises(FactorsNotFoundError, match="Eigendecomposition"):
         analyzer.load_all_factors("partial")                      # ekfac needs eigenvectors and Lambda too
+
+
+def test_borrowed_factors_and_score_directories_have_the_references_files(tmp_path, cpu_engine):
+    """File layout compared with the reference side by side in the build container: ``load_from_factors_name`` makes the borrowed
+    covariances / eigendecomposition part of the new name (files + ``factor_loaded_*_arguments.json``), and a scores directory
+    records the factor arguments it was computed with next to its score arguments."""
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, prepare_model
+    from test_pipeline_gpu import make_task
+
+    kind = "mlp"
+    task = make_task(kind)
+    analyzer = Analyzer("t", prepare_model(fx.make_model(kind), task), task, output_dir=str(tmp_path), disable_tqdm=True)
+    train = data.TensorDataset(*fx.make_data(kind, 20, seed=1))
+    query = data.TensorDataset(*fx.make_data(kind, 4, seed=2))
+    fargs = FactorArguments(use_empirical_fisher=True)
+    analyzer.fit_all_factors("f", train, per_device_batch_size=4, factor_args=fargs)
+    analyzer.perform_eigendecomposition("g", factor_args=fargs, load_from_factors_name="f")
+    analyzer.fit_lambda_matrices("h", train, per_device_batch_size=4, factor_args=fargs, load_from_factors_name="g")
+    g, h = set(os.listdir(analyzer.factors_output_dir("g"))), set(os.listdir(analyzer.factors_output_dir("h")))
+    assert {"activation_covariance.safetensors", "gradient_covariance.safetensors", "factor_loaded_covariance_arguments.json",
+            "activation_eigenvectors.safetensors", "factor_arguments.json"} <= g
+    assert {"activation_eigenvectors.safetensors", "gradient_eigenvalues.safetensors", "factor_loaded_eigendecomposition_arguments.json",
+            "lambda_matrix.safetensors"} <= h
+    want, got = analyzer.load_covariance_matrices("f"), analyzer.load_covariance_matrices("g")
+    assert all(torch.equal(got[k][m], want[k][m]) for k in want for m in want[k])
+    assert all(torch.equal(analyzer.load_lambda_matrices("h")[k][m], v) for k, d in analyzer.load_lambda_matrices("f").items() for m, v in d.items())
+    analyzer.compute_pairwise_scores("s", "h", query, train, per_device_query_batch_size=2, per_device_train_batch_size=4)
+    assert {"score_arguments.json", "factor_arguments.json", "pairwise_scores.safetensors"} <= set(os.listdir(analyzer.scores_output_dir("s")))
