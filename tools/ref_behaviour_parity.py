@@ -6,7 +6,9 @@
 Part 1: invalid or premature calls (scores before factors, Lambda before the eigendecomposition, too many partitions, unknown
 names, invalid arguments ...): does each side return or raise, and which exception class.  Part 2: multi-call flows (refit with
 other arguments, overwrite, another dataset, ``load_from_factors_name``, partial partitions, partitioned self scores): outcome AND
-the set of files each side leaves in its output directory.  A line ends in ``<--`` where the two differ.  Return-value
+the set of files each side leaves in its output directory.  Part 3: interchange -- this engine scores from factor directories the
+reference wrote and the reference from directories this engine wrote (partitioned fits, three strategies, three fixtures), the
+argument JSON files are compared key by key.  A line ends in ``<--`` where the two differ.  Return-value
 differences of ``compute_*`` (the reference returns None and stores; this engine also returns what it stored) are expected.
 """
 import os
@@ -154,9 +156,63 @@ def part_flows():
 
 
 
+def analyzer(pkg, ours, d, kind):
+    task=f.make_task(pkg,kind)
+    model=pkg.prepare_model(fx.make_model(kind).double(),task)
+    kw=dict(disable_tqdm=True,output_dir=d)
+    if not ours: kw["cpu"]=True
+    else:
+        from kronfluence_amd.utils.state import State
+        State._reset_state()
+    return pkg.Analyzer("x",model,task,**kw)
+
+def part_interchange():
+    import json
+    import shutil
+    for kind in ("mlp","conv","seq"):
+      for strategy in ("ekfac","kfac","diagonal"):
+        train=data.TensorDataset(*fx.make_data(kind,20,seed=1)); query=data.TensorDataset(*fx.make_data(kind,4,seed=2))
+        f64=torch.float64
+        def fa(pkg): return pkg.FactorArguments(strategy=strategy,use_empirical_fisher=True,covariance_data_partitions=2,lambda_module_partitions=2,activation_covariance_dtype=f64,gradient_covariance_dtype=f64,per_sample_gradient_dtype=f64,lambda_dtype=f64)
+        def sa(pkg): return pkg.ScoreArguments(damping_factor=1e-3,per_sample_gradient_dtype=f64,precondition_dtype=f64,score_dtype=f64)
+        with tempfile.TemporaryDirectory() as dr, tempfile.TemporaryDirectory() as do:
+            ar=analyzer(f.ref_pkg,False,dr,kind); ar.fit_all_factors("f",train,per_device_batch_size=4,factor_args=fa(f.ref_pkg))
+            ao=analyzer(f.our_pkg,True,do,kind); ao.fit_all_factors("f",train,per_device_batch_size=4,factor_args=fa(f.our_pkg))
+            # JSON contents
+            for name in sorted(os.listdir(os.path.join(dr,"x","factors_f"))):
+                if name.endswith(".json"):
+                    a=json.load(open(os.path.join(dr,"x","factors_f",name))); b=json.load(open(os.path.join(do,"x","factors_f",name)))
+                    if a!=b:
+                        diff={k:(a.get(k),b.get(k)) for k in set(a)|set(b) if a.get(k)!=b.get(k)}
+                        print(f"  {kind} {strategy} {name}: JSON differs: {diff}")
+            # reference scores from reference factors
+            ar.compute_pairwise_scores("s","f",query,train,per_device_query_batch_size=2,per_device_train_batch_size=4,score_args=sa(f.ref_pkg))
+            want=ar.load_pairwise_scores("s")["all_modules"].double()
+            # cross: our engine on the reference's factor files, the reference on ours
+            shutil.copytree(os.path.join(dr,"x","factors_f"), os.path.join(do,"x","factors_fromref"))
+            shutil.copytree(os.path.join(do,"x","factors_f"), os.path.join(dr,"x","factors_fromours"))
+            try:
+                ao.compute_pairwise_scores("s2","fromref",query,train,per_device_query_batch_size=2,per_device_train_batch_size=4,score_args=sa(f.our_pkg))
+                e1=float((ao.load_pairwise_scores("s2")["all_modules"].double()-want).norm()/want.norm())
+            except Exception as ex: e1=f"{type(ex).__name__}: {str(ex)[:120]}"
+            try:
+                ar.compute_pairwise_scores("s3","fromours",query,train,per_device_query_batch_size=2,per_device_train_batch_size=4,score_args=sa(f.ref_pkg))
+                e2=float((ar.load_pairwise_scores("s3")["all_modules"].double()-want).norm()/want.norm())
+            except Exception as ex: e2=f"{type(ex).__name__}: {str(ex)[:120]}"
+            # score file metadata + reading each other's score files
+            try:
+                so=f.our_pkg.Analyzer.load_file(os.path.join(dr,"x","scores_s","pairwise_scores.safetensors"))
+                e3=float((so["all_modules"].double()-want).norm()/want.norm())
+            except Exception as ex: e3=f"{type(ex).__name__}: {str(ex)[:120]}"
+            print(f"{kind:4s} {strategy:8s} ours on the reference's factors: {e1} | the reference on ours: {e2} | our load_file on its scores: {e3}")
+
+
+
 if __name__ == "__main__":
     f.cpu_engine.install(f._Patch())
     print("== part 1: invalid or premature calls")
     part_errors()
     print("== part 2: flows and the files they leave")
     part_flows()
+    print("== part 3: each engine on the other's factor files (partitioned fits), argument JSON contents, score files")
+    part_interchange()
