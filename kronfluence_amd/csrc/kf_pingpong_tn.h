@@ -1,38 +1,34 @@
-// kf_pingpong_tn.h -- PREPARED FOR ROUND 5, NOT PART OF THE LIBRARY, never run on a GPU (tools/next/README.md).
+// kf_pingpong_tn.h -- the 256 x 256 x 64 wave-role-split main loop of kf_pingpong.h (request schedule ISSUE = 1) for K-MAJOR
+// operands (round 5): both operands are X[k][row] -- the contraction index is the slow axis, as in the hooked [t][feature] rows of
+// a Linear layer on sequences -- and C[m][n] += sum_k A[k][m] B[k][n].  The K-contiguous loop needs two transposed copies of the
+// hooked tensors per call (transpose_rows_kernel: 22 % of a GPT-2 score call, 0.8 of the 3.0 GB it moves); this one reads them
+// where autograd left them.
 //
-// The 256 x 256 x 64 wave-role-split main loop of kronfluence_amd/csrc/kf_pingpong.h (request schedule ISSUE = 1) for K-MAJOR
-// operands: both operands are given as X[k][row] (the contraction index is the slow axis: the hooked [t][feature] rows of a
-// sequence layer), C[m][n] += sum_k A[k][m] B[k][n].  Phases, barriers, the four pieces per k-tile, their liveness, the counted
-// waits and the ordering argument are those of kf_pingpong.h (tools/pp_schedule_check.py); what differs is
+// Phases, barriers, the four pieces per k-tile, their liveness, the request schedule, the counted waits and the RAW / WAR argument
+// are those of kf_pingpong.h, ISSUE = 1 (tools/pp_schedule_check.py models them; nothing about WHEN a piece is written or read
+// changes).  What differs is WHERE the bytes of a piece sit and how a fragment is read:
 //
-//   the LDS image   a 16 KB piece = 128 rows (features) x 64 k as 64 rows of 256 bytes, one per k: exactly what an LDS-DMA
-//                   request writes lane-linearly when its 64 lanes fetch 4 k x 256 contiguous bytes (fully coalesced).  The
-//                   64-byte quarter q of the row of k sits at quarter q ^ (k & 3):
-//                       piece + k * 256 + (((f >> 5) ^ (k & 3)) * 64) + (f & 31) * 2            f = piece-local row 0..127
-//                   so that the four k rows one 32-lane half of a transposing read touches fall into the four bank quarters.
-//   the fragments   ds_read_b64_tr_b16 (ASSUMED semantics, to be confirmed by tools/next/tr_probe.py: within a 16-lane group
-//                   lane l receives element l & 3 of the 64-bit words addressed by lanes (l >> 2) + 4 j, j = 0..3): lane s of
-//                   group g addresses (k = kk * 16 + 8 (g >> 1) + 4 quad + (s >> 2), f = f0 + 16 (g & 1) + 4 (s & 3)); two reads
-//                   (quad 0, 1) give the lane the 8 consecutive k of row f0 + (lane & 31) that v_mfma_f32_32x32x16_bf16 wants.
+//   the LDS image   keeps 16-byte global chunks (8 rows of one k) whole: kf_tn_map.h, three candidate images (template IMG);
+//                   a request is still 64 lanes x 16 bytes written lane-linearly, 16 requests per 16 KB piece, wave w issues
+//                   requests w and w + 8 of every piece (8 per wave and k-tile, as before);
+//   the fragments   two ds_read_b64_tr_b16 per bf16x8 operand fragment (32 / 16 LDS instructions in the two L segments instead
+//                   of 16 / 8, the same LDS-array time: 2 cycles per 8-byte read against 4 per 16-byte read).
 //
-// Pieces (piece-local row fl of tile row f):   A0: rows of blocks i = 0, 1 of both wave rows, fl = (f >> 7) * 64 + (f & 63), f & 64 == 0
-//                                              A1: blocks i = 2, 3, same fl, f & 64 != 0        B0: f < 128, fl = f        B1: fl = f - 128
-// Requests: a piece is 16 requests of 4 k rows; wave w issues requests w and w + 8 of every piece (8 per k-tile, as before).
-// Lane j of request q fetches k = 4 q + (j >> 4) and the 16-byte chunk whose image position is j & 15 in that row: logical
-// quarter ((j & 15) >> 2) ^ (k & 3), chunk j & 3 of it, i.e. fl = that quarter * 32 + (j & 3) * 8.
+// The transposing read returns the 8-byte-aligned word's data whatever the low address bits (cdna_hip_programming.md G17): the
+// piece base must be 16-byte aligned -- the kernels carve their dynamic LDS from offset 0 and have no static __shared__.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "../../kronfluence_amd/csrc/kf_engine.h"
-#include "../../kronfluence_amd/csrc/kf_pingpong.h"
+#include "kf_engine.h"
+#include "kf_pingpong.h"
 #include "kf_tn_map.h"
 
 namespace kf {
 namespace pptn {
 
-using pp::bf16x8;
 using pp::barrier;
+using pp::bf16x8;
 using pp::glds16;
 using pp::wait_lds_reads;
 using pp::wait_vmcnt;
@@ -44,59 +40,92 @@ constexpr int SMEM_BYTES = 2 * STAGE_BYTES;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 
+__device__ __forceinline__ uint32_t lds_address(const void* p) {
+    return static_cast<uint32_t>(reinterpret_cast<uintptr_t>((__attribute__((address_space(3))) const void*)p));
+}
+
+// One transposing read.  Inline asm, not __builtin_amdgcn_ds_read_tr16_b64_*: hipcc (ROCm 7.2) puts an s_waitcnt vmcnt(0) in
+// front of the builtin whenever an LDS-DMA request is in flight (it carries no memory operand the waitcnt pass could tell apart
+// from the DMA's destination) -- which would drain the pipeline the counted waits keep full.  The compiler does not count an asm
+// load: every L segment ends with wait_lds_reads() + barrier() (a sched_barrier) before the first MFMA that consumes a fragment
+// (cdna_hip_programming.md section 5.7, form iii).
+template <int OFFSET>
+__device__ __forceinline__ s16x4 read_tr(uint32_t lds_byte_address) {
+    static_assert(OFFSET >= 0 && OFFSET < 65536 && OFFSET % 8 == 0, "16-bit offset field, 8-byte aligned words");
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_address), "n"(OFFSET));
+    return v;
+}
+
+// the lane's bf16x8 operand fragment of k-slab KK: k-quads 0 and 1
+template <int IMG, int KK>
+__device__ __forceinline__ bf16x8 fragment(uint32_t base) {
+    union { s16x4 h[2]; bf16x8 v; } u;
+    u.h[0] = read_tr<tnmap::word_step<IMG>(KK, 0)>(base);
+    u.h[1] = read_tr<tnmap::word_step<IMG>(KK, 1)>(base);
+    return u.v;
+}
+
 // per-lane DMA sources for k-tile 0: p[2 piece + h] = request w + 8 h of the piece
 struct Sources {
     const uint16_t* p[8];
 };
 
-// row_a(f) / row_b(f): address of (k = 0, tile row f) of the operand; ld_a / ld_b: elements between consecutive k.  Rows are
-// fetched in chunks of 8: the functors get the chunk's first row (a multiple of 8) and clamp it themselves.
-template <class RowA, class RowB>
+// row_a(f) / row_b(f): address of (k = 0, tile row f) of the operand for the FIRST of a chunk of 8 rows (f % 8 == 0; the functor
+// clamps a chunk that starts beyond the operand itself); ld_a / ld_b: elements between consecutive k.
+template <int IMG, class RowA, class RowB>
 __device__ __forceinline__ void make_sources(Sources& s, int wave, int lane, RowA row_a, int64_t ld_a, RowB row_b, int64_t ld_b) {
+    using Img = tnmap::Image<IMG>;
 #pragma unroll
     for (int piece = 0; piece < 4; ++piece)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const int k = tnmap::dma_k(wave, h, lane);
-            const int f = tnmap::tile_row(piece, tnmap::dma_row(wave, h, lane));
+            const int q = tnmap::request_of(wave, h);
+            const int k = Img::dma_k(q, lane);
+            const int f = tnmap::tile_row(piece, Img::dma_row(q, lane));
             s.p[2 * piece + h] = piece < 2 ? row_a(f) + k * ld_a : row_b(f) + k * ld_b;
         }
 }
 
-// acc[i][jn] += A^T B over k-tiles [0, nt); walk_a(t) / walk_b(t): element offset of k-tile t (= t * 64 * ld for plain operands).
-template <class WalkA, class WalkB>
+// acc[i][jn] (i = 0..3 row blocks, jn = 0..1 column blocks of the wave's 128 x 64 tile) += A^T B over k-tiles [0, nt).
+// walk_a(t) / walk_b(t): element offset of k-tile t relative to Sources::p (t * 64 * ld for a plain operand).  `wave` must be
+// wave-uniform.  All 512 threads; sm: SMEM_BYTES of LDS at a 16-byte-aligned base.  On return every wave has finished reading LDS.
+template <int IMG, class WalkA, class WalkB>
 __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane,
                                          WalkA walk_a, WalkB walk_b) {
     const int wm = wave >> 2, wn = wave & 3;
-    const unsigned char* piece_b = sm + tnmap::b_piece(wn) * PIECE_BYTES;
 
     auto issue_at = [&](int piece, int t, int64_t off) {
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-            glds16(src.p[2 * piece + h] + off, sm + (t & 1) * STAGE_BYTES + piece * PIECE_BYTES + tnmap::dma_base(wave, h));
+            glds16(src.p[2 * piece + h] + off,
+                   sm + (t & 1) * STAGE_BYTES + piece * PIECE_BYTES + tnmap::request_of(wave, h) * tnmap::REQUEST_BYTES);
     };
     auto issue_piece = [&](int piece, int t) { issue_at(piece, t, piece < 2 ? walk_a(t) : walk_b(t)); };
 
+    // per-lane LDS byte addresses of the words of k-slab 0, quad 0 for this wave's blocks in stage 0; k-slab kk / quad add a
+    // compile-time constant (tnmap::word_step: folded into the instruction's offset field), stage 1 adds STAGE_BYTES
+    const uint32_t sm_lds = lds_address(sm);
+    uint32_t wa[4], wb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wa[i] = sm_lds + tnmap::a_piece(i) * PIECE_BYTES + tnmap::word<IMG>(tnmap::a_row(wm, i), 0, 0, lane);
+#pragma unroll
+    for (int jn = 0; jn < 2; ++jn) wb[jn] = sm_lds + tnmap::b_piece(wn) * PIECE_BYTES + tnmap::word<IMG>(tnmap::b_row(wn, jn), 0, 0, lane);
+
     bf16x8 a[2][4], b[2][4];
-    auto read_tr = [&](const unsigned char* piece, int fl0, int kk) -> bf16x8 {
-        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(piece + tnmap::word(fl0, kk, 0, lane)));
-        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(piece + tnmap::word(fl0, kk, 1, lane)));
-        union { s16x4 h[2]; bf16x8 v; } u;
-        u.h[0] = lo; u.h[1] = hi;
-        return u.v;
-    };
     auto read_a = [&](int half, int buf) {   // half 0: blocks 0, 1 (piece A0), half 1: blocks 2, 3 (piece A1)
-        const unsigned char* piece = sm + buf * STAGE_BYTES + tnmap::a_piece(2 * half) * PIECE_BYTES;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) a[i][kk] = read_tr(piece, tnmap::a_row(wm, 2 * half + i), kk);
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t base = wa[2 * half + i] + buf * STAGE_BYTES;
+            a[i][0] = fragment<IMG, 0>(base); a[i][1] = fragment<IMG, 1>(base); a[i][2] = fragment<IMG, 2>(base); a[i][3] = fragment<IMG, 3>(base);
+        }
     };
     auto read_b = [&](int buf) {
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) b[jn][kk] = read_tr(piece_b + buf * STAGE_BYTES, tnmap::b_row(wn, jn), kk);
+        for (int jn = 0; jn < 2; ++jn) {
+            const uint32_t base = wb[jn] + buf * STAGE_BYTES;
+            b[jn][0] = fragment<IMG, 0>(base); b[jn][1] = fragment<IMG, 1>(base); b[jn][2] = fragment<IMG, 2>(base); b[jn][3] = fragment<IMG, 3>(base);
+        }
     };
 #define KF_TN_GROUP(HALF, KK)                                                                                          \
     _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                      \
@@ -111,12 +140,14 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
         }
     };
 
+    // prologue: k-tile 0 complete, A0 / B0 / B1 of k-tile 1 on their way
     issue_piece(0, 0); issue_piece(2, 0); issue_piece(3, 0); issue_piece(1, 0);
-    if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); issue_piece(3, 1); wait_vmcnt<8>(); }
+    if (nt > 1) { issue_piece(0, 1); issue_piece(2, 1); issue_piece(3, 1); wait_vmcnt<8>(); }   // in flight: A1(0), A0 B0 B1(1)
     else wait_vmcnt<2>();
     barrier();
-    if (wm == 1) barrier();
+    if (wm == 1) barrier();   // Y runs half a phase behind X from here on (wave-uniform branch)
 
+    // one k-tile = L(2t) M(2t) L(2t+1) M(2t+1); M(2t) carries A1(t+1), M(2t+1) A0, B0, B1 of t+2 (kf_pingpong.h, ISSUE = 1)
 #define KF_TN_TILE(T, MORE1, MORE2)                                                                                    \
     do {                                                                                                               \
         const int t_ = (T), buf_ = t_ & 1;                                                                             \
@@ -124,7 +155,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
         if (MORE1) oa_ = walk_a(t_ + 1);                                                                               \
         read_a(0, buf_);                                                                                               \
         read_b(buf_);                                                                                                  \
-        if (MORE1) wait_vmcnt<6>();                                                                                    \
+        if (MORE1) wait_vmcnt<6>();   /* A1(t) landed; in flight: A0, B0, B1 of t+1 */                                 \
         else wait_vmcnt<0>();                                                                                          \
         wait_lds_reads();                                                                                              \
         barrier();                                                                                                     \
@@ -138,7 +169,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
         barrier();                                                                                                     \
         if (MORE2) { oa_ = walk_a(t_ + 2); ob_ = walk_b(t_ + 2); }                                                     \
         read_a(1, buf_);                                                                                               \
-        if (MORE1) wait_vmcnt<2>();                                                                                    \
+        if (MORE1) wait_vmcnt<2>();   /* A0, B0, B1 of t+1 landed; in flight: A1(t+1) */                               \
         wait_lds_reads();                                                                                              \
         barrier();                                                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
@@ -157,7 +188,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
     for (; t + 2 < nt; ++t) KF_TN_TILE(t, true, true);
     if (t + 1 < nt) { KF_TN_TILE(t, true, false); ++t; }
     KF_TN_TILE(t, false, false);
-    if (wm == 0) barrier();
+    if (wm == 0) barrier();   // X waits for Y's last segment: barrier counts match, all LDS reads are done
 #undef KF_TN_TILE
 #undef KF_TN_GROUP
 }

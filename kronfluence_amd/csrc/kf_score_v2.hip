@@ -35,6 +35,7 @@
 #include "kf_engine.h"
 #include "kf_pingpong.h"
 #include "kf_pingpong64.h"
+#include "kf_pingpong_tn.h"
 
 using namespace kf;
 
@@ -83,6 +84,7 @@ struct ScoreV2Args {
     float* C; int64_t ldc;
     const uint16_t* A; const uint16_t* B;
     int M, N, KT;                          // KT = K / 64
+    int a_rows;                            // rows of a k-tile of A in memory (>= M: a launch may cover a row range of P)
     int tiles_m, tiles_n, ksplit, kchunk;  // kchunk in k-tiles
     float alpha;
 };
@@ -121,7 +123,7 @@ __global__ __launch_bounds__(SV2_THREADS) void score_gemm_v2_kernel(ScoreV2Args 
         const int row = (wave * GB + t) * 8 + (lane >> 3);
         off_b[t] = min(n0 + row, a.N - 1) * 64 + ((lane & 7) ^ lds_swz(row)) * 8;
     }
-    const int64_t a_kt = static_cast<int64_t>(a.M) * 64, b_kt = static_cast<int64_t>(a.N) * 64;
+    const int64_t a_kt = static_cast<int64_t>(a.a_rows) * 64, b_kt = static_cast<int64_t>(a.N) * 64;
     // part `part` (0..3) of the DMA requests of one stage: 1/4 of this wave's row groups of A and of B.  The requests of
     // the NEXT k-step are spread over the four MFMA groups of the current one -- issuing all of them up front keeps every
     // wave of the CU in its (50-150 cycles per request) issue phase at the same time, with the matrix pipes idle.
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(pp::THREADS) void score_gemm_v3_kernel(ScoreV2Args 
     if (kt_begin >= kt_end) return;
 
     pp::Sources src;
-    const int64_t kt_a = static_cast<int64_t>(a.M) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
+    const int64_t kt_a = static_cast<int64_t>(a.a_rows) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
     const uint16_t* abase = a.A + kt_begin * kt_a;
     const uint16_t* bbase = a.B + kt_begin * kt_b;
     pp::make_sources(src, wave, lane,
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(pp64::THREADS) void score_gemm_v4_kernel(ScoreV2Arg
     if (kt_begin >= kt_end) return;
 
     pp64::Sources<TA, TB> src;
-    const int64_t kt_a = static_cast<int64_t>(a.M) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
+    const int64_t kt_a = static_cast<int64_t>(a.a_rows) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
     const uint16_t* abase = a.A + kt_begin * kt_a;
     const uint16_t* bbase = a.B + kt_begin * kt_b;
     pp64::make_sources<TA, TB>(src, wave, lane,
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(pp::THREADS) void score_gemm_v5_kernel(ScoreV2Args 
     if (kt_begin >= kt_end) return;
 
     ppw::Sources<WM, WN> src;
-    const int64_t kt_a = static_cast<int64_t>(a.M) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
+    const int64_t kt_a = static_cast<int64_t>(a.a_rows) * 64, kt_b = static_cast<int64_t>(a.N) * 64;
     const uint16_t* abase = a.A + kt_begin * kt_a;
     const uint16_t* bbase = a.B + kt_begin * kt_b;
     ppw::make_sources<WM, WN>(src, wave, lane,
@@ -632,13 +634,15 @@ inline bool wide_tile_enabled() { const char* e = getenv("KF_WIDE_TILE"); return
 // MFMA groups of the M segments, 2 = as 1 with A0 left in the short L segment.  KF_PP_ISSUE overrides (read per call: A/B
 // measurements in one process, race screens on every schedule).
 constexpr int PP_ISSUE_DEFAULT = 1;
-inline int pp_issue() {
+inline int pp_issue(int preferred) {
     const char* e = getenv("KF_PP_ISSUE");
-    return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : PP_ISSUE_DEFAULT;
+    return (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : preferred;
 }
+// `preferred`: the schedule measured fastest for the calling kernel (profiles/r04_issue_ab_kernel_stats.csv: 2 for the covariance
+// kernel, whose L segments also carry the offset-table read; 1 for the others)
 template <class F>
-inline void with_pp_issue(F&& launch) {
-    switch (pp_issue()) {
+inline void with_pp_issue(F&& launch, int preferred = PP_ISSUE_DEFAULT) {
+    switch (pp_issue(preferred)) {
     case 0: launch(std::integral_constant<int, 0>{}); break;
     case 2: launch(std::integral_constant<int, 2>{}); break;
     default: launch(std::integral_constant<int, 1>{}); break;
@@ -648,6 +652,25 @@ inline void with_pp_issue(F&& launch) {
 inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A/B measurements, fallback)
     const char* e = getenv("KF_ENGINE");
     return (e && atoi(e) == 2) ? 2 : 3;
+}
+
+// Round 5: sequence layers on the K-major loop (kf_pingpong_tn.h) -- no transposed copies of the hooked tensors.  KF_TN=0 switches
+// back to transpose_rows + the K-contiguous kernels (A/B measurements, fallback); KF_TN_IMG = 0 / 1 / 2 picks the LDS image
+// (kf_tn_map.h; read per call).
+constexpr int TN_IMAGE_DEFAULT = 2;
+inline bool tn_enabled() {
+    const char* e = getenv("KF_TN");
+    return engine_generation() == 3 && !(e && e[0] == '0' && e[1] == 0);
+}
+template <class F>
+inline void with_tn_image(F&& launch) {
+    const char* e = getenv("KF_TN_IMG");
+    const int image = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : TN_IMAGE_DEFAULT;
+    switch (image) {
+    case 0: launch(std::integral_constant<int, 0>{}); break;
+    case 1: launch(std::integral_constant<int, 1>{}); break;
+    default: launch(std::integral_constant<int, 2>{}); break;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1108,6 +1131,118 @@ __global__ __launch_bounds__(pp::THREADS) void psg_gemm_pp_kernel(PsgPpArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Round 5: the same per-sample gradients straight from the HOOKED tensors.  G[n] is [T][O] and A[n] is [T][I] in memory -- the
+// contraction index t is the slow axis of both -- so the K-contiguous kernels above needed two transposed copies per call
+// (transpose_rows_kernel: 22 % of a GPT-2 score call).  Here the 256 x 256 loop runs on K-major operands (kf_pingpong_tn.h:
+// [t][feature] LDS images, ds_read_b64_tr_b16 fragments) and the two train micro-batches of a pair are two base pointers, not a
+// copy.  Covers the real input columns [0, I) (I, O % 256 == 0); the bias column and the padding of the augmented axis come from
+// psg_bias_cols_kernel below.  Work items, operand roles (tile rows = i, tile columns = o) and the epilogue are those of
+// psg_gemm_pp_kernel.
+// ------------------------------------------------------------------------------------------------
+struct PsgTnArgs {
+    uint16_t* out; int64_t out_tile_stride;
+    const uint16_t* G[2]; const uint16_t* A[2];   // segment s: samples [s ? b0 : 0, ...), G[s]: [.][T][O], A[s]: [.][T][I]
+    int b0;
+    int O, I, Ip, KT, batch, tiles_m, tiles_n;    // tiles_m = O / 256, tiles_n = I / 256
+};
+
+template <int IMG>
+__global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_kernel(PsgTnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int tiles = a.tiles_m * a.tiles_n;
+    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+    if (j >= per_xcd || item >= items) return;
+    const int z = static_cast<int>(item / tiles), tile = static_cast<int>(item - static_cast<int64_t>(z) * tiles);
+    const int tn = tile / a.tiles_m, tm = tile - tn * a.tiles_m;
+    const int i0 = tn * 256, m0 = tm * 256;   // tile rows: i0 .. (activation columns), tile columns: m0 .. (output-gradient columns)
+    const int seg = z >= a.b0, zs = z - (seg ? a.b0 : 0);
+    const int64_t T = static_cast<int64_t>(a.KT) * 64;
+    const uint16_t* rows_i = a.A[seg] + zs * T * a.I + i0;
+    const uint16_t* rows_m = a.G[seg] + zs * T * a.O + m0;
+
+    pptn::Sources src;
+    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return rows_i + f; }, static_cast<int64_t>(a.I),
+                            [&](int f) { return rows_m + f; }, static_cast<int64_t>(a.O));
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    const int64_t step_a = static_cast<int64_t>(a.I) * 64, step_b = static_cast<int64_t>(a.O) * 64;
+    pptn::mainloop<IMG>(acc, sm, src, a.KT, wave, lane, [&](int t) { return t * step_a; }, [&](int t) { return t * step_b; });
+    __syncthreads();   // every wave is done with the stage buffers: the epilogue reuses them
+    const int hi = lane >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn) {
+            const int ml = wn * 64 + jn * 32 + (lane & 31);
+            unsigned char* dst = sm + ml * 512 + hi * 8;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {   // registers 4 q .. 4 q + 3: tile rows i = wm * 128 + i * 32 + 8 q + 4 hi + (0 .. 3)
+                const int c = wm * 16 + i * 4 + q;
+                uint2 w;
+                w.x = pack_bf16x2(acc[i][jn][4 * q], acc[i][jn][4 * q + 1]);
+                w.y = pack_bf16x2(acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]);
+                *reinterpret_cast<uint2*>(dst + ((c ^ (ml & 31)) << 4)) = w;
+            }
+        }
+    __syncthreads();
+    // 512 threads = 16 result rows x 32 chunks per pass; 16 rows further d = o Ip + i grows by 16 Ip, a multiple of 64
+    const int er = tid >> 5, ech = tid & 31, n = i0 + ech * 8;
+    const int64_t d = static_cast<int64_t>(m0 + er) * a.Ip + n;
+    uint16_t* dst = a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63);
+    const int64_t step = static_cast<int64_t>(a.Ip >> 2) * a.out_tile_stride;
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int ml = er + 16 * it;
+        *reinterpret_cast<u32x4*>(dst + it * step) = *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ech ^ (ml & 31)) << 4));
+    }
+}
+
+// Columns [I, Ip) of the per-sample gradients of the kernel above: psg[n][o][I] = sum_t G[n][t][o] (the gradient with respect to
+// the bias: the ones column of A', module/linear.py:30-46) when `ones`, zeros after it (the padding of the augmented axis to a
+// multiple of 8).  One workgroup per (256 output columns, sample); the four waves take every fourth t.
+struct PsgBiasArgs {
+    uint16_t* out; int64_t out_tile_stride;
+    const uint16_t* G[2]; int b0;
+    int O, I, Ip, T, ones;
+};
+
+__global__ __launch_bounds__(256) void psg_bias_cols_kernel(PsgBiasArgs a) {
+    __shared__ float part[4][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int z = blockIdx.y, o0 = blockIdx.x * 256 + lane * 4;
+    const int seg = z >= a.b0, zs = z - (seg ? a.b0 : 0);
+    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (a.ones && o0 < a.O) {   // O % 8 == 0: four columns are entirely in or out
+        const uint16_t* g = a.G[seg] + static_cast<int64_t>(zs) * a.T * a.O + o0;
+        for (int t = wave; t < a.T; t += 4) {
+            const uint2 w = *reinterpret_cast<const uint2*>(g + static_cast<int64_t>(t) * a.O);
+            s[0] += __uint_as_float(w.x << 16); s[1] += __uint_as_float(w.x & 0xffff0000u);
+            s[2] += __uint_as_float(w.y << 16); s[3] += __uint_as_float(w.y & 0xffff0000u);
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) part[wave][lane * 4 + e] = s[e];
+    __syncthreads();
+    const int o = blockIdx.x * 256 + tid;
+    if (o >= a.O) return;
+    const float sum = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+    for (int c = a.I; c < a.Ip; c += 8) {   // I, Ip % 8 == 0: 16-byte chunks of the k-tile-major gradient buffer
+        const int64_t d = static_cast<int64_t>(o) * a.Ip + c;
+        u32x4 w = {0u, 0u, 0u, 0u};
+        if (c == a.I && a.ones) w[0] = pack_bf16x2(sum, 0.0f);
+        *reinterpret_cast<u32x4*>(a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63)) = w;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Zero-padded, column-phase-split copy of a convolution input for the implicit im2col above:
 //   Xs[phase][n][c][y][j] = x_pad[n][c][y][s2 * j + phase],  x_pad = x with p1 / p2 zero borders,
 //   y < Hp, j < Wq.  One 16-byte store (8 columns) per thread.
@@ -1415,6 +1550,76 @@ __global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
             }
 }
 
+// Round 5: the covariance of UNMASKED sequence rows straight from the hooked tensor.  X is [rows][d] in memory (rows = all tokens
+// of the batch, the contraction index), i.e. K-major: C += X^T X on the K-major loop of kf_pingpong_tn.h -- no transposed copy
+// (kf_syrk_rows_bf16 used to write and re-read one per call).  Work items = (k-tile range, upper-triangular 256-row tile pair),
+// range major per XCD as above; same staging matrix, same finalize pass.  The bias row / column of an activation covariance
+// (the ones column of A') is a column sum: colsum_accum_kernel.
+struct CovTnArgs {
+    float* stage; int np;
+    const uint16_t* X; int64_t ld;   // [KT * 64][ld], columns [0, N) are used
+    int N, KT, tiles, kchunk, kblocks, plain_store;
+};
+
+template <int IMG>
+__global__ __launch_bounds__(pptn::THREADS) void cov_gemm_tn_kernel(CovTnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int pairs = a.tiles * (a.tiles + 1) / 2;
+    const int64_t items = static_cast<int64_t>(a.kblocks) * pairs, per_xcd = (items + 7) / 8;
+    const int L = blockIdx.x, xcd = L & 7, jx = L >> 3;
+    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + jx;
+    if (jx >= per_xcd || item >= items) return;
+    const int kb = static_cast<int>(item / pairs);
+    int t = static_cast<int>(item % pairs), ti = 0;
+    while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
+    const int tj = ti + t;
+    const int m0 = ti * 256, n0 = tj * 256;
+    const int kt_begin = kb * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
+    if (kt_begin >= kt_end) return;
+
+    const uint16_t* base = a.X + static_cast<int64_t>(kt_begin) * 64 * a.ld;
+    pptn::Sources src;
+    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return base + min(m0 + f, a.N - 8); }, a.ld,
+                            [&](int f) { return base + min(n0 + f, a.N - 8); }, a.ld);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    const int64_t step = a.ld * 64;
+    pptn::mainloop<IMG>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int kt) { return kt * step; }, [&](int kt) { return kt * step; });
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = wn * 64 + jn * 32 + (lane & 31);
+                float* dst = a.stage + static_cast<int64_t>(m0 + ml) * a.np + n0 + nl;
+                if (a.plain_store) *dst = acc[i][jn][r];
+                else atomicAdd(dst, acc[i][jn][r]);
+            }
+}
+
+// C[d][j] += alpha * sum_r X[r][j], C[j][d] += the same, C[d][d] += alpha * rows: row / column d of the covariance of [X, 1].
+// grid (ceil(d / 256), row blocks); a block sums `rows_per_block` rows of 256 columns.
+__global__ __launch_bounds__(256) void colsum_accum_kernel(float* C, int64_t ldc, const uint16_t* X, int64_t ld, int64_t rows, int d,
+                                                           int rows_per_block, float alpha) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
+    if (j < d) {
+        float s = 0.0f;
+#pragma unroll 8
+        for (int64_t r = r0; r < r1; ++r) s += __uint_as_float(static_cast<uint32_t>(X[r * ld + j]) << 16);
+        atomicAdd(C + static_cast<int64_t>(d) * ldc + j, alpha * s);
+        atomicAdd(C + static_cast<int64_t>(j) * ldc + d, alpha * s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(C + static_cast<int64_t>(d) * ldc + d, alpha * static_cast<float>(r1 - r0));
+}
+
 // covariance[i][j] += alpha * stage[p(i)][p(j)] (or its transpose: only tile pairs ti <= tj are computed); p = operand row of
 // covariance index i: identity for plain rows, (i % taps) * Cp + i / taps for the (c, ky, kx) patch order of a convolution.
 struct CovFinalizeArgs {
@@ -1468,7 +1673,7 @@ int launch_cov_v3(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     c.plain_store = zblocks == 1;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(zblocks * pairs, 8)));
     if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
-    with_pp_issue([&](auto iss) { hipLaunchKernelGGL((cov_gemm_v3_kernel<decltype(iss)::value>), grid, dim3(pp::THREADS), COV_V3_SMEM, st, c); });
+    with_pp_issue([&](auto iss) { hipLaunchKernelGGL((cov_gemm_v3_kernel<decltype(iss)::value>), grid, dim3(pp::THREADS), COV_V3_SMEM, st, c); }, 2);
     f.stage = c.stage; f.np = c.np; f.tile_shift = 8;
     hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();
@@ -1498,6 +1703,33 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
     if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
     hipLaunchKernelGGL(cov_gemm_v2_kernel, grid, dim3(NTHREADS), PV2_SMEM, st, c);
     f.stage = c.stage; f.np = c.np; f.tile_shift = 7;
+    hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
+    return launch_status();
+}
+
+// covariance of unmasked K-major rows X[rows][ld] (columns [0, N)) on the K-major loop: C[0..N)[0..N) += alpha X^T X
+int launch_cov_tn(float* stage, const uint16_t* X, int64_t ld, int64_t rows, int64_t N, CovFinalizeArgs& f, hipStream_t st) {
+    CovTnArgs c{};
+    c.stage = stage; c.X = X; c.ld = ld; c.N = static_cast<int>(N); c.KT = static_cast<int>(rows / 64);
+    c.tiles = static_cast<int>(cdiv(N, 256));
+    c.np = c.tiles * 256;
+    const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = c.KT;
+    // one workgroup per CU: rounds of 256 items; among 1-4 rounds the cheapest by (k-tiles per item + ~12 for the prologue and
+    // the 64 K staging atomics), as launch_cov_v3 -- the split is over k-tiles here, not samples
+    int64_t kblocks = 1, best = INT64_MAX;
+    c.kchunk = c.KT;
+    for (int rounds = 1; rounds <= 4; ++rounds) {
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>({steps, rounds * 256 / pairs, steps / 16}));
+        const int64_t chunk = cdiv(steps, want), blocks = cdiv(steps, chunk);
+        const int64_t cost = cdiv(blocks * pairs, 256) * (chunk + 12);
+        if (cost < best) { best = cost; kblocks = blocks; c.kchunk = static_cast<int>(chunk); }
+    }
+    c.kblocks = static_cast<int>(kblocks);
+    c.plain_store = kblocks == 1;
+    const dim3 grid(static_cast<unsigned>(8 * cdiv(kblocks * pairs, 8)));
+    if (!c.plain_store && hipMemsetAsync(c.stage, 0, static_cast<size_t>(c.np) * c.np * 4, st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
+    with_tn_image([&](auto img) { hipLaunchKernelGGL((cov_gemm_tn_kernel<decltype(img)::value>), grid, dim3(pptn::THREADS), pptn::SMEM_BYTES, st, c); });
+    f.stage = c.stage; f.np = c.np; f.tile_shift = 8;
     hipLaunchKernelGGL(cov_finalize_kernel, dim3(static_cast<unsigned>(cdiv(f.d, 256)), static_cast<unsigned>(f.d)), dim3(256), 0, st, f);
     return launch_status();
 }
@@ -1539,32 +1771,42 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess;
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, COV_V3_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess;
         if (!ok) status = KF_ERR_LAUNCH_FAILED;
     });
     return status;
 }
 
-int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t* psg, int64_t Q, int64_t b, int64_t D,
-                    float scale, hipStream_t st) {
+// one launch over the query rows [q_begin, q_begin + q_rows) of P (k-tile-major, `Q` rows per k-tile) on tile shape `shape`
+// (-1: chosen by padded area)
+void launch_score_rows(float* scores, int64_t ld, const uint16_t* P, const uint16_t* psg, int64_t Q, int64_t q_begin, int64_t q_rows,
+                       int64_t b, int64_t D, float scale, int shape, hipStream_t st) {
     ScoreV2Args s;
-    s.C = scores; s.ldc = ld; s.A = P; s.B = psg;
-    s.M = static_cast<int>(Q); s.N = static_cast<int>(b); s.KT = static_cast<int>(D / 64);
-    // tile shape: least padded area, the 64 x 64-per-wave shapes charged 15 % for their extra LDS traffic per flop
-    const int64_t area[3] = {cdiv(Q, 256) * 256 * cdiv(b, 256) * 256, cdiv(Q, 256) * 256 * cdiv(b, 128) * 128,
-                             cdiv(Q, 128) * 128 * cdiv(b, 256) * 256};
-    int shape = 0;
-    if (area[1] * 115 < area[shape] * 100) shape = 1;
-    if (area[2] * 115 < (shape == 0 ? area[0] * 100 : area[1] * 115)) shape = 2;
-    // round 4: when a half tile wins, the 512 x 128 / 128 x 512 shapes (two-phase loop, 128 x 64 waves) cover the same narrow
-    // side with fewer DMA requests per MFMA -- taken when they pad no more than the 256-row shape does
-    if (half_tile_engine() == 4 && wide_tile_enabled()) {
-        if (shape == 1 && cdiv(Q, 512) * 512 == cdiv(Q, 256) * 256) shape = 3;
-        else if (shape == 2 && cdiv(b, 512) * 512 == cdiv(b, 256) * 256) shape = 4;
+    s.C = scores + q_begin * ld; s.ldc = ld; s.A = P + q_begin * 64; s.B = psg;
+    s.M = static_cast<int>(q_rows); s.a_rows = static_cast<int>(Q); s.N = static_cast<int>(b); s.KT = static_cast<int>(D / 64);
+    if (shape < 0) {
+        // tile shape: least padded area, the 64 x 64-per-wave shapes charged 15 % for their extra LDS traffic per flop
+        const int64_t area[3] = {cdiv(q_rows, 256) * 256 * cdiv(b, 256) * 256, cdiv(q_rows, 256) * 256 * cdiv(b, 128) * 128,
+                                 cdiv(q_rows, 128) * 128 * cdiv(b, 256) * 256};
+        shape = 0;
+        if (area[1] * 115 < area[shape] * 100) shape = 1;
+        if (area[2] * 115 < (shape == 0 ? area[0] * 100 : area[1] * 115)) shape = 2;
+        // round 4: when a half tile wins, the 512 x 128 / 128 x 512 shapes (two-phase loop, 128 x 64 waves) cover the same narrow
+        // side with fewer DMA requests per MFMA -- taken when they pad no more than the 256-row shape does
+        if (half_tile_engine() == 4 && wide_tile_enabled()) {
+            if (shape == 1 && cdiv(q_rows, 512) * 512 == cdiv(q_rows, 256) * 256) shape = 3;
+            else if (shape == 2 && cdiv(b, 512) * 512 == cdiv(b, 256) * 256) shape = 4;
+        }
+        if (const char* e = getenv("KF_SCORE_SHAPE")) shape = std::min(4, std::max(0, atoi(e)));   // measurements only
     }
-    if (const char* e = getenv("KF_SCORE_SHAPE")) shape = std::min(4, std::max(0, atoi(e)));   // measurements only
     const int tm = shape == 3 ? 512 : (shape == 2 || shape == 4) ? 128 : 256, tn = shape == 4 ? 512 : (shape == 1 || shape == 3) ? 128 : 256;
-    s.tiles_m = static_cast<int>(cdiv(Q, tm)); s.tiles_n = static_cast<int>(cdiv(b, tn));
+    s.tiles_m = static_cast<int>(cdiv(q_rows, tm)); s.tiles_n = static_cast<int>(cdiv(b, tn));
     const int64_t tiles = static_cast<int64_t>(s.tiles_m) * s.tiles_n;
     // one workgroup per CU: ONE round of work items over the 256 CUs (measured 4-6 % faster than two rounds of half the
     // length: fewer atomic epilogues and pipeline fills), at least 16 k-steps per item
@@ -1585,6 +1827,23 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
         hipLaunchKernelGGL((score_gemm_v4_kernel<128, 256>), grid, dim3(pp64::THREADS), PP64_SMEM, st, s);
     else if (shape == 1) hipLaunchKernelGGL((score_gemm_v2_kernel<256, 128, 4>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
     else hipLaunchKernelGGL((score_gemm_v2_kernel<128, 256, 2>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
+}
+
+int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t* psg, int64_t Q, int64_t b, int64_t D,
+                    float scale, hipStream_t st) {
+    // Mixed row tiling: Q = 256 a + r with 0 < r <= 128 and a wide train side (BERT: 872 queries against 512 sequences) would pad
+    // its last 256-row tile more than half -- `a` row tiles on the 256 x 256 loop and ONE launch of 128 x 256 tiles (64 x 64
+    // waves, kf_pingpong64.h) for the last r rows instead: 896 instead of 1 024 padded rows.  KF_SCORE_MIXED=0 switches it off.
+    const int64_t rest = Q % 256;
+    const char* mixed_env = getenv("KF_SCORE_MIXED");
+    const bool mixed = Q > 256 && rest > 0 && rest <= 128 && b > 128 && engine_generation() == 3 && half_tile_engine() == 4 &&
+                       !getenv("KF_SCORE_SHAPE") && !(mixed_env && atoi(mixed_env) == 0);
+    if (mixed) {
+        launch_score_rows(scores, ld, P, psg, Q, 0, Q - rest, b, D, scale, 0, st);
+        launch_score_rows(scores, ld, P, psg, Q, Q - rest, rest, b, D, scale, 2, st);
+    } else {
+        launch_score_rows(scores, ld, P, psg, Q, 0, Q, b, D, scale, -1, st);
+    }
     return launch_status();
 }
 
@@ -1932,6 +2191,31 @@ int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tile
     uint16_t* gt = reinterpret_cast<uint16_t*>(workspace);
     uint16_t* at = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align256(2 * b * O * R));
     uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(at) + align256(2 * b * Ip * R));
+    int64_t tn_min_r = 256;   // shorter contractions (BERT: T = 128) stay on the persistent 128 x 128 kernel; KF_TN_MIN_R: measurements, tests
+    if (const char* e = getenv("KF_TN_MIN_R")) tn_min_r = std::max<int64_t>(64, atoll(e));
+    if (tn_enabled() && R >= tn_min_r && O % 256 == 0 && I % 256 == 0 && R * std::max(O, I) < (1LL << 31)) {
+        // K-major path: the hooked [t][feature] tensors are the operands; the two segments are two base pointers
+        PsgTnArgs g{};
+        g.out = psg; g.out_tile_stride = b * 64;
+        g.G[0] = reinterpret_cast<const uint16_t*>(G); g.A[0] = reinterpret_cast<const uint16_t*>(A);
+        g.G[1] = reinterpret_cast<const uint16_t*>(G1); g.A[1] = reinterpret_cast<const uint16_t*>(A1);
+        g.b0 = static_cast<int>(b0);
+        g.O = static_cast<int>(O); g.I = static_cast<int>(I); g.Ip = static_cast<int>(Ip); g.KT = static_cast<int>(R / 64); g.batch = static_cast<int>(b);
+        g.tiles_m = static_cast<int>(O / 256); g.tiles_n = static_cast<int>(I / 256);
+        const int64_t items = b * g.tiles_m * g.tiles_n;
+        if (items >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+        with_tn_image([&](auto img) {
+            hipLaunchKernelGGL((psg_gemm_tn_kernel<decltype(img)::value>), dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pptn::THREADS), pptn::SMEM_BYTES, st, g);
+        });
+        if (Ip > I) {
+            PsgBiasArgs c{};
+            c.out = psg; c.out_tile_stride = b * 64; c.G[0] = g.G[0]; c.G[1] = g.G[1]; c.b0 = g.b0;
+            c.O = g.O; c.I = g.I; c.Ip = g.Ip; c.T = static_cast<int>(R); c.ones = append_ones ? 1 : 0;
+            hipLaunchKernelGGL(psg_bias_cols_kernel, dim3(static_cast<unsigned>(cdiv(O, 256)), static_cast<unsigned>(b)), dim3(256), 0, st, c);
+        }
+        if (launch_status() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+        return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
+    }
     // the two segments (train micro-batches) land one behind the other in the transposed copies: from there on ONE batch of b0 + b1
     const void* seg_g[2] = {G, G1};
     const void* seg_a[2] = {A, A1};
@@ -2033,6 +2317,18 @@ int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T
     if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
     hipStream_t st = as_stream(stream);
     const int64_t d = d_in + (append_ones ? 1 : 0), W = (d + 7) / 8 * 8;
+    if (!mask && tn_enabled() && d_in >= 256 && b * T < (1LL << 30)) {
+        // unmasked rows: X^T X on the K-major loop straight from the hooked tensor + the bias row / column as a column sum
+        CovFinalizeArgs f{};
+        f.out = C; f.ldc = ldc; f.d = static_cast<int>(d_in); f.conv = 0; f.alpha = alpha;
+        float* stage = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + align256(2 * b * W * T));
+        const int rc = launch_cov_tn(stage, reinterpret_cast<const uint16_t*>(X), d_in, b * T, d_in, f, st);
+        if (rc != KF_OK || !append_ones) return rc;
+        const int rows_per_block = 256;
+        hipLaunchKernelGGL(colsum_accum_kernel, dim3(static_cast<unsigned>(cdiv(d_in, 256)), static_cast<unsigned>(cdiv(b * T, rows_per_block))), dim3(256), 0,
+                           st, C, ldc, reinterpret_cast<const uint16_t*>(X), d_in, b * T, static_cast<int>(d_in), rows_per_block, alpha);
+        return launch_status();
+    }
     uint16_t* xt = reinterpret_cast<uint16_t*>(workspace);
     TransposeArgs t;
     t.out = xt; t.x = reinterpret_cast<const uint16_t*>(X); t.T = static_cast<int>(T); t.C = static_cast<int>(d_in); t.Cp = static_cast<int>(W);

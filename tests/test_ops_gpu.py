@@ -1072,3 +1072,155 @@ def test_low_rank_factors_are_near_optimal(ops, q, o, ip, k):
     best_err = float(sv[k:].norm() / sv.norm())  # Eckart-Young: error of the exact truncated SVD
     err = float((approx - p.double()).norm() / p.double().norm())
     assert err <= best_err * 1.02 + 1e-5, (err, best_err)
+
+
+# ---- round 5: sequence layers on the K-major loop (csrc/kf_pingpong_tn.h) --------------------------------------------------------
+@pytest.fixture
+def tn_env():
+    """Sets ``KF_TN`` / ``KF_TN_IMG`` (read per call by the library) for a test and restores them."""
+    before = {k: os.environ.get(k) for k in ("KF_TN", "KF_TN_IMG")}
+
+    def choose(tn=None, image=None):
+        for key, value in (("KF_TN", tn), ("KF_TN_IMG", image)):
+            if value is None:
+                os.environ.pop(key, None)
+            else:
+                os.environ[key] = str(value)
+
+    yield choose
+    for key, value in before.items():
+        if value is None:
+            os.environ.pop(key, None)
+        else:
+            os.environ[key] = value
+
+
+@pytest.mark.parametrize("image", [0, 1, 2])
+@pytest.mark.parametrize("q,b0,b1,r,o,i,bias", [(20, 3, 0, 256, 256, 512, True), (33, 2, 3, 512, 768, 768, True), (9, 2, 0, 320, 256, 256, False),
+                                                (16, 1, 0, 1024, 512, 256, True), (300, 5, 4, 64, 256, 256, True)])
+def test_pairwise_score_rows_k_major(ops, tn_env, image, q, b0, b1, r, o, i, bias, monkeypatch):
+    """kf_pairwise_score_rows2 on the K-major loop: the hooked ``[b, T, O]`` / ``[b, T, I]`` tensors are the operands of the
+    per-sample-gradient kernel (no transposed copies), the bias column is a column sum of ``G`` (module/linear.py:68-77, 112-122).
+    Every LDS image against the fp64 oracle and against the K-contiguous path (``KF_TN=0``) on the same inputs: same bf16
+    per-sample gradients -> the scores agree to the order of the split-K atomics."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    monkeypatch.setenv("KF_TN_MIN_R", "64")   # the 64-deep case too (the default keeps T < 256 on the 128 x 128 kernel)
+    width = i + int(bias)
+    pad = (-width) % 8
+    p = _rand(q, o, width, seed=7).to(torch.bfloat16)
+    tiled = TiledQueries(p.to(DEV), pad)
+    b = b0 + b1
+    g, a = _rand(b, r, o, dtype=torch.bfloat16), _rand(b, r, i, dtype=torch.bfloat16, seed=1)
+    want = ref.linear_pairwise_score(p.double(), a.double(), g.double(), bias)
+    gd, ad = g.to(DEV), a.to(DEV)
+
+    def run():
+        scores = torch.zeros(q, b + 2, device=DEV)
+        second = (gd[b0:].contiguous(), ad[b0:].contiguous()) if b1 else None
+        ops.pairwise_score_rows(scores, 1, tiled, gd[:b0].contiguous(), ad[:b0].contiguous(), bias, second=second)
+        assert float(scores[:, 0].abs().max()) == 0.0 and float(scores[:, -1].abs().max()) == 0.0
+        return scores[:, 1:-1]
+
+    tn_env(tn=1, image=image)
+    got = run()
+    assert rel(got, want) <= 4e-3, rel(got, want)
+    tn_env(tn=0)
+    old = run()
+    assert rel(got, old) <= 2e-5, rel(got, old)
+
+
+@pytest.mark.parametrize("image", [0, 1, 2])
+@pytest.mark.parametrize("b,t,d,bias,alpha", [(5, 128, 768, True, 1.0), (3, 64, 256, False, 0.25), (2, 512, 776, False, 1.0), (4, 256, 1032, True, 1.0),
+                                              (1, 64, 3072, True, 1.0), (70, 64, 264, True, 1.0)])
+def test_sequence_covariance_k_major(ops, tn_env, image, b, t, d, bias, alpha):
+    """kf_syrk_rows_bf16 on the K-major loop (unmasked rows): ``X^T X`` straight from the hooked ``[b, T, d]`` tensor, the bias row /
+    column as a column sum (module/linear.py:30-54, tracker/factor.py:58, 93) -- ragged 256-row tiles (776, 1032, 264), one and
+    many k-tile ranges; every LDS image against the fp64 oracle and the K-contiguous path."""
+    x = _rand(b, t, d, dtype=torch.bfloat16)
+    rows = x.double().flatten(0, 1)
+    if bias:
+        rows = torch.cat([rows, torch.ones(rows.shape[0], 1, dtype=torch.float64)], dim=1)
+    want = alpha * rows.t() @ rows
+    xd = x.to(DEV)
+
+    def run():
+        cov = torch.zeros(d + bias, d + bias, device=DEV)
+        cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+        if bias:
+            assert alpha == 1.0
+            ops.linear_activation_cov(cov, cnt, xd, None, True)
+        else:
+            ops.linear_gradient_cov(cov, cnt, xd, None, alpha)
+        assert int(cnt) == b * t
+        return cov
+
+    tn_env(tn=1, image=image)
+    got = run()
+    assert rel(got, want) <= TOL, rel(got, want)
+    assert rel(got, got.t()) <= 1e-6
+    tn_env(tn=0)
+    assert rel(got, run()) <= 1e-5
+
+
+@pytest.mark.parametrize("image", [0, 1, 2])
+def test_k_major_loop_race_screen(ops, tn_env, image):
+    """The K-major loop keeps the counted-``vmcnt`` / raw-barrier ordering of csrc/kf_pingpong.h and reads its fragments with inline
+    asm the compiler does not count: 40 launches of the per-sample-gradient + score call and of the covariance call on the same
+    operands beside a stream that keeps HBM unevenly busy; every result must match the first to fp32 atomic-order noise."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    tn_env(tn=1, image=image)
+    q, b, r, o, i = 512, 24, 512, 768, 768
+    p = TiledQueries(_rand(q, o, i + 1, seed=7).to(torch.bfloat16).to(DEV), 7)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    noise = torch.empty(1 << 28, dtype=torch.uint8, device=DEV)
+    side = torch.cuda.Stream()
+    first = {}
+    for launch in range(40):
+        with torch.cuda.stream(side):
+            if launch % 3 != 2:
+                noise[: (launch % 5 + 1) << 25].add_(1)
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score_rows(scores, 0, p, g, a, True)
+        cov, cnt = torch.zeros(o, o, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        ops.linear_gradient_cov(cov, cnt, g, None, 1.0)
+        for key, value in (("score", scores), ("cov", cov)):
+            if launch == 0:
+                first[key] = value.clone()
+            else:
+                worst = float((value - first[key]).abs().max() / first[key].abs().max())
+                assert worst <= 1e-5, (key, launch, worst)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("q,b", [(872, 512), (600, 256), (385, 300), (1100, 129)])
+@pytest.mark.parametrize("mixed", [True, False])
+def test_score_gemm_mixed_row_tiling(ops, q, b, mixed, monkeypatch):
+    """Round 5: a query count of 256 a + r, 0 < r <= 128, against a wide train side (BERT: 872 queries x 512 sequences) runs ``a``
+    row tiles on the 256 x 256 loop and ONE launch of 128 x 256 tiles for the last ``r`` rows (896 instead of 1 024 padded rows);
+    both launches add into the same score block.  Against torch on the same bf16 per-sample gradients, with the split switched off
+    (``KF_SCORE_MIXED=0``) as the control; long split-K chunks and 1 / 2 / 3 / 5 k-tiles per item."""
+    from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
+
+    if not mixed:
+        monkeypatch.setenv("KF_SCORE_MIXED", "0")
+    r, o, i = 16, 128, 1152
+    p = _rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV)
+    g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)
+    psg = torch.einsum("bro,bri->boi", g.float(), a.float()).to(torch.bfloat16)
+    want = p.float().flatten(1) @ psg.float().flatten(1).t()
+    tiled = TiledQueries(p, 0)
+    for _ in range(2):
+        scores = torch.zeros(q, b + 2, device=DEV)
+        ops.pairwise_score(scores, 1, tiled, g, a, False)
+        assert rel(scores[:, 1:-1], want) <= 1e-5, rel(scores[:, 1:-1], want)
+        assert float(scores[:, 0].abs().max()) == 0.0 and float(scores[:, -1].abs().max()) == 0.0
+    for short in (8, 16, 24, 40):
+        ps = _rand(q, 8, short, seed=9).to(torch.bfloat16).to(DEV)
+        gs, as_ = _rand(b, r, 8, dtype=torch.bfloat16, seed=2).to(DEV), _rand(b, r, short, dtype=torch.bfloat16, seed=3).to(DEV)
+        psg = torch.einsum("bro,bri->boi", gs.float(), as_.float()).to(torch.bfloat16)
+        want_s = ps.float().flatten(1) @ psg.float().flatten(1).t()
+        scores = torch.zeros(q, b, device=DEV)
+        ops.pairwise_score(scores, 0, TiledQueries(ps, 0), gs, as_, False)
+        assert rel(scores, want_s) <= 1e-5, (short, rel(scores, want_s))

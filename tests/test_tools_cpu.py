@@ -91,28 +91,30 @@ def test_request_schedules_of_the_256_loop_are_ordered():
 
 
 def test_tn_operand_index_arithmetic_replays_on_the_host(tmp_path):
-    """tools/next (prepared for the next round, not part of the library): the LDS image, LDS-DMA lane mapping and transposing-read
-    addresses of the K-major operand path are plain functions (kf_tn_map.h); tn_map_check.cpp replays them with g++ -- every chunk
-    of a piece written once where the image says, every fragment the MFMA operand layout under the assumed lane semantics of
-    ds_read_b64_tr_b16, all 64 banks per 32-lane half."""
+    """The K-major operand path (csrc/kf_pingpong_tn.h): the LDS images, LDS-DMA lane mappings and transposing-read addresses are
+    plain functions (csrc/kf_tn_map.h); tools/tn_map_check.cpp replays them with g++ for all three images -- every chunk of a piece
+    written once where the image says, every fragment the MFMA operand layout under the lane semantics of ds_read_b64_tr_b16, all
+    64 banks per 32-lane half, the (k-slab, quad) address step a compile-time constant."""
     import shutil
     import subprocess
 
     if shutil.which("g++") is None:
         pytest.skip("no g++")
+    csrc = os.path.join(ROOT, "kronfluence_amd", "csrc")
     exe = tmp_path / "tn_map_check"
-    subprocess.run(["g++", "-std=c++17", "-O1", os.path.join(ROOT, "tools", "next", "tn_map_check.cpp"), "-o", str(exe)], check=True)
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I", csrc, os.path.join(ROOT, "tools", "tn_map_check.cpp"), "-o", str(exe)], check=True)
     done = subprocess.run([str(exe)], capture_output=True, text=True)
     assert done.returncode == 0 and done.stdout.strip() == "ok", done.stdout[-500:]
-    # ... and it is a check: a read address without the swizzle, a DMA mapping with two k rows swapped -> rejected
-    header = open(os.path.join(ROOT, "tools", "next", "kf_tn_map.h")).read()
-    mutants = [("((((fl0 >> 5) ^ (s >> 2)) & 3) << 6)", "(((fl0 >> 5) & 3) << 6)"),
-               ("return 4 * (wave + 8 * h) + (lane >> 4);", "return 4 * (wave + 8 * h) + ((lane >> 4) ^ 1);")]
+    # ... and it is a check: an image without its swizzle, a DMA mapping with two k rows swapped, a wrong address step -> rejected
+    header = open(os.path.join(csrc, "kf_tn_map.h")).read()
+    mutants = [("return k * 256 + ((((fl >> 5) ^ k) & 3) << 6) + (fl & 31) * 2;", "return k * 256 + (((fl >> 5) & 3) << 6) + (fl & 31) * 2;"),
+               ("static KF_TN_HD int dma_k(int q, int lane) { return 16 * (q & 3) + (lane >> 2); }",
+                "static KF_TN_HD int dma_k(int q, int lane) { return 16 * (q & 3) + ((lane >> 2) ^ 1); }"),
+               ("(16 * kk + 8 * quad) * 64", "(16 * kk + 4 * quad) * 64")]
     for index, (old, new) in enumerate(mutants):
-        assert header.count(old) == 1
+        assert header.count(old) == 1, old
         work = tmp_path / f"mutant{index}"
         work.mkdir()
         (work / "kf_tn_map.h").write_text(header.replace(old, new))
-        shutil.copy(os.path.join(ROOT, "tools", "next", "tn_map_check.cpp"), work / "tn_map_check.cpp")
-        subprocess.run(["g++", "-std=c++17", "-O1", str(work / "tn_map_check.cpp"), "-o", str(work / "check")], check=True)
+        subprocess.run(["g++", "-std=c++17", "-O1", "-I", str(work), os.path.join(ROOT, "tools", "tn_map_check.cpp"), "-o", str(work / "check")], check=True)
         assert subprocess.run([str(work / "check")], capture_output=True).returncode == 1, index

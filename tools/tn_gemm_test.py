@@ -1,0 +1,81 @@
+"""Driver of tools/tn_gemm.hip: the K-major ("TN") 256 x 256 main loop of kronfluence_amd/csrc/kf_pingpong_tn.h, stand-alone.
+
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I kronfluence_amd/csrc tools/tn_gemm.hip -o tools/libtn_gemm.so
+    gpurun --timeout 150 -- 'python tools/tr_probe.py; python tools/tn_gemm_test.py'
+
+C = A^T B for K-major bf16 operands, for each of the three candidate LDS images (kf_tn_map.h), against torch in fp32 on the same
+bf16 values: 1, 2, 3, 5 and many k-tiles, ragged tiles, repeated launches beside a stream that keeps HBM busy (race screen); then
+timing per image (one workgroup per tile, no split-K: the loop's own rate at 4096^3).  Exit code 0 when every image agrees."""
+import ctypes
+import os
+import sys
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEV = "cuda:0"
+
+
+def main():
+    lib = ctypes.CDLL(os.path.join(HERE, "libtn_gemm.so"))
+    lib.tn_gemm.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                            ctypes.c_int64, ctypes.c_void_p]
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    torch.manual_seed(0)
+    good = {}
+    for image in (0, 1, 2):
+        bad = 0
+        for m, n, k in [(256, 256, 64), (256, 256, 128), (256, 256, 192), (512, 256, 320), (768, 776, 512), (264, 1000, 1152), (3072, 776, 128)]:
+            a = torch.randn(k, m, device=DEV).bfloat16()
+            b = torch.randn(k, n, device=DEV).bfloat16()
+            c = torch.zeros(m, n, device=DEV)
+            rc = lib.tn_gemm(image, c.data_ptr(), n, a.data_ptr(), b.data_ptr(), m, n, k, stream)
+            torch.cuda.synchronize()
+            want = a.float().t() @ b.float()
+            err = float((c - want).norm() / want.norm())
+            flag = "" if (rc == 0 and err < 1e-5) else "   <-- MISMATCH"
+            bad += bool(flag)
+            print(f"  image {image} M={m:5d} N={n:5d} K={k:5d} (k-tiles {k // 64:3d}): rc {rc} rel_F {err:.1e}{flag}", flush=True)
+        if not bad:   # race screen: 40 launches beside a copy stream; every result must equal the first bit for bit
+            m, n, k = 1024, 1024, 1536
+            a = torch.randn(k, m, device=DEV).bfloat16()
+            b = torch.randn(k, n, device=DEV).bfloat16()
+            side = torch.cuda.Stream()
+            big = torch.empty((1 << 28) + (1 << 16), dtype=torch.uint8, device=DEV)
+            first = None
+            for it in range(40):
+                nbytes = (1 << 27) + (it % 7) * 4096
+                with torch.cuda.stream(side):
+                    big[:nbytes].copy_(big[1 << 27:(1 << 27) + nbytes], non_blocking=True)
+                c = torch.zeros(m, n, device=DEV)
+                lib.tn_gemm(image, c.data_ptr(), n, a.data_ptr(), b.data_ptr(), m, n, k, stream)
+                if first is None:
+                    first = c
+                elif not torch.equal(first, c):
+                    bad += 1
+            torch.cuda.synchronize()
+            print(f"  image {image} race screen (40 launches beside a busy stream): {'identical' if not bad else 'DIFFERENT RESULTS'}", flush=True)
+        good[image] = not bad
+    for image in (0, 1, 2):
+        if not good[image]:
+            continue
+        for m, n, k in [(768, 776, 512), (3072, 776, 512), (4096, 4096, 4096)]:
+            a = torch.randn(k, m, device=DEV).bfloat16()
+            b = torch.randn(k, n, device=DEV).bfloat16()
+            c = torch.zeros(m, n, device=DEV)
+            for _ in range(2):
+                lib.tn_gemm(image, c.data_ptr(), n, a.data_ptr(), b.data_ptr(), m, n, k, stream)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(10):
+                lib.tn_gemm(image, c.data_ptr(), n, a.data_ptr(), b.data_ptr(), m, n, k, stream)
+            e.record()
+            torch.cuda.synchronize()
+            t = s.elapsed_time(e) / 10
+            print(f"  image {image} M={m:5d} N={n:5d} K={k:5d}: {t:7.3f} ms {2.0 * m * n * k / t / 1e9:6.0f} TFLOP/s", flush=True)
+    print("images that agree with torch:", [i for i in good if good[i]])
+    return 0 if all(good.values()) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

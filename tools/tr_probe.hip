@@ -1,4 +1,4 @@
-// tr_probe.hip -- PREPARED FOR ROUND 5, NOT PART OF THE LIBRARY, never run on a GPU yet.
+// tr_probe.hip -- stand-alone probe, not part of the library.
 //
 // Probes of gfx950's transposing LDS read (ds_read_b64_tr_b16, __builtin_amdgcn_ds_read_tr16_b64_*): what a TN operand path
 // for the per-sample-gradient and covariance kernels needs to know before it is written (DESIGN.md section 8, item 1 -- the hooked
@@ -12,7 +12,7 @@
 //                        read for candidate LDS images of an MFMA operand (bank conflicts of the transposing read are "hardware-
 //                        transpose-specific", cdna_hip_programming.md T10: measured, not derived).
 //
-// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/next/tr_probe.hip -o tools/next/libtr_probe.so ; driver: tr_probe.py
+// Build: hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/tr_probe.hip -o tools/libtr_probe.so ; driver: tr_probe.py
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

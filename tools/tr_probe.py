@@ -1,7 +1,7 @@
-"""Driver of tools/next/tr_probe.hip -- PREPARED FOR ROUND 5, never run on a GPU yet (see the .hip header).
+"""Driver of tools/tr_probe.hip (lane semantics and LDS-array cycles of gfx950's transposing LDS read).
 
-    hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/next/tr_probe.hip -o tools/next/libtr_probe.so     (here: cross-compiles)
-    gpurun -- 'python tools/next/tr_probe.py'
+    hipcc --offload-arch=gfx950 -O3 -shared -fPIC tools/tr_probe.hip -o tools/libtr_probe.so     (here: cross-compiles)
+    gpurun -- 'python tools/tr_probe.py'
 
 Part 1 (semantics): for a few per-lane address patterns prints, per lane, which LDS positions (16-bit units) it received, and checks
 the rule the design of a TN operand path assumes (cdna_hip_programming.md T10: within a 16-lane group, lane l receives element l & 3 of
@@ -79,6 +79,11 @@ def rows64(t, o):               # [o / 32][t][32 o]: 64-byte rows (four t rows =
     return (o >> 5) * 4096 + t * 64 + (o & 31) * 2
 
 
+def rows64_swapped(t, o):       # as rows64 with bits 2 and 3 of t swapped in the row index (kf_tn_map.h IMG 2; the guide's [8-key][32-col] subtile)
+    row = (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1)
+    return (o >> 5) * 4096 + row * 64 + (o & 31) * 2
+
+
 def rows32(t, o):               # [o / 16][t][16 o]: 32-byte rows -- the guide's [k][16-col] subtile
     return (o >> 4) * 2048 + t * 32 + (o & 15) * 2
 
@@ -92,8 +97,8 @@ def rows256_quarter_swizzle(t, o):  # the planned image: the 64-byte quarter of 
     return (o >> 7) * 16384 + t * 256 + quarter * 64 + (o & 31) * 2
 
 
-LAYOUTS = [("256-B rows", rows256), ("256-B rows, quarters swizzled by t & 3 (planned)", rows256_quarter_swizzle), ("plain [t][256 o]", plain), ("128-B rows", rows128), ("128-B rows, halves swizzled by t bit 1", rows128_half_swizzle),
-           ("64-B rows", rows64), ("32-B rows ([k][16] subtiles)", rows32)]
+LAYOUTS = [("256-B rows", rows256), ("256-B rows, quarters swizzled by t & 3 (IMG 0)", rows256_quarter_swizzle), ("plain [t][256 o]", plain), ("128-B rows", rows128), ("128-B rows, halves swizzled by t bit 1", rows128_half_swizzle),
+           ("64-B rows (IMG 1)", rows64), ("64-B rows, t bits 2 / 3 swapped (IMG 2)", rows64_swapped), ("32-B rows ([k][16] subtiles)", rows32)]
 
 
 def main():
