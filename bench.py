@@ -502,13 +502,73 @@ def _pmc_traffic(workload: str) -> Optional[dict]:
     return summary
 
 
+def _library_kernel_pattern():
+    """Regex that matches the (demangled) name of a kernel of libkronfluence_hip.so: every ``*_kernel`` the HIP sources define, in
+    the anonymous namespace or in ``kf::`` (torch's own kernels live in ``at::native::``)."""
+    import glob
+    import re
+
+    names = set()
+    for path in glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "kronfluence_amd", "csrc", "*.h")):
+        with open(path, encoding="utf-8") as handle:
+            names.update(re.findall(r"void ([A-Za-z0-9_]+_kernel)\b", handle.read()))
+    return re.compile(r"^(?:void )?(?:\(anonymous namespace\)::|kf::)(?:" + "|".join(sorted(names)) + r")\b")
+
+
+def _device_busy(step: Callable[[int], object], count: int) -> Optional[dict]:
+    """Where a pairwise step spends its wall time on the device: one step over the first ``count`` train samples
+    un-profiled (wall clock), the same step again under the torch profiler (device activity only: roctracer kernel records), kernel
+    durations summed by owner.  Everything runs on one stream, so the sum IS the busy time: ``device_busy_frac`` = all kernels and
+    copies / wall; ``idle_frac`` = the rest -- the GPU waiting for the host (Python hooks, autograd, ctypes launches).  Outside
+    the timed region; MIOpen / hipBLASLt heuristics are warm by then."""
+    try:
+        from torch.autograd import DeviceType
+        from torch.profiler import ProfilerActivity, profile
+
+        pattern = _library_kernel_pattern()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        step(count)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            step(count)
+            torch.cuda.synchronize()
+        ours = model = copies = 0.0
+        launches_ours = launches_model = 0
+        for e in prof.key_averages():
+            if e.device_type != DeviceType.CUDA:
+                continue
+            us = float(e.self_device_time_total)
+            if pattern.match(e.key):
+                ours += us
+                launches_ours += e.count
+            elif e.key.startswith(("Memcpy", "Memset", "__amd_rocclr_")):
+                copies += us
+            else:
+                model += us
+                launches_model += e.count
+        busy = (ours + model + copies) * 1e-6
+        return {"n_train": count, "wall_s": wall, "kf_kernel_s": ours * 1e-6, "model_kernel_s": model * 1e-6, "copy_s": copies * 1e-6,
+                "kf_kernel_launches": launches_ours, "model_kernel_launches": launches_model,
+                "device_busy_frac": busy / wall, "idle_frac": max(0.0, 1.0 - busy / wall),
+                "kf_kernel_frac": ours * 1e-6 / wall, "model_kernel_frac": model * 1e-6 / wall,
+                "method": "torch profiler (device activity) on one extra step after the timed region; kernel durations / the wall "
+                          "clock of the same step un-profiled; kf = kernels of libkronfluence_hip.so, model = everything else "
+                          "(MIOpen, hipBLASLt, attention, elementwise, softmax)"}
+    except Exception as error:  # diagnostics must never take the measurement down
+        return {"error": f"{type(error).__name__}: {error}"[:200]}
+
+
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int], steps: int, warmup: int,
-                 factor_reps: int, cpu_baseline: bool, n_fit: Optional[int] = None, warm_n_train: Optional[int] = None) -> dict:
+                 factor_reps: int, cpu_baseline: bool, n_fit: Optional[int] = None, warm_n_train: Optional[int] = None,
+                 busy_n_train: Optional[int] = None) -> dict:
     """``n_fit``: fit the factors on the first ``n_fit`` train samples only (the pairwise stage does not care how many samples
     the factors saw; used by the full-size extras to keep the default run within minutes -- reported in ``factor_fit.n_fit``).
     ``warm_n_train``: the warm-up steps score against the first ``warm_n_train`` train samples (one-time costs -- allocator
-    growth, GEMM / MIOpen heuristics, the k-tile-major query layout code paths -- without paying a full-size step)."""
+    growth, GEMM / MIOpen heuristics, the k-tile-major query layout code paths -- without paying a full-size step).
+    ``busy_n_train``: train samples of the two extra steps that measure ``device_busy`` (default: all)."""
     from kronfluence_amd import ops, prepare_model
     from kronfluence_amd.utils import comm
     from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
@@ -622,6 +682,9 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     elapsed = time.perf_counter() - t0
     new_segments = torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0
     gc.enable()
+    busy = None
+    if rank == 0 and world == 1 and os.environ.get("KF_BENCH_BUSY", "1") != "0":
+        busy = _device_busy(step, min(n_train, max(4 * spec["train_batch"], busy_n_train or n_train)))
     if os.environ.get("KF_BENCH_PROFILE") and rank == 0:
         # diagnostics only (outside the timed region): one more step under the torch profiler, per-kernel device totals to a file
         from torch.profiler import ProfilerActivity, profile
@@ -774,6 +837,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                            "lambda_samples_per_sec": n_fit / fit_times["lambda"],
                            "eigendecomposition_fixed_seconds": fit_times["eigendecomposition"]},
             "peak_hbm_gib": round(peak_mem, 1),
+            # where the wall time of a step goes on the device: hand-written kernels / the model's own kernels / idle (host bound)
+            "device_busy": busy,
             # rank 0's collectives (RCCL over xGMI; all inside the timed regions): seconds are stream time between events
             # around each call -- for the query all-gather only the wait still exposed after overlapping with backward
             "exchanges": ({"backend": dist.get_backend(), "ranks": world, "factor_fit": fit_exchanges,
@@ -852,7 +917,7 @@ def main() -> None:
             "gpu_pairs_per_sec": m["value"], "ms_per_step": m["ms_per_step"], "cpu_pairs_per_sec": cpu_rate,
             "cpu_cores": m["cpu_baseline"]["cores"], "ratio": m["value"] / cpu_rate, "target_ratio": 10.0,
             "scores_rel_F_vs_cpu_oracle": m["cpu_baseline"].get("gpu_vs_cpu_scores_rel_F"), "damping": 1e-8,
-            "target_rel": 1e-4, "roofline": m["roofline"], "factor_fit": m["factor_fit"],
+            "target_rel": 1e-4, "roofline": m["roofline"], "factor_fit": m["factor_fit"], "device_busy": m["device_busy"],
         }}
     if default_run:
         # N = 1: BERT-base and GPT-2-small at bounded sizes.  N > 1: GPT-2-small only -- the config the north-star scaling
@@ -861,8 +926,8 @@ def main() -> None:
         # BERT-base at its FULL 67 349 x 872 (configs[2]); GPT-2-small at 16 384 x 1 024 sequences of 512 tokens (the score
         # contraction dominates the stage from there on; the full 100 k x 2 k is the 8-GPU configuration).  The factors are
         # fitted on a bounded prefix (n_fit) and the warm-up step scores a small prefix, so the default run stays within minutes.
-        sizes = {"bert_base": dict(n_train=WORKLOADS["bert_base"]["full_n_train"], n_fit=8192, warm_n_train=1024),
-                 "gpt2_small": dict(n_train=16384, n_fit=2048, warm_n_train=512),
+        sizes = {"bert_base": dict(n_train=WORKLOADS["bert_base"]["full_n_train"], n_fit=8192, warm_n_train=1024, busy_n_train=8192),
+                 "gpt2_small": dict(n_train=16384, n_fit=2048, warm_n_train=512, busy_n_train=2048),
                  # configs[4] as a one-block slice at full width (C5 proper is 32 blocks x 100k x 1k on 8 GPUs): ONE cold factor
                  # fit -- its 40 s are three 14336^2 eigendecompositions
                  "llama_block": dict(n_train=64, n_fit=64, warm_n_train=16, factor_reps=0)}
@@ -873,11 +938,11 @@ def main() -> None:
                 # first-touch allocations and GEMM heuristics)
                 size = sizes[other]
                 r = run_workload(other, state, size["n_train"], None, steps=1, warmup=1, factor_reps=size.get("factor_reps", 1), cpu_baseline=False,
-                                 n_fit=size["n_fit"], warm_n_train=size["warm_n_train"])
+                                 n_fit=size["n_fit"], warm_n_train=size["warm_n_train"], busy_n_train=size.get("busy_n_train"))
                 if rank == 0:
                     extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline",
                                                       "roofline_cov", "roofline_cov_f32", "roofline_lambda", "roofline_lambda_update", "factor_fit",
-                                                      "exchanges", "peak_hbm_gib")}
+                                                      "exchanges", "peak_hbm_gib", "device_busy")}
             except Exception as error:  # an extra must never take the headline down with it
                 extras[other] = {"error": f"{type(error).__name__}: {error}"[:300]}
                 gc.collect()

@@ -657,7 +657,7 @@ inline int engine_generation() {  // KF_ENGINE=2 forces the round-2 main loop (A
 // Round 5: sequence layers on the K-major loop (kf_pingpong_tn.h) -- no transposed copies of the hooked tensors.  KF_TN=0 switches
 // back to transpose_rows + the K-contiguous kernels (A/B measurements, fallback); KF_TN_IMG = 0 / 1 / 2 picks the LDS image
 // (kf_tn_map.h; read per call).
-constexpr int TN_IMAGE_DEFAULT = 2;
+constexpr int TN_IMAGE_DEFAULT = 0;   // measured (profiles/r05_tn_ab.log): 256-byte global rows per request win on the large shapes
 inline bool tn_enabled() {
     const char* e = getenv("KF_TN");
     return engine_generation() == 3 && !(e && e[0] == '0' && e[1] == 0);
@@ -667,9 +667,9 @@ inline void with_tn_image(F&& launch) {
     const char* e = getenv("KF_TN_IMG");
     const int image = (e && e[0] >= '0' && e[0] <= '2' && e[1] == 0) ? e[0] - '0' : TN_IMAGE_DEFAULT;
     switch (image) {
-    case 0: launch(std::integral_constant<int, 0>{}); break;
     case 1: launch(std::integral_constant<int, 1>{}); break;
-    default: launch(std::integral_constant<int, 2>{}); break;
+    case 2: launch(std::integral_constant<int, 2>{}); break;
+    default: launch(std::integral_constant<int, 0>{}); break;
     }
 }
 
@@ -1205,6 +1205,103 @@ __global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_kernel(PsgTnArgs a)
     }
 }
 
+// The same gradients from PERSISTENT workgroups (one per CU) on pptn::mainloop_items: the items of a workgroup run through the loop
+// without a break in the DMA pipeline, the bf16 result tile of an item leaves through 32 KB of LDS BESIDE the stage buffers (four
+// rounds of one 32-row block per wave) while the next item's first k-tiles land, and the bias column (sum_t G[n][t][o]: the ones
+// column of A') is summed from the fragments the waves hold anyway -- no second pass over G.  Items g = (z * tiles_n + tn) * tiles_m +
+// tm; XCD x owns a contiguous range (a sample's tiles share its operands through one L2), its workgroups take every
+// (gridDim / 8)-th item of it.
+struct PsgTnItemsArgs {
+    PsgTnArgs p;
+    int ones;                 // the bias column (column I of the augmented axis) is wanted; Ip == I + 8 then, else Ip == I
+    int dz, dn, dm;           // gridDim / 8 decomposed: (dz * tiles_n + dn) * tiles_m + dm
+};
+constexpr int PSG_TN_ITEMS_SMEM = pptn::SMEM_BYTES + 32768;
+
+template <int IMG>
+__global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_items_kernel(PsgTnItemsArgs v) {
+    const PsgTnArgs& a = v.p;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
+    const int tiles = a.tiles_m * a.tiles_n, per_wg = gridDim.x >> 3;
+    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int64_t g0 = static_cast<int64_t>(xcd) * per_xcd + j, g_end = min(items, (xcd + 1) * per_xcd);
+    if (g0 >= g_end) return;
+    const int n_items = static_cast<int>((g_end - g0 + per_wg - 1) / per_wg);
+    const int z0 = static_cast<int>(g0 / tiles), tile0 = static_cast<int>(g0 - static_cast<int64_t>(z0) * tiles);
+    const int tn0 = tile0 / a.tiles_m, tm0 = tile0 - tn0 * a.tiles_m;
+    const int64_t T = static_cast<int64_t>(a.KT) * 64;
+    const int64_t seg_a = a.A[1] ? a.A[1] - a.A[0] : 0, seg_g = a.G[1] ? a.G[1] - a.G[0] : 0;   // second segment relative to the first (elements)
+
+    pptn::Sources src;
+    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return a.A[0] + f; }, static_cast<int64_t>(a.I),
+                            [&](int f) { return a.G[0] + f; }, static_cast<int64_t>(a.O));
+    auto base = [&](int z, int tn, int tm, int64_t& oa, int64_t& ob) {
+        const bool second = z >= a.b0;
+        const int64_t zs = z - (second ? a.b0 : 0);
+        oa = (second ? seg_a : 0) + zs * T * a.I + tn * 256;
+        ob = (second ? seg_g : 0) + zs * T * a.O + tm * 256;
+    };
+    const pptn::ItemGrid grid{a.tiles_m, a.tiles_n, v.dz, v.dn, v.dm};
+    unsigned char* stage = sm + pptn::SMEM_BYTES;
+    const uint32_t stage_lds = pptn::lds_address(stage);
+    const int lr = lane & 31, hi = lane >> 5;
+    auto epilogue = [&](const pptn::ItemCursor& c, f32x16 (&acc)[4][2], float cs) {
+        const int i0 = c.tn * 256, m0 = c.tm * 256;
+        const int c8 = tid & 7, mrow = tid >> 3;   // this thread's 16-byte chunk of a staged row and its row (+ 64 per pass)
+#pragma unroll
+        for (int ib = 0; ib < 4; ++ib) {
+            // stage: row m (128 B) = the 64 result columns i = wm * 128 + ib * 32 + (0 .. 31) of both wave rows; the 16-byte chunk
+            // (wm, q) at position (wm * 4 + q) ^ (m & 7), its two 8-byte halves (hi) swapped on rows with bit 3 set: the 16 lanes of a
+            // store group (16 rows, one chunk, one half) then fall into 16 different 8-byte bank pairs
+#pragma unroll
+            for (int jn = 0; jn < 2; ++jn) {
+                const int m = wn * 64 + jn * 32 + lr;
+                const uint32_t row = stage_lds + m * 128 + ((hi ^ ((m >> 3) & 1)) << 3);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    uint2 w;
+                    w.x = pack_bf16x2(acc[ib][jn][4 * q], acc[ib][jn][4 * q + 1]);
+                    w.y = pack_bf16x2(acc[ib][jn][4 * q + 2], acc[ib][jn][4 * q + 3]);
+                    pptn::lds_store_b64(row + (((wm * 4 + q) ^ (m & 7)) << 4), w);
+                }
+            }
+            pp::wait_lds_reads();   // lgkmcnt(0): this wave's staging stores are in LDS (never vmcnt: the next item's k-tiles are in flight)
+            pp::barrier();
+            const int il = (c8 >> 2) * 128 + ib * 32 + (c8 & 3) * 8;
+#pragma unroll
+            for (int pass = 0; pass < 4; ++pass) {
+                const int m = mrow + 64 * pass;
+                u32x4 w = *reinterpret_cast<const u32x4*>(stage + m * 128 + ((c8 ^ (m & 7)) << 4));
+                if ((m >> 3) & 1) w = u32x4{w[2], w[3], w[0], w[1]};
+                const int64_t d = static_cast<int64_t>(m0 + m) * a.Ip + i0 + il;
+                *reinterpret_cast<u32x4*>(a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(c.z) * 64 + (d & 63)) = w;
+            }
+            pp::wait_lds_reads();
+            pp::barrier();   // the staging rows are free again
+        }
+        if (v.ones && c.tn == 0) {   // (wave-uniform) column I of the augmented axis: the bias gradient, zeros after it up to Ip
+            const float total = cs + __shfl_xor(cs, 32);
+            if (hi == 0) {
+                const int m = m0 + wn * 64 + wm * 32 + lr;
+                const int64_t d = static_cast<int64_t>(m) * a.Ip + a.I;
+                *reinterpret_cast<u32x4*>(a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(c.z) * 64 + (d & 63)) =
+                    u32x4{pack_bf16x2(total, 0.0f), 0u, 0u, 0u};
+            }
+        }
+    };
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int jn = 0; jn < 2; ++jn)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
+    pptn::mainloop_items<IMG>(acc, sm, src, n_items, a.KT, wave, lane, grid, z0, tn0, tm0, static_cast<int64_t>(a.I) * 64,
+                              static_cast<int64_t>(a.O) * 64, base, [&](const pptn::ItemCursor& c) { return v.ones && c.tn == 0; }, epilogue);
+}
+
 // Columns [I, Ip) of the per-sample gradients of the kernel above: psg[n][o][I] = sum_t G[n][t][o] (the gradient with respect to
 // the bias: the ones column of A', module/linear.py:30-46) when `ones`, zeros after it (the padding of the augmented axis to a
 // multiple of 8).  One workgroup per (256 output columns, sample); the four waves take every fourth t.
@@ -1554,11 +1651,12 @@ __global__ __launch_bounds__(pp::THREADS) void cov_gemm_v3_kernel(CovV2Args a) {
 // of the batch, the contraction index), i.e. K-major: C += X^T X on the K-major loop of kf_pingpong_tn.h -- no transposed copy
 // (kf_syrk_rows_bf16 used to write and re-read one per call).  Work items = (k-tile range, upper-triangular 256-row tile pair),
 // range major per XCD as above; same staging matrix, same finalize pass.  The bias row / column of an activation covariance
-// (the ones column of A') is a column sum: colsum_accum_kernel.
+// (the ones column of A') is a column sum: the tile pairs (0, tj) sum their B operand over k beside the MFMAs.
 struct CovTnArgs {
     float* stage; int np;
     const uint16_t* X; int64_t ld;   // [KT * 64][ld], columns [0, N) are used
     int N, KT, tiles, kchunk, kblocks, plain_store;
+    float* ones_out; int64_t ldc; float alpha;   // non-null: the covariance itself, whose row / column N (the bias one) gets alpha * column sums
 };
 
 template <int IMG>
@@ -1590,34 +1688,34 @@ __global__ __launch_bounds__(pptn::THREADS) void cov_gemm_tn_kernel(CovTnArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
     const int64_t step = a.ld * 64;
-    pptn::mainloop<IMG>(acc, sm, src, kt_end - kt_begin, wave, lane, [&](int kt) { return kt * step; }, [&](int kt) { return kt * step; });
+    // the bias row / column (ones != 0): the column sums of the tile pairs (0, tj) cover every column once per k-tile range
+    const bool colsum = a.ones_out != nullptr && ti == 0;
+    auto epilogue = [&](const pptn::ItemCursor&, f32x16 (&acc)[4][2], float cs) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
+            for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = wn * 64 + jn * 32 + (lane & 31);
-                float* dst = a.stage + static_cast<int64_t>(m0 + ml) * a.np + n0 + nl;
-                if (a.plain_store) *dst = acc[i][jn][r];
-                else atomicAdd(dst, acc[i][jn][r]);
+                for (int r = 0; r < 16; ++r) {
+                    const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = wn * 64 + jn * 32 + (lane & 31);
+                    float* dst = a.stage + static_cast<int64_t>(m0 + ml) * a.np + n0 + nl;
+                    if (a.plain_store) *dst = acc[i][jn][r];
+                    else atomicAdd(dst, acc[i][jn][r]);
+                }
+        if (colsum) {   // (wave-uniform) C[d][j] += alpha sum_k X[k][j], C[j][d] += the same, for this item's k-tiles
+            const float total = a.alpha * (cs + __shfl_xor(cs, 32));
+            const int col = n0 + wn * 64 + wm * 32 + (lane & 31);
+            if (lane < 32 && col < a.N) {
+                atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + col, total);
+                atomicAdd(a.ones_out + static_cast<int64_t>(col) * a.ldc + a.N, total);
             }
-}
-
-// C[d][j] += alpha * sum_r X[r][j], C[j][d] += the same, C[d][d] += alpha * rows: row / column d of the covariance of [X, 1].
-// grid (ceil(d / 256), row blocks); a block sums `rows_per_block` rows of 256 columns.
-__global__ __launch_bounds__(256) void colsum_accum_kernel(float* C, int64_t ldc, const uint16_t* X, int64_t ld, int64_t rows, int d,
-                                                           int rows_per_block, float alpha) {
-    const int j = blockIdx.x * 256 + threadIdx.x;
-    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block, r1 = min(rows, r0 + rows_per_block);
-    if (j < d) {
-        float s = 0.0f;
-#pragma unroll 8
-        for (int64_t r = r0; r < r1; ++r) s += __uint_as_float(static_cast<uint32_t>(X[r * ld + j]) << 16);
-        atomicAdd(C + static_cast<int64_t>(d) * ldc + j, alpha * s);
-        atomicAdd(C + static_cast<int64_t>(j) * ldc + d, alpha * s);
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(C + static_cast<int64_t>(d) * ldc + d, alpha * static_cast<float>(r1 - r0));
+            if (tj == 0 && threadIdx.x == 0)
+                atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + a.N, a.alpha * 64.0f * static_cast<float>(kt_end - kt_begin));
+        }
+    };
+    const pptn::ItemGrid grid{1, 1, 0, 0, 0};
+    pptn::mainloop_items<IMG>(acc, sm, src, 1, kt_end - kt_begin, wave, lane, grid, 0, 0, 0, step, step,
+                              [](int, int, int, int64_t& oa, int64_t& ob) { oa = 0; ob = 0; }, [&](const pptn::ItemCursor&) { return colsum; }, epilogue);
 }
 
 // covariance[i][j] += alpha * stage[p(i)][p(j)] (or its transpose: only tile pairs ti <= tj are computed); p = operand row of
@@ -1708,9 +1806,10 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
 }
 
 // covariance of unmasked K-major rows X[rows][ld] (columns [0, N)) on the K-major loop: C[0..N)[0..N) += alpha X^T X
-int launch_cov_tn(float* stage, const uint16_t* X, int64_t ld, int64_t rows, int64_t N, CovFinalizeArgs& f, hipStream_t st) {
+int launch_cov_tn(float* stage, const uint16_t* X, int64_t ld, int64_t rows, int64_t N, CovFinalizeArgs& f, bool ones, hipStream_t st) {
     CovTnArgs c{};
     c.stage = stage; c.X = X; c.ld = ld; c.N = static_cast<int>(N); c.KT = static_cast<int>(rows / 64);
+    c.ones_out = ones ? f.out : nullptr; c.ldc = f.ldc; c.alpha = f.alpha;
     c.tiles = static_cast<int>(cdiv(N, 256));
     c.np = c.tiles * 256;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = c.KT;
@@ -1775,6 +1874,9 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_items_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PSG_TN_ITEMS_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_items_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PSG_TN_ITEMS_SMEM) == hipSuccess &&
+            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_items_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PSG_TN_ITEMS_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess;
@@ -2191,7 +2293,7 @@ int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tile
     uint16_t* gt = reinterpret_cast<uint16_t*>(workspace);
     uint16_t* at = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + align256(2 * b * O * R));
     uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(at) + align256(2 * b * Ip * R));
-    int64_t tn_min_r = 256;   // shorter contractions (BERT: T = 128) stay on the persistent 128 x 128 kernel; KF_TN_MIN_R: measurements, tests
+    int64_t tn_min_r = 128;   // T = 64 stays on the persistent 128 x 128 kernel; KF_TN_MIN_R: measurements, tests
     if (const char* e = getenv("KF_TN_MIN_R")) tn_min_r = std::max<int64_t>(64, atoll(e));
     if (tn_enabled() && R >= tn_min_r && O % 256 == 0 && I % 256 == 0 && R * std::max(O, I) < (1LL << 31)) {
         // K-major path: the hooked [t][feature] tensors are the operands; the two segments are two base pointers
@@ -2204,6 +2306,21 @@ int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tile
         g.tiles_m = static_cast<int>(O / 256); g.tiles_n = static_cast<int>(I / 256);
         const int64_t items = b * g.tiles_m * g.tiles_n;
         if (items >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
+        // persistent workgroups (one per CU, items pipelined, bias column folded in) when every workgroup gets at least two items
+        // and the augmented axis is I (+ one chunk holding the bias column); KF_PSG_PERSIST=0: one workgroup per item (A/B, fallback)
+        const char* persist_env = getenv("KF_PSG_PERSIST");
+        const bool persistent = !(persist_env && persist_env[0] == '0') && g.KT >= 2 && items >= 512 && (Ip == I || (append_ones && Ip == I + 8));
+        if (persistent) {
+            PsgTnItemsArgs v{};
+            v.p = g; v.ones = append_ones ? 1 : 0;
+            const int per_wg = 32, tiles = g.tiles_m * g.tiles_n;   // 256 workgroups: 32 per XCD
+            v.dm = per_wg % g.tiles_m; v.dn = (per_wg / g.tiles_m) % g.tiles_n; v.dz = per_wg / tiles;
+            with_tn_image([&](auto img) {
+                hipLaunchKernelGGL((psg_gemm_tn_items_kernel<decltype(img)::value>), dim3(256), dim3(pptn::THREADS), PSG_TN_ITEMS_SMEM, st, v);
+            });
+            if (launch_status() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+            return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
+        }
         with_tn_image([&](auto img) {
             hipLaunchKernelGGL((psg_gemm_tn_kernel<decltype(img)::value>), dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pptn::THREADS), pptn::SMEM_BYTES, st, g);
         });
@@ -2322,12 +2439,7 @@ int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T
         CovFinalizeArgs f{};
         f.out = C; f.ldc = ldc; f.d = static_cast<int>(d_in); f.conv = 0; f.alpha = alpha;
         float* stage = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + align256(2 * b * W * T));
-        const int rc = launch_cov_tn(stage, reinterpret_cast<const uint16_t*>(X), d_in, b * T, d_in, f, st);
-        if (rc != KF_OK || !append_ones) return rc;
-        const int rows_per_block = 256;
-        hipLaunchKernelGGL(colsum_accum_kernel, dim3(static_cast<unsigned>(cdiv(d_in, 256)), static_cast<unsigned>(cdiv(b * T, rows_per_block))), dim3(256), 0,
-                           st, C, ldc, reinterpret_cast<const uint16_t*>(X), d_in, b * T, static_cast<int>(d_in), rows_per_block, alpha);
-        return launch_status();
+        return launch_cov_tn(stage, reinterpret_cast<const uint16_t*>(X), d_in, b * T, d_in, f, append_ones != 0, st);
     }
     uint16_t* xt = reinterpret_cast<uint16_t*>(workspace);
     TransposeArgs t;

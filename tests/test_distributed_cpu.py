@@ -1,4 +1,4 @@
-"""World-size-2 (gloo, CPU) tests of the N > 1 exchange steps of the hot path:
+"""World-size-2 / 3 / 8 (gloo, CPU) tests of the N > 1 exchange steps of the hot path:
 bucketed factor all-reduce (C1-C3), query-gradient all-gather + interleave (C4), score-block
 gather (C5).  The arithmetic on the shards needs a GPU, so shard-local results are synthesised
 here; what is tested is that the exchange reproduces the single-process result."""
@@ -263,6 +263,105 @@ def test_whole_stages_on_two_ranks_match_single_process(tmp_path, cpu_engine):
         want = analyzer.compute_self_scores(name, "f", train, per_device_train_batch_size=5,
                                             score_args=ScoreArguments(damping_factor=None, **kw))["all_modules"]
         assert close(got[name], want), name
+
+
+# ---- odd world sizes: wrap-around padding of the train shards together with a truncated last query round --------------------
+_MANY = dict(kind="mlp", n_train=45, n_query=11, q=2, b=5, fit_b=7)   # N % P != 0 and Q % (q P) != 0 for P = 3 and P = 8
+
+
+def _pipeline_many_ranks(rank, world, out_dir):
+    import cpu_engine
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.utils import comm
+    from test_pipeline_gpu import make_task
+
+    cpu_engine.install_in_worker()
+    c = _MANY
+    task = make_task(c["kind"])
+    model = prepare_model(fx.make_model(c["kind"]), task)
+    analyzer = Analyzer("t", model, task, output_dir=out_dir, disable_tqdm=True)
+    assert analyzer.state.num_processes == world and analyzer.state.process_index == rank
+    train = data.TensorDataset(*fx.make_data(c["kind"], c["n_train"], seed=1))
+    query = data.TensorDataset(*fx.make_data(c["kind"], c["n_query"], seed=2))
+    comm.EXCHANGE_LOG = {}
+    analyzer.fit_all_factors("f", train, per_device_batch_size=c["fit_b"], factor_args=FactorArguments(use_empirical_fisher=True))
+    fit_log, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), {}
+    out = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=c["q"], per_device_train_batch_size=c["b"],
+                                           score_args=ScoreArguments(damping_factor=None))
+    score_log, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
+    low = analyzer.compute_pairwise_scores("low", "f", query, train, per_device_query_batch_size=c["q"], per_device_train_batch_size=c["b"],
+                                           score_args=ScoreArguments(damping_factor=None, query_gradient_low_rank=3,
+                                                                     query_gradient_accumulation_steps=2))
+    own = analyzer.compute_self_scores("self", "f", train, per_device_train_batch_size=c["b"], score_args=ScoreArguments(damping_factor=None))
+    if rank == 0:
+        torch.save({"scores": out["all_modules"], "low": low["all_modules"], "self": own["all_modules"], "fit_log": fit_log,
+                    "score_log": score_log}, os.path.join(out_dir, "many_ranks.pt"))
+    else:
+        assert out is None and low is None
+        torch.save({"fit_log": fit_log, "score_log": score_log}, os.path.join(out_dir, f"log_rank{rank}.pt"))
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world):
+    """P = 3 and P = 8 with N = 45 train samples (N % P != 0: the contiguous train shards are wrap-padded to ceil(N / P),
+    utils/dataset.py:181-196, and the gathered score blocks cut back with ``cat[:, :N]``), Q = 11 queries at 2 per rank (Q % (q P) !=
+    0: the strided query sampler pads with duplicates and the last round is truncated, score/pairwise.py:239-246), the 2 L = 6
+    eigenproblems of the 3-layer fixture dealt over 8 ranks (two ranks own none), the factor fit strided without padding -- all
+    against the single-process run; and the bytes every exchange moved against the section-8(e) volumes BY FORMULA."""
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.module.tracked_module import TrackedModule
+    from test_pipeline_gpu import make_task
+
+    c = _MANY
+    (tmp_path / "many").mkdir()
+    _run("_pipeline_many_ranks", tmp_path / "many", world=world)
+    got = torch.load(tmp_path / "many" / "many_ranks.pt")
+    task = make_task(c["kind"])
+    model = prepare_model(fx.make_model(c["kind"]), task)
+    analyzer = Analyzer("t", model, task, output_dir=str(tmp_path / "one"), disable_tqdm=True)
+    train = data.TensorDataset(*fx.make_data(c["kind"], c["n_train"], seed=1))
+    query = data.TensorDataset(*fx.make_data(c["kind"], c["n_query"], seed=2))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=c["fit_b"], factor_args=FactorArguments(use_empirical_fisher=True))
+    common = dict(per_device_query_batch_size=c["q"], per_device_train_batch_size=c["b"])
+    want = analyzer.compute_pairwise_scores("s", "f", query, train, score_args=ScoreArguments(damping_factor=None), **common)["all_modules"]
+    low = analyzer.compute_pairwise_scores("low", "f", query, train, score_args=ScoreArguments(damping_factor=None, query_gradient_low_rank=3),
+                                           **common)["all_modules"]
+    own = analyzer.compute_self_scores("self", "f", train, per_device_train_batch_size=c["b"], score_args=ScoreArguments(damping_factor=None))["all_modules"]
+
+    def close(a, b, tol):
+        a, b = a.double(), b.double()
+        return a.shape == b.shape and float((a - b).abs().max() / b.abs().max()) <= tol
+
+    assert want.shape == (c["n_query"], c["n_train"])
+    assert close(got["scores"], want, 2e-5) and close(got["low"], low, 1e-4) and close(got["self"], own, 2e-5)
+
+    # exchange volumes, rank 0 (every rank logs the same collectives): SURVEY.md section 8(e)
+    shapes = [(m.original_module.weight.shape[0], m.original_module.weight.shape[1] + 1) for m in model.modules() if isinstance(m, TrackedModule)]
+    cov_floats = sum(ip * ip + o * o for o, ip in shapes)
+    lam_floats = sum(o * ip for o, ip in shapes)
+    layers = len(shapes)
+    fit = got["fit_log"]
+    # covariances: one fp32 bucket + one int64 bucket (2 counters per layer + the stage's sample counter); Lambda likewise
+    assert fit["factor_all_reduce"]["calls"] == 4
+    assert fit["factor_all_reduce"]["bytes"] == 4 * (cov_floats + lam_floats) + 8 * (2 * layers + 1) + 8 * (layers + 1)
+    # 2 L eigenproblems, each broadcast from its owner: eigenvalues + eigenvectors in the factor dtype
+    assert fit["eigen_broadcast"]["calls"] == 2 * layers
+    assert fit["eigen_broadcast"]["bytes"] == 4 * sum(ip * ip + ip + o * o + o for o, ip in shapes)
+    # queries: ceil(Q / (q P)) rounds, each an all-gather of P q gradients per layer; scores: one [Q, ceil(N / P)] fp32 block per rank
+    rounds = -(-c["n_query"] // (c["q"] * world))
+    score = got["score_log"]
+    assert score["query_all_gather"]["calls"] == rounds * layers
+    assert score["query_all_gather"]["bytes"] == rounds * world * c["q"] * lam_floats * 4
+    assert score["score_gather"]["calls"] == 1
+    assert score["score_gather"]["bytes"] == c["n_query"] * (-(-c["n_train"] // world)) * 4
+    for rank in range(1, world):
+        other = torch.load(tmp_path / "many" / f"log_rank{rank}.pt")
+        assert other["fit_log"] == {k: {x: v[x] for x in ("calls", "bytes")} | {"seconds": other["fit_log"][k]["seconds"]} for k, v in fit.items()}
+        assert {k: (v["calls"], v["bytes"]) for k, v in other["score_log"].items()} == {k: (v["calls"], v["bytes"]) for k, v in score.items()}
 
 
 # ---- the reference's launch idiom: prepare_model -> apply_ddp -> Analyzer ---------------------------------------------------

@@ -1,0 +1,60 @@
+#!/usr/bin/env bash
+# The GPU command lines of round 5, one sub-command each:  gpurun --timeout S -- 'bash tools/gpu/r05.sh <what>'
+#   probe     lane semantics / LDS cycles of ds_read_b64_tr_b16 (tools/tr_probe.py), the K-major main loop stand-alone for its three
+#             LDS images (tools/tn_gemm_test.py), the new kernel tests, tools/r05_ab.py ab under the kernel trace, and the PMC replays
+#             of the transformer entry points (before: KF_TN=0, after: KF_TN=1)
+#   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
+# Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
+set -u
+what="${1:-probe}"
+mkdir -p gpurun_out
+cd "$GRAFT_REPO_ROOT"
+export TMPDIR=/tmp
+R="$GRAFT_REPO_ROOT"
+
+replay_pmc() {  # replay_pmc <out_base> <workload> <entry>: three counter passes of one entry point's calls
+    local base="$1" w="$2" e="$3"
+    mkdir -p "$base"
+    for spec in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        set -- $spec; local tag="$1"; shift
+        ( cd /tmp && timeout 200 rocprofv3 --pmc "$@" --output-format csv -d "$R/$base/${w}_${e}_$tag" -- \
+            python "$R/tools/r05_ab.py" replay "$w" "$e" "$R/$base/${w}_${e}_meta.json" ) > "$base/${w}_${e}_$tag.log" 2>&1 || echo "pmc pass $w $e $tag failed"
+    done
+}
+
+case "$what" in
+probe)
+    ( timeout 120 python tools/tr_probe.py ) > gpurun_out/r05_tr_probe.log 2>&1; echo "tr_probe rc $?"
+    grep -v "^W0" gpurun_out/r05_tr_probe.log | tail -40
+    ( timeout 200 python tools/tn_gemm_test.py ) > gpurun_out/r05_tn_gemm.log 2>&1; echo "tn_gemm_test rc $?"
+    tail -45 gpurun_out/r05_tn_gemm.log
+    ( timeout 600 python -m pytest tests/test_ops_gpu.py -q -k "k_major or mixed_row or rows_v2 or two_segments or sequence_rows or half_tile" --durations=5 ) > gpurun_out/r05_probe_tests.log 2>&1
+    tail -25 gpurun_out/r05_probe_tests.log
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r05_ab_trace" -- python "$R/tools/r05_ab.py" ab ) > gpurun_out/r05_ab.log 2>&1
+    find gpurun_out/r05_ab_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05_ab_kernel_stats.csv \;
+    rm -rf gpurun_out/r05_ab_trace
+    grep -v "^W0\|rocprof" gpurun_out/r05_ab.log | tail -30
+    # counters: before (K-contiguous path) for GPT-2, after (K-major) for GPT-2 and BERT
+    export KF_TN=0
+    for e in score cov; do replay_pmc gpurun_out/r05_pmc_before gpt2_small $e; done
+    unset KF_TN
+    ( python tools/pmc_entry_summary.py gpt2_small gpurun_out/r05_pmc_gpt2_small_before.json gpurun_out/r05_pmc_before ) > gpurun_out/r05_pmc_before_summary.log 2>&1
+    grep "^==" gpurun_out/r05_pmc_before_summary.log
+    for w in gpt2_small bert_base; do
+        for e in score cov lambda; do replay_pmc gpurun_out/r05_pmc $w $e; done
+        ( python tools/pmc_entry_summary.py $w gpurun_out/r05_pmc_$w.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_${w}_summary.log 2>&1
+        grep "^==" gpurun_out/r05_pmc_${w}_summary.log
+    done
+    find gpurun_out/r05_pmc gpurun_out/r05_pmc_before -name "*.csv" -size +2M -delete
+    ;;
+pmc)
+    for w in gpt2_small bert_base; do
+        for e in score cov lambda; do replay_pmc gpurun_out/r05_pmc $w $e; done
+        ( python tools/pmc_entry_summary.py $w gpurun_out/r05_pmc_$w.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_${w}_summary.log 2>&1
+        grep "^==" gpurun_out/r05_pmc_${w}_summary.log
+    done
+    find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
+    ;;
+*)
+    echo "unknown sub-command $what"; exit 2 ;;
+esac

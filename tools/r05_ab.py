@@ -158,11 +158,13 @@ def replay(workload, entry, meta_path):
             b = spec["factor_batch"]
             g, a = rand(b, t_len, o), rand(b, t_len, i)
             w = ipp
+            # random "eigenvector" matrices: the traffic of the rotations does not depend on orthogonality (and torch.linalg.qr
+            # segfaults under rocprofv3 --pmc)
             qa_t = torch.zeros(w, w, device=DEV)
-            qa_t[:ip, :ip] = torch.linalg.qr(torch.randn(ip, ip, device=DEV))[0].t()
+            qa_t[:ip, :ip] = torch.randn(ip, ip, device=DEV) / ip ** 0.5
             bias_row = qa_t[:ip, i].contiguous() if bias else None
             qa_t = qa_t.bfloat16().contiguous()
-            qg_t = torch.linalg.qr(torch.randn(o, o, device=DEV))[0].t().contiguous().bfloat16()
+            qg_t = (torch.randn(o, o, device=DEV) / o ** 0.5).bfloat16()
             lam = torch.zeros(o, ip, device=DEV)
             torch.cuda.synchronize()
             for _ in range(count):

@@ -41,12 +41,12 @@ def main():
             a = torch.randn(k, m, device=DEV).bfloat16()
             b = torch.randn(k, n, device=DEV).bfloat16()
             side = torch.cuda.Stream()
-            big = torch.empty((1 << 28) + (1 << 16), dtype=torch.uint8, device=DEV)
+            big, other = torch.empty((1 << 27) + (1 << 16), dtype=torch.uint8, device=DEV), torch.empty((1 << 27) + (1 << 16), dtype=torch.uint8, device=DEV)
             first = None
             for it in range(40):
                 nbytes = (1 << 27) + (it % 7) * 4096
                 with torch.cuda.stream(side):
-                    big[:nbytes].copy_(big[1 << 27:(1 << 27) + nbytes], non_blocking=True)
+                    big[:nbytes].copy_(other[:nbytes], non_blocking=True)
                 c = torch.zeros(m, n, device=DEV)
                 lib.tn_gemm(image, c.data_ptr(), n, a.data_ptr(), b.data_ptr(), m, n, k, stream)
                 if first is None:
