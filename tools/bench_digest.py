@@ -15,6 +15,14 @@ def show(name, r, indent=""):
     if fit:
         print(f"{indent}  factor_fit: " + ", ".join(f"{k} {v:.2f}s" for k, v in fit["seconds"].items())
               + f"  n_fit {fit['n_fit']}  eigh_paths {fit.get('eigh_paths')}")
+    busy = r.get("device_busy")
+    if busy:
+        if "error" in busy:
+            print(f"{indent}  device_busy: ERROR {busy['error']}")
+        else:
+            print(f"{indent}  device_busy: busy {busy['device_busy_frac']:.3f} (kf kernels {busy['kf_kernel_frac']:.3f}, model kernels "
+                  f"{busy['model_kernel_frac']:.3f}) idle {busy['idle_frac']:.3f} of a {busy['wall_s']:.2f} s step over {busy['n_train']} "
+                  f"train samples; launches kf {busy['kf_kernel_launches']} model {busy['model_kernel_launches']}")
     for key in ("roofline", "roofline_cov", "roofline_cov_f32", "roofline_lambda", "roofline_lambda_update"):
         v = r.get(key)
         if v:

@@ -3,6 +3,7 @@
 #   probe     lane semantics / LDS cycles of ds_read_b64_tr_b16 (tools/tr_probe.py), the K-major main loop stand-alone for its three
 #             LDS images (tools/tn_gemm_test.py), the new kernel tests, tools/r05_ab.py ab under the kernel trace, and the PMC replays
 #             of the transformer entry points (before: KF_TN=0, after: KF_TN=1)
+#   check2    the persistent K-major gradient kernel: tests, A/B, counters, bounded GPT-2 / BERT bench lines
 #   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -46,6 +47,28 @@ probe)
         grep "^==" gpurun_out/r05_pmc_${w}_summary.log
     done
     find gpurun_out/r05_pmc gpurun_out/r05_pmc_before -name "*.csv" -size +2M -delete
+    ;;
+check2)
+    # the persistent K-major gradient kernel + folded bias columns: kernel tests, A/B under the kernel trace, counters, bounded benches
+    ( timeout 200 python tools/tn_gemm_test.py ) > gpurun_out/r05_tn_gemm.log 2>&1; echo "tn_gemm_test rc $?"
+    tail -12 gpurun_out/r05_tn_gemm.log
+    ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_layer_shapes_gpu.py -q --durations=8 ) > gpurun_out/r05_check2_tests.log 2>&1
+    tail -20 gpurun_out/r05_check2_tests.log
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r05_ab2_trace" -- python "$R/tools/r05_ab.py" ab ) > gpurun_out/r05_ab2.log 2>&1
+    find gpurun_out/r05_ab2_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05_ab2_kernel_stats.csv \;
+    rm -rf gpurun_out/r05_ab2_trace
+    grep -v "^W0\|^E0\|rocprof" gpurun_out/r05_ab2.log | tail -24
+    rm -rf gpurun_out/r05_pmc
+    for w in gpt2_small bert_base; do
+        for e in score cov lambda; do replay_pmc gpurun_out/r05_pmc $w $e; done
+        ( python tools/pmc_entry_summary.py $w gpurun_out/r05_pmc_$w.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_${w}_summary.log 2>&1
+        grep "^==" gpurun_out/r05_pmc_${w}_summary.log
+    done
+    find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
+    ( timeout 600 python bench.py --workload gpt2_small --n-train 4096 --n-fit 1024 --warm-n-train 256 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_check2_gpt2.json 2> gpurun_out/r05_check2_gpt2.log
+    python tools/bench_digest.py gpurun_out/r05_check2_gpt2.json || tail -c 2000 gpurun_out/r05_check2_gpt2.log
+    ( timeout 600 python bench.py --workload bert_base --n-train 16384 --n-fit 2048 --warm-n-train 1024 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_check2_bert.json 2> gpurun_out/r05_check2_bert.log
+    python tools/bench_digest.py gpurun_out/r05_check2_bert.json || tail -c 2000 gpurun_out/r05_check2_bert.log
     ;;
 pmc)
     for w in gpt2_small bert_base; do
