@@ -197,8 +197,11 @@ class PairwiseScoreTracker(BaseTracker):
         if r == 1:
             return "factored"
         i = a.shape[-1]
+        # the sequence form runs on the bf16 engines and holds U, V in bf16: only when every operand already IS bf16 (the low-precision
+        # presets) -- with fp32 factors / gradients the expanded order keeps the reference's fp32 arithmetic, whatever the cost model
+        # says
         eligible = (g.is_cuda and o % 8 == 0 and i % 8 == 0 and k % 8 == 0 and o >= 64 and i >= 64 and ip == i + int(ones)
-                    and b <= 65535)
+                    and b <= 65535 and left.dtype == right.dtype == g.dtype == a.dtype == torch.bfloat16)
         if not eligible:
             return "expand"
         block = float(q) * o * ip

@@ -36,6 +36,8 @@ from oracle import ekfac_ref as ref  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
+DEV = "cuda:0"
+
 
 def rel(a, b):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
@@ -779,3 +781,23 @@ def test_low_rank_contraction_orders_agree(monkeypatch):
     print(f"low-rank 48 of 64: factored vs expanded order {agree:.1e}; expanded vs full rank {approx:.1e}")
     assert agree <= 2e-2, (agree, approx)   # (the rank-48 approximation itself is only reported: its error is the data's, not the kernels')
 
+
+
+def test_low_rank_plan_takes_the_bf16_sequence_form_for_bf16_operands_only():
+    """the factored sequence order runs on the bf16 engines and rounds its two row products to bf16, so the plan may pick
+    it only when the factors, gradients and activations already ARE bf16 (the low-precision presets); fp32 operands keep the
+    reference's fp32 arithmetic (the expanded order) even where the cost model prefers the factored one."""
+    from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
+
+    tracker = PairwiseScoreTracker.__new__(PairwiseScoreTracker)
+    q, o, k, i, b, r = 8, 4096, 64, 4096, 16, 512   # a Llama projection: the factored order is ~3x cheaper by the model
+    for dtype, want in ((torch.bfloat16, "factored"), (torch.float32, "expand")):
+        left, right = torch.empty(q, o, k, dtype=dtype, device=DEV), torch.empty(q, k, i, dtype=dtype, device=DEV)
+        g, a = torch.empty(b, r, o, dtype=dtype, device=DEV), torch.empty(b, r, i, dtype=dtype, device=DEV)
+        assert tracker._low_rank_plan(left, right, g, a, False) == want, dtype
+    mixed = tracker._low_rank_plan(torch.empty(q, o, k, dtype=torch.float32, device=DEV), torch.empty(q, k, i, dtype=torch.float32, device=DEV),
+                                   torch.empty(b, r, o, dtype=torch.bfloat16, device=DEV), torch.empty(b, r, i, dtype=torch.bfloat16, device=DEV), False)
+    assert mixed == "expand"
+    # one row per sample: the fp32 skinny-GEMM form, whatever the dtype
+    assert tracker._low_rank_plan(torch.empty(q, o, k, device=DEV), torch.empty(q, k, i, device=DEV), torch.empty(b, 1, o, device=DEV),
+                                  torch.empty(b, 1, i, device=DEV), False) == "factored"
