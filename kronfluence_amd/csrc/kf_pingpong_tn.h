@@ -57,13 +57,6 @@ __device__ __forceinline__ s16x4 read_tr(uint32_t lds_byte_address) {
     return v;
 }
 
-// An 8-byte LDS store the compiler does not see as one (mainloop_items' epilogues): hipcc drains vmcnt to 0 in front of a plain LDS
-// store while an LDS-DMA request is in flight -- here the next item's k-tiles, which must stay in flight.  Uncounted: the caller waits
-// with wait_lds_reads() (lgkmcnt(0)) before the barrier that publishes the data.
-__device__ __forceinline__ void lds_store_b64(uint32_t lds_byte_address, uint2 data) {
-    asm volatile("ds_write_b64 %0, %1" ::"v"(lds_byte_address), "v"(data) : "memory");
-}
-
 // the lane's bf16x8 operand fragment of k-slab KK: k-quads 0 and 1
 template <int IMG, int KK>
 __device__ __forceinline__ bf16x8 fragment(uint32_t base) {
@@ -94,12 +87,29 @@ __device__ __forceinline__ void make_sources(Sources& s, int wave, int lane, Row
         }
 }
 
-// acc[i][jn] (i = 0..3 row blocks, jn = 0..1 column blocks of the wave's 128 x 64 tile) += A^T B over k-tiles [0, nt).
-// walk_a(t) / walk_b(t): element offset of k-tile t relative to Sources::p (t * 64 * ld for a plain operand).  `wave` must be
-// wave-uniform.  All 512 threads; sm: SMEM_BYTES of LDS at a 16-byte-aligned base.  On return every wave has finished reading LDS.
-template <int IMG, class WalkA, class WalkB>
-__device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane,
-                                         WalkA walk_a, WalkB walk_b) {
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+
+// sum of the eight bf16 of a fragment, added to acc (v_dot2c_f32_bf16 with a pair of ones: beside the MFMAs it costs ~10 cycles each)
+__device__ __forceinline__ float sum8(const bf16x8& f, float acc) {
+    const bf16x2 one = {static_cast<__bf16>(1.0f), static_cast<__bf16>(1.0f)};
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), one, acc, false);
+    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), one, acc, false);
+    return acc;
+}
+
+// acc[i][jn] (i = 0..3 row blocks, jn = 0..1 column blocks of the wave's 128 x 64 tile) += A^T B over k-tiles [0, nt); k-tile t of
+// an operand sits t * step_a / t * step_b elements behind Sources::p.  `wave` must be wave-uniform.  All 512 threads; sm: SMEM_BYTES
+// of LDS at a 16-byte-aligned base.  On return every wave has finished reading LDS and every request has landed.
+//
+// colsum (wave-uniform): the waves also sum the B operand over k -- the column sums of the K-major B matrix, i.e. the bias column
+// of a per-sample gradient (sum_t G[t][o]) or the bias row of a covariance -- from the fragments they hold anyway: wave (wm, wn)
+// sums columns wn * 64 + wm * 32 + (lane & 31) of the tile; lanes l and l ^ 32 hold the two k-octets of a column (the caller adds
+// them).  Returns this lane's partial sum (0 without colsum).
+template <int IMG>
+__device__ __forceinline__ float mainloop(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int nt, int wave, int lane,
+                                          int64_t step_a, int64_t step_b, bool colsum = false) {
     const int wm = wave >> 2, wn = wave & 3;
 
     auto issue_at = [&](int piece, int t, int64_t off) {
@@ -108,7 +118,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
             glds16(src.p[2 * piece + h] + off,
                    sm + (t & 1) * STAGE_BYTES + piece * PIECE_BYTES + tnmap::request_of(wave, h) * tnmap::REQUEST_BYTES);
     };
-    auto issue_piece = [&](int piece, int t) { issue_at(piece, t, piece < 2 ? walk_a(t) : walk_b(t)); };
+    auto issue_piece = [&](int piece, int t) { issue_at(piece, t, t * (piece < 2 ? step_a : step_b)); };
 
     // per-lane LDS byte addresses of the words of k-slab 0, quad 0 for this wave's blocks in stage 0; k-slab kk / quad add a
     // compile-time constant (tnmap::word_step: folded into the instruction's offset field), stage 1 adds STAGE_BYTES
@@ -154,12 +164,11 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
     barrier();
     if (wm == 1) barrier();   // Y runs half a phase behind X from here on (wave-uniform branch)
 
+    float cs = 0.0f;
     // one k-tile = L(2t) M(2t) L(2t+1) M(2t+1); M(2t) carries A1(t+1), M(2t+1) A0, B0, B1 of t+2 (kf_pingpong.h, ISSUE = 1)
 #define KF_TN_TILE(T, MORE1, MORE2)                                                                                    \
     do {                                                                                                               \
         const int t_ = (T), buf_ = t_ & 1;                                                                             \
-        int64_t oa_ = 0, ob_ = 0;                                                                                      \
-        if (MORE1) oa_ = walk_a(t_ + 1);                                                                               \
         read_a(0, buf_);                                                                                               \
         read_b(buf_);                                                                                                  \
         if (MORE1) wait_vmcnt<6>();   /* A1(t) landed; in flight: A0, B0, B1 of t+1 */                                 \
@@ -168,25 +177,28 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
         barrier();                                                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
         KF_TN_GROUP(0, 0);                                                                                             \
-        ride(MORE1, 1, t_ + 1, oa_);                                                                                   \
+        ride(MORE1, 1, t_ + 1, (t_ + 1) * step_a);                                                                     \
         KF_TN_GROUP(0, 1);                                                                                             \
         KF_TN_GROUP(0, 2);                                                                                             \
         KF_TN_GROUP(0, 3);                                                                                             \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
         barrier();                                                                                                     \
-        if (MORE2) { oa_ = walk_a(t_ + 2); ob_ = walk_b(t_ + 2); }                                                     \
         read_a(1, buf_);                                                                                               \
         if (MORE1) wait_vmcnt<2>();   /* A0, B0, B1 of t+1 landed; in flight: A1(t+1) */                               \
         wait_lds_reads();                                                                                              \
         barrier();                                                                                                     \
         __builtin_amdgcn_s_setprio(1);                                                                                 \
         KF_TN_GROUP(1, 0);                                                                                             \
-        ride(MORE2, 0, t_ + 2, oa_);                                                                                   \
+        ride(MORE2, 0, t_ + 2, (t_ + 2) * step_a);                                                                     \
         KF_TN_GROUP(1, 1);                                                                                             \
-        ride(MORE2, 2, t_ + 2, ob_);                                                                                   \
+        ride(MORE2, 2, t_ + 2, (t_ + 2) * step_b);                                                                     \
         KF_TN_GROUP(1, 2);                                                                                             \
-        ride(MORE2, 3, t_ + 2, ob_);                                                                                   \
+        ride(MORE2, 3, t_ + 2, (t_ + 2) * step_b);                                                                     \
         KF_TN_GROUP(1, 3);                                                                                             \
+        if (colsum) {   /* the B fragments of this k-tile are still in registers */                                    \
+            if (wm == 0) { cs = sum8(b[0][0], cs); cs = sum8(b[0][1], cs); cs = sum8(b[0][2], cs); cs = sum8(b[0][3], cs); } \
+            else { cs = sum8(b[1][0], cs); cs = sum8(b[1][1], cs); cs = sum8(b[1][2], cs); cs = sum8(b[1][3], cs); }   \
+        }                                                                                                              \
         __builtin_amdgcn_s_setprio(0);                                                                                 \
         barrier();                                                                                                     \
     } while (0)
@@ -198,218 +210,7 @@ __device__ __forceinline__ void mainloop(f32x16 (&acc)[4][2], unsigned char* sm,
     if (wm == 0) barrier();   // X waits for Y's last segment: barrier counts match, all LDS reads are done
 #undef KF_TN_TILE
 #undef KF_TN_GROUP
-}
-
-
-// ------------------------------------------------------------------------------------------------
-// The same loop over MANY work items per workgroup (persistent workgroups), without a break in the DMA pipeline at an item
-// boundary: while the last k-tile of an item is being multiplied, the first two k-tiles of the next item are already on their
-// way, and its result tile leaves through LDS *beside* the stage buffers while they land.  One workgroup per item spends more
-// time around its 8-k-tile loop than in it (per-sample gradients of GPT-2: 21 us per item of which 7 us are MFMAs -- workgroup
-// launch, a cold DMA round trip, the 128 KB result tile, the store drain before the LDS is released).
-//
-// Items of a workgroup: g0, g0 + stride, g0 + 2 stride, ...; item g = (z * tiles_n + tn) * tiles_m + tm.  The stride is given
-// decomposed (dz, dn, dm) so that stepping an ItemCursor needs no division.  Global k-tile index T = item * KT + t; the tile loop is
-// that of mainloop() with walk(T) = base(item of T) + t * step.  Three cursors follow the three places an item is looked at:
-// the A1 request of tile T + 1 (issued in M(2T)), the A0 / B0 / B1 requests of tile T + 2 (M(2T + 1)), and the item being multiplied.
-//
-// At the end of an item the two wave groups are brought back into lock-step (X waits one barrier, as at the end of mainloop()),
-// `epilogue(cursor, acc, colsum)` runs on all eight waves -- it may use LDS beyond SMEM_BYTES and raw barriers, must execute the
-// same number of barriers on every wave, must not wait for vmcnt, and issues exactly EPI_STORES vector-memory instructions per
-// wave (or more) -- the accumulators are cleared and Y drops half a phase behind again.
-//
-// vmcnt across the epilogue (loads and stores retire in issue order on one counter: the counted waits of the first tile after an
-// epilogue include the stores -- S = EPI_STORES):
-//     issue order   ... A1(t) | A0 B0 B1 (t+1) | S stores | A1(t+1) [M(2t)] | A0 B0 B1 (t+2) [M(2t+1)] ...
-//     end of L(2t)    needs A1(t):          younger = 6 + S          ->  vmcnt(6 + S)      (no tile t+1: vmcnt(S))
-//     end of L(2t+1)  needs A0 B0 B1 (t+1): younger = S + 2          ->  vmcnt(2 + S)
-//     end of L(2t+2)  needs A1(t+1), issued AFTER the stores          ->  vmcnt(6) as always (the stores have retired by then)
-// A count that is too SMALL only waits longer (safe); the stores of an epilogue that issues more than EPI_STORES are older than
-// what the count keeps in flight.  Needs KT >= 2 when there is more than one item (the tile after an epilogue is never the last one
-// of its item).
-//
-// COLSUM: waves also sum the B operand over k (the column sums of the K-major B matrix -- the bias column of a per-sample gradient,
-// the bias row of a covariance): wave (wm, wn) sums columns wn * 64 + wm * 32 + (lane & 31) of the tile with v_dot2c_f32_bf16 on
-// the fragments it holds anyway; lanes l and l ^ 32 hold the two k-octets of a column (the caller adds them).
-// ------------------------------------------------------------------------------------------------
-struct ItemGrid {
-    int tiles_m, tiles_n;   // tile = tn * tiles_m + tm
-    int dz, dn, dm;         // the stride between a workgroup's consecutive items: (dz * tiles_n + dn) * tiles_m + dm
-};
-
-struct ItemCursor {
-    int z, tn, tm;   // the item
-    int t;           // k-tile inside it
-    int64_t a, b;    // element offsets of that k-tile relative to Sources::p
-    __device__ __forceinline__ void next_item(const ItemGrid& g) {
-        tm += g.dm;
-        if (tm >= g.tiles_m) { tm -= g.tiles_m; ++tn; }
-        tn += g.dn;
-        if (tn >= g.tiles_n) { tn -= g.tiles_n; ++z; }
-        z += g.dz;
-    }
-};
-
-constexpr int EPI_STORES = 16;
-
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ float sum8(const bf16x8& f, float acc) {
-    const bf16x2 one = {static_cast<__bf16>(1.0f), static_cast<__bf16>(1.0f)};
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 0, 1), one, acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 2, 3), one, acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 4, 5), one, acc, false);
-    acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_shufflevector(f, f, 6, 7), one, acc, false);
-    return acc;
-}
-
-// base(z, tn, tm, a, b): element offsets of k-tile 0 of the item; step_a / step_b: per k-tile; colsum(cursor) -> bool (wave-uniform):
-// whether the item being multiplied wants the column sums.
-template <int IMG, class Base, class WantColsum, class Epilogue>
-__device__ __forceinline__ void mainloop_items(f32x16 (&acc)[4][2], unsigned char* sm, const Sources& src, int n_items, int KT, int wave,
-                                               int lane, const ItemGrid& grid, int z0, int tn0, int tm0, int64_t step_a, int64_t step_b,
-                                               Base base, WantColsum want_colsum, Epilogue epilogue) {
-    const int wm = wave >> 2, wn = wave & 3;
-    const int NT = n_items * KT;
-
-    auto issue_at = [&](int piece, int t, int64_t off) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            glds16(src.p[2 * piece + h] + off,
-                   sm + (t & 1) * STAGE_BYTES + piece * PIECE_BYTES + tnmap::request_of(wave, h) * tnmap::REQUEST_BYTES);
-    };
-    auto advance = [&](ItemCursor& c) {   // one k-tile further
-        ++c.t; c.a += step_a; c.b += step_b;
-        if (c.t == KT) { c.t = 0; c.next_item(grid); base(c.z, c.tn, c.tm, c.a, c.b); }
-    };
-
-    const uint32_t sm_lds = lds_address(sm);
-    uint32_t wa[4], wb[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wa[i] = sm_lds + tnmap::a_piece(i) * PIECE_BYTES + tnmap::word<IMG>(tnmap::a_row(wm, i), 0, 0, lane);
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn) wb[jn] = sm_lds + tnmap::b_piece(wn) * PIECE_BYTES + tnmap::word<IMG>(tnmap::b_row(wn, jn), 0, 0, lane);
-
-    bf16x8 a[2][4], b[2][4];
-    auto read_a = [&](int half, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t at = wa[2 * half + i] + buf * STAGE_BYTES;
-            a[i][0] = fragment<IMG, 0>(at); a[i][1] = fragment<IMG, 1>(at); a[i][2] = fragment<IMG, 2>(at); a[i][3] = fragment<IMG, 3>(at);
-        }
-    };
-    auto read_b = [&](int buf) {
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const uint32_t at = wb[jn] + buf * STAGE_BYTES;
-            b[jn][0] = fragment<IMG, 0>(at); b[jn][1] = fragment<IMG, 1>(at); b[jn][2] = fragment<IMG, 2>(at); b[jn][3] = fragment<IMG, 3>(at);
-        }
-    };
-#define KF_TNI_GROUP(HALF, KK)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                      \
-        _Pragma("unroll") for (int jn = 0; jn < 2; ++jn)                                                               \
-            acc[(HALF) * 2 + i][jn] =                                                                                  \
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][KK], b[jn][KK], acc[(HALF) * 2 + i][jn], 0, 0, 0)
-    auto ride = [&](bool on, int piece, int t, int64_t off) {
-        if (on) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_at(piece, t, off);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // cursors: c1 -> tile T + 1 (its A1 piece), c2 -> tile T + 2 (A0, B0, B1), cc -> the item being multiplied
-    ItemCursor c1{z0, tn0, tm0, 0, 0, 0};
-    base(c1.z, c1.tn, c1.tm, c1.a, c1.b);
-    ItemCursor cc = c1;
-    // prologue: k-tile 0 complete, A0 / B0 / B1 of k-tile 1 on their way
-    issue_at(0, 0, c1.a); issue_at(2, 0, c1.b); issue_at(3, 0, c1.b); issue_at(1, 0, c1.a);
-    if (NT > 1) {
-        advance(c1);   // tile 1
-        issue_at(0, 1, c1.a); issue_at(2, 1, c1.b); issue_at(3, 1, c1.b);
-        wait_vmcnt<8>();
-    } else {
-        wait_vmcnt<2>();
-    }
-    ItemCursor c2 = c1;
-    if (NT > 2) advance(c2);   // tile 2
-    barrier();
-    if (wm == 1) barrier();   // Y runs half a phase behind X from here on
-
-    float cs = 0.0f;
-    bool colsum_on = want_colsum(cc);
-    // AFTER (wave-uniform): the first tile behind an epilogue -- its two counted waits include the epilogue's stores
-#define KF_TNI_TILE(T, MORE1, MORE2, AFTER)                                                                            \
-    do {                                                                                                               \
-        const int t_ = (T), buf_ = t_ & 1;                                                                             \
-        read_a(0, buf_);                                                                                               \
-        read_b(buf_);                                                                                                  \
-        if (MORE1) { if (AFTER) wait_vmcnt<6 + EPI_STORES>(); else wait_vmcnt<6>(); }                                  \
-        else { if (AFTER) wait_vmcnt<EPI_STORES>(); else wait_vmcnt<0>(); }                                            \
-        wait_lds_reads();                                                                                              \
-        barrier();                                                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
-        KF_TNI_GROUP(0, 0);                                                                                            \
-        ride(MORE1, 1, t_ + 1, c1.a);                                                                                  \
-        KF_TNI_GROUP(0, 1);                                                                                            \
-        KF_TNI_GROUP(0, 2);                                                                                            \
-        KF_TNI_GROUP(0, 3);                                                                                            \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
-        barrier();                                                                                                     \
-        if (MORE1) advance(c1);                                                                                        \
-        read_a(1, buf_);                                                                                               \
-        if (MORE1) { if (AFTER) wait_vmcnt<2 + EPI_STORES>(); else wait_vmcnt<2>(); }                                  \
-        wait_lds_reads();                                                                                              \
-        barrier();                                                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
-        KF_TNI_GROUP(1, 0);                                                                                            \
-        ride(MORE2, 0, t_ + 2, c2.a);                                                                                  \
-        KF_TNI_GROUP(1, 1);                                                                                            \
-        ride(MORE2, 2, t_ + 2, c2.b);                                                                                  \
-        KF_TNI_GROUP(1, 2);                                                                                            \
-        ride(MORE2, 3, t_ + 2, c2.b);                                                                                  \
-        KF_TNI_GROUP(1, 3);                                                                                            \
-        if (colsum_on) {                                                                                               \
-            if (wm == 0) { cs = sum8(b[0][0], cs); cs = sum8(b[0][1], cs); cs = sum8(b[0][2], cs); cs = sum8(b[0][3], cs); } \
-            else { cs = sum8(b[1][0], cs); cs = sum8(b[1][1], cs); cs = sum8(b[1][2], cs); cs = sum8(b[1][3], cs); }   \
-        }                                                                                                              \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
-        barrier();                                                                                                     \
-        if (MORE2) advance(c2);                                                                                        \
-    } while (0)
-
-    // The last item is peeled off the item loop: only its last two k-tiles take the tail forms of the tile, so the hot loop has one
-    // form and no three-way merge of the 128 accumulator registers (which cost 250 spilled VGPRs when tried).
-    auto finish_item = [&](bool more_items) {
-        if (wm == 0) barrier();   // X waits for Y's last segment: both groups in lock-step, every LDS read of the item is done
-        epilogue(cc, acc, cs);
-        if (more_items) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-            cs = 0.0f;
-            cc.next_item(grid);
-            colsum_on = want_colsum(cc);
-            if (wm == 1) barrier();   // Y half a phase behind again
-        }
-    };
-    int T = 0;
-    for (int it = 0; it + 1 < n_items; ++it) {
-        for (int t = 0; t < KT; ++t, ++T) KF_TNI_TILE(T, true, true, t == 0 && it > 0);
-        finish_item(true);
-    }
-    for (int t = 0; t + 2 < KT; ++t, ++T) KF_TNI_TILE(T, true, true, t == 0 && n_items > 1);
-    if (KT >= 2) {
-        KF_TNI_TILE(T, true, false, KT == 2 && n_items > 1);
-        ++T;
-    }
-    KF_TNI_TILE(T, false, false, false);   // (KT == 1 is allowed for a single item only)
-    finish_item(false);
-#undef KF_TNI_TILE
-#undef KF_TNI_GROUP
+    return cs;
 }
 
 }  // namespace pptn

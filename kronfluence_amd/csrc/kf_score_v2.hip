@@ -1135,15 +1135,18 @@ __global__ __launch_bounds__(pp::THREADS) void psg_gemm_pp_kernel(PsgPpArgs a) {
 // contraction index t is the slow axis of both -- so the K-contiguous kernels above needed two transposed copies per call
 // (transpose_rows_kernel: 22 % of a GPT-2 score call).  Here the 256 x 256 loop runs on K-major operands (kf_pingpong_tn.h:
 // [t][feature] LDS images, ds_read_b64_tr_b16 fragments) and the two train micro-batches of a pair are two base pointers, not a
-// copy.  Covers the real input columns [0, I) (I, O % 256 == 0); the bias column and the padding of the augmented axis come from
-// psg_bias_cols_kernel below.  Work items, operand roles (tile rows = i, tile columns = o) and the epilogue are those of
-// psg_gemm_pp_kernel.
+// copy.  Covers the real input columns [0, I) (I, O % 256 == 0).  The bias column (column I of the augmented axis: the ones column
+// of A', i.e. sum_t G[n][t][o]) is summed from the G fragments the waves of the tiles tn == 0 hold anyway (v_dot2c_f32_bf16 beside
+// the MFMAs) -- no second pass over G -- and written with the 7 zeros that pad the axis to Ip = I + 8.  Work items, operand roles
+// (tile rows = i, tile columns = o) and the epilogue are those of psg_gemm_pp_kernel.  (A persistent, item-pipelined form was
+// measured and removed: profiles/r05_psg_persistent_negative.log.)
 // ------------------------------------------------------------------------------------------------
 struct PsgTnArgs {
     uint16_t* out; int64_t out_tile_stride;
     const uint16_t* G[2]; const uint16_t* A[2];   // segment s: samples [s ? b0 : 0, ...), G[s]: [.][T][O], A[s]: [.][T][I]
     int b0;
     int O, I, Ip, KT, batch, tiles_m, tiles_n;    // tiles_m = O / 256, tiles_n = I / 256
+    int ones;                                     // the bias column is wanted: Ip == I + 8 (else Ip == I)
 };
 
 template <int IMG>
@@ -1173,8 +1176,8 @@ __global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_kernel(PsgTnArgs a)
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    const int64_t step_a = static_cast<int64_t>(a.I) * 64, step_b = static_cast<int64_t>(a.O) * 64;
-    pptn::mainloop<IMG>(acc, sm, src, a.KT, wave, lane, [&](int t) { return t * step_a; }, [&](int t) { return t * step_b; });
+    const bool bias = a.ones && tn == 0;   // (wave-uniform)
+    const float cs = pptn::mainloop<IMG>(acc, sm, src, a.KT, wave, lane, static_cast<int64_t>(a.I) * 64, static_cast<int64_t>(a.O) * 64, bias);
     __syncthreads();   // every wave is done with the stage buffers: the epilogue reuses them
     const int hi = lane >> 5;
 #pragma unroll
@@ -1203,139 +1206,13 @@ __global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_kernel(PsgTnArgs a)
         const int ml = er + 16 * it;
         *reinterpret_cast<u32x4*>(dst + it * step) = *reinterpret_cast<const u32x4*>(sm + ml * 512 + ((ech ^ (ml & 31)) << 4));
     }
-}
-
-// The same gradients from PERSISTENT workgroups (one per CU) on pptn::mainloop_items: the items of a workgroup run through the loop
-// without a break in the DMA pipeline, the bf16 result tile of an item leaves through 32 KB of LDS BESIDE the stage buffers (four
-// rounds of one 32-row block per wave) while the next item's first k-tiles land, and the bias column (sum_t G[n][t][o]: the ones
-// column of A') is summed from the fragments the waves hold anyway -- no second pass over G.  Items g = (z * tiles_n + tn) * tiles_m +
-// tm; XCD x owns a contiguous range (a sample's tiles share its operands through one L2), its workgroups take every
-// (gridDim / 8)-th item of it.
-struct PsgTnItemsArgs {
-    PsgTnArgs p;
-    int ones;                 // the bias column (column I of the augmented axis) is wanted; Ip == I + 8 then, else Ip == I
-    int dz, dn, dm;           // gridDim / 8 decomposed: (dz * tiles_n + dn) * tiles_m + dm
-};
-constexpr int PSG_TN_ITEMS_SMEM = pptn::SMEM_BYTES + 32768;
-
-template <int IMG>
-__global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_items_kernel(PsgTnItemsArgs v) {
-    const PsgTnArgs& a = v.p;
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
-    const int tiles = a.tiles_m * a.tiles_n, per_wg = gridDim.x >> 3;
-    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
-    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
-    const int64_t g0 = static_cast<int64_t>(xcd) * per_xcd + j, g_end = min(items, (xcd + 1) * per_xcd);
-    if (g0 >= g_end) return;
-    const int n_items = static_cast<int>((g_end - g0 + per_wg - 1) / per_wg);
-    const int z0 = static_cast<int>(g0 / tiles), tile0 = static_cast<int>(g0 - static_cast<int64_t>(z0) * tiles);
-    const int tn0 = tile0 / a.tiles_m, tm0 = tile0 - tn0 * a.tiles_m;
-    const int64_t T = static_cast<int64_t>(a.KT) * 64;
-    const int64_t seg_a = a.A[1] ? a.A[1] - a.A[0] : 0, seg_g = a.G[1] ? a.G[1] - a.G[0] : 0;   // second segment relative to the first (elements)
-
-    pptn::Sources src;
-    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return a.A[0] + f; }, static_cast<int64_t>(a.I),
-                            [&](int f) { return a.G[0] + f; }, static_cast<int64_t>(a.O));
-    auto base = [&](int z, int tn, int tm, int64_t& oa, int64_t& ob) {
-        const bool second = z >= a.b0;
-        const int64_t zs = z - (second ? a.b0 : 0);
-        oa = (second ? seg_a : 0) + zs * T * a.I + tn * 256;
-        ob = (second ? seg_g : 0) + zs * T * a.O + tm * 256;
-    };
-    const pptn::ItemGrid grid{a.tiles_m, a.tiles_n, v.dz, v.dn, v.dm};
-    unsigned char* stage = sm + pptn::SMEM_BYTES;
-    const uint32_t stage_lds = pptn::lds_address(stage);
-    const int lr = lane & 31, hi = lane >> 5;
-    auto epilogue = [&](const pptn::ItemCursor& c, f32x16 (&acc)[4][2], float cs) {
-        const int i0 = c.tn * 256, m0 = c.tm * 256;
-        const int c8 = tid & 7, mrow = tid >> 3;   // this thread's 16-byte chunk of a staged row and its row (+ 64 per pass)
-#pragma unroll
-        for (int ib = 0; ib < 4; ++ib) {
-            // stage: row m (128 B) = the 64 result columns i = wm * 128 + ib * 32 + (0 .. 31) of both wave rows; the 16-byte chunk
-            // (wm, q) at position (wm * 4 + q) ^ (m & 7), its two 8-byte halves (hi) swapped on rows with bit 3 set: the 16 lanes of a
-            // store group (16 rows, one chunk, one half) then fall into 16 different 8-byte bank pairs
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn) {
-                const int m = wn * 64 + jn * 32 + lr;
-                const uint32_t row = stage_lds + m * 128 + ((hi ^ ((m >> 3) & 1)) << 3);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    uint2 w;
-                    w.x = pack_bf16x2(acc[ib][jn][4 * q], acc[ib][jn][4 * q + 1]);
-                    w.y = pack_bf16x2(acc[ib][jn][4 * q + 2], acc[ib][jn][4 * q + 3]);
-                    pptn::lds_store_b64(row + (((wm * 4 + q) ^ (m & 7)) << 4), w);
-                }
-            }
-            pp::wait_lds_reads();   // lgkmcnt(0): this wave's staging stores are in LDS (never vmcnt: the next item's k-tiles are in flight)
-            pp::barrier();
-            const int il = (c8 >> 2) * 128 + ib * 32 + (c8 & 3) * 8;
-#pragma unroll
-            for (int pass = 0; pass < 4; ++pass) {
-                const int m = mrow + 64 * pass;
-                u32x4 w = *reinterpret_cast<const u32x4*>(stage + m * 128 + ((c8 ^ (m & 7)) << 4));
-                if ((m >> 3) & 1) w = u32x4{w[2], w[3], w[0], w[1]};
-                const int64_t d = static_cast<int64_t>(m0 + m) * a.Ip + i0 + il;
-                *reinterpret_cast<u32x4*>(a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(c.z) * 64 + (d & 63)) = w;
-            }
-            pp::wait_lds_reads();
-            pp::barrier();   // the staging rows are free again
+    if (bias) {   // column I: wave (wm, wn) summed G over t for output columns m0 + wn * 64 + wm * 32 + (lane & 31); k-octets in lanes l, l ^ 32
+        const float total = cs + __shfl_xor(cs, 32);
+        if (hi == 0) {
+            const int64_t db = static_cast<int64_t>(m0 + wn * 64 + wm * 32 + (lane & 31)) * a.Ip + a.I;
+            *reinterpret_cast<u32x4*>(a.out + (db >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (db & 63)) =
+                u32x4{pack_bf16x2(total, 0.0f), 0u, 0u, 0u};
         }
-        if (v.ones && c.tn == 0) {   // (wave-uniform) column I of the augmented axis: the bias gradient, zeros after it up to Ip
-            const float total = cs + __shfl_xor(cs, 32);
-            if (hi == 0) {
-                const int m = m0 + wn * 64 + wm * 32 + lr;
-                const int64_t d = static_cast<int64_t>(m) * a.Ip + a.I;
-                *reinterpret_cast<u32x4*>(a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(c.z) * 64 + (d & 63)) =
-                    u32x4{pack_bf16x2(total, 0.0f), 0u, 0u, 0u};
-            }
-        }
-    };
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    pptn::mainloop_items<IMG>(acc, sm, src, n_items, a.KT, wave, lane, grid, z0, tn0, tm0, static_cast<int64_t>(a.I) * 64,
-                              static_cast<int64_t>(a.O) * 64, base, [&](const pptn::ItemCursor& c) { return v.ones && c.tn == 0; }, epilogue);
-}
-
-// Columns [I, Ip) of the per-sample gradients of the kernel above: psg[n][o][I] = sum_t G[n][t][o] (the gradient with respect to
-// the bias: the ones column of A', module/linear.py:30-46) when `ones`, zeros after it (the padding of the augmented axis to a
-// multiple of 8).  One workgroup per (256 output columns, sample); the four waves take every fourth t.
-struct PsgBiasArgs {
-    uint16_t* out; int64_t out_tile_stride;
-    const uint16_t* G[2]; int b0;
-    int O, I, Ip, T, ones;
-};
-
-__global__ __launch_bounds__(256) void psg_bias_cols_kernel(PsgBiasArgs a) {
-    __shared__ float part[4][256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int z = blockIdx.y, o0 = blockIdx.x * 256 + lane * 4;
-    const int seg = z >= a.b0, zs = z - (seg ? a.b0 : 0);
-    float s[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (a.ones && o0 < a.O) {   // O % 8 == 0: four columns are entirely in or out
-        const uint16_t* g = a.G[seg] + static_cast<int64_t>(zs) * a.T * a.O + o0;
-        for (int t = wave; t < a.T; t += 4) {
-            const uint2 w = *reinterpret_cast<const uint2*>(g + static_cast<int64_t>(t) * a.O);
-            s[0] += __uint_as_float(w.x << 16); s[1] += __uint_as_float(w.x & 0xffff0000u);
-            s[2] += __uint_as_float(w.y << 16); s[3] += __uint_as_float(w.y & 0xffff0000u);
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) part[wave][lane * 4 + e] = s[e];
-    __syncthreads();
-    const int o = blockIdx.x * 256 + tid;
-    if (o >= a.O) return;
-    const float sum = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
-    for (int c = a.I; c < a.Ip; c += 8) {   // I, Ip % 8 == 0: 16-byte chunks of the k-tile-major gradient buffer
-        const int64_t d = static_cast<int64_t>(o) * a.Ip + c;
-        u32x4 w = {0u, 0u, 0u, 0u};
-        if (c == a.I && a.ones) w[0] = pack_bf16x2(sum, 0.0f);
-        *reinterpret_cast<u32x4*>(a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(z) * 64 + (d & 63)) = w;
     }
 }
 
@@ -1687,35 +1564,30 @@ __global__ __launch_bounds__(pptn::THREADS) void cov_gemm_tn_kernel(CovTnArgs a)
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    const int64_t step = a.ld * 64;
-    // the bias row / column (ones != 0): the column sums of the tile pairs (0, tj) cover every column once per k-tile range
-    const bool colsum = a.ones_out != nullptr && ti == 0;
-    auto epilogue = [&](const pptn::ItemCursor&, f32x16 (&acc)[4][2], float cs) {
+    // the bias row / column (ones_out != null): the column sums of the tile pairs (0, tj) cover every column once per k-tile range
+    const bool colsum = a.ones_out != nullptr && ti == 0;   // (wave-uniform)
+    const float cs = pptn::mainloop<IMG>(acc, sm, src, kt_end - kt_begin, wave, lane, a.ld * 64, a.ld * 64, colsum);
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
+        for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = wn * 64 + jn * 32 + (lane & 31);
-                    float* dst = a.stage + static_cast<int64_t>(m0 + ml) * a.np + n0 + nl;
-                    if (a.plain_store) *dst = acc[i][jn][r];
-                    else atomicAdd(dst, acc[i][jn][r]);
-                }
-        if (colsum) {   // (wave-uniform) C[d][j] += alpha sum_k X[k][j], C[j][d] += the same, for this item's k-tiles
-            const float total = a.alpha * (cs + __shfl_xor(cs, 32));
-            const int col = n0 + wn * 64 + wm * 32 + (lane & 31);
-            if (lane < 32 && col < a.N) {
-                atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + col, total);
-                atomicAdd(a.ones_out + static_cast<int64_t>(col) * a.ldc + a.N, total);
+            for (int r = 0; r < 16; ++r) {
+                const int ml = wm * 128 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), nl = wn * 64 + jn * 32 + (lane & 31);
+                float* dst = a.stage + static_cast<int64_t>(m0 + ml) * a.np + n0 + nl;
+                if (a.plain_store) *dst = acc[i][jn][r];
+                else atomicAdd(dst, acc[i][jn][r]);
             }
-            if (tj == 0 && threadIdx.x == 0)
-                atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + a.N, a.alpha * 64.0f * static_cast<float>(kt_end - kt_begin));
+    if (colsum) {   // C[N][j] += alpha sum_k X[k][j], C[j][N] += the same, for this item's k-tiles; the corner counts the rows
+        const float total = a.alpha * (cs + __shfl_xor(cs, 32));
+        const int col = n0 + wn * 64 + wm * 32 + (lane & 31);
+        if (lane < 32 && col < a.N) {
+            atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + col, total);
+            atomicAdd(a.ones_out + static_cast<int64_t>(col) * a.ldc + a.N, total);
         }
-    };
-    const pptn::ItemGrid grid{1, 1, 0, 0, 0};
-    pptn::mainloop_items<IMG>(acc, sm, src, 1, kt_end - kt_begin, wave, lane, grid, 0, 0, 0, step, step,
-                              [](int, int, int, int64_t& oa, int64_t& ob) { oa = 0; ob = 0; }, [&](const pptn::ItemCursor&) { return colsum; }, epilogue);
+        if (tj == 0 && threadIdx.x == 0)
+            atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + a.N, a.alpha * 64.0f * static_cast<float>(kt_end - kt_begin));
+    }
 }
 
 // covariance[i][j] += alpha * stage[p(i)][p(j)] (or its transpose: only tile pairs ti <= tj are computed); p = operand row of
@@ -1874,9 +1746,6 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_items_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PSG_TN_ITEMS_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_items_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PSG_TN_ITEMS_SMEM) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_items_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PSG_TN_ITEMS_SMEM) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess;
@@ -2295,7 +2164,8 @@ int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tile
     uint16_t* psg = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(at) + align256(2 * b * Ip * R));
     int64_t tn_min_r = 128;   // T = 64 stays on the persistent 128 x 128 kernel; KF_TN_MIN_R: measurements, tests
     if (const char* e = getenv("KF_TN_MIN_R")) tn_min_r = std::max<int64_t>(64, atoll(e));
-    if (tn_enabled() && R >= tn_min_r && O % 256 == 0 && I % 256 == 0 && R * std::max(O, I) < (1LL << 31)) {
+    if (tn_enabled() && R >= tn_min_r && O % 256 == 0 && I % 256 == 0 && R * std::max(O, I) < (1LL << 31) &&
+        (Ip == I || (append_ones && Ip == I + 8))) {
         // K-major path: the hooked [t][feature] tensors are the operands; the two segments are two base pointers
         PsgTnArgs g{};
         g.out = psg; g.out_tile_stride = b * 64;
@@ -2303,33 +2173,12 @@ int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tile
         g.G[1] = reinterpret_cast<const uint16_t*>(G1); g.A[1] = reinterpret_cast<const uint16_t*>(A1);
         g.b0 = static_cast<int>(b0);
         g.O = static_cast<int>(O); g.I = static_cast<int>(I); g.Ip = static_cast<int>(Ip); g.KT = static_cast<int>(R / 64); g.batch = static_cast<int>(b);
-        g.tiles_m = static_cast<int>(O / 256); g.tiles_n = static_cast<int>(I / 256);
+        g.tiles_m = static_cast<int>(O / 256); g.tiles_n = static_cast<int>(I / 256); g.ones = append_ones ? 1 : 0;
         const int64_t items = b * g.tiles_m * g.tiles_n;
         if (items >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
-        // persistent workgroups (one per CU, items pipelined, bias column folded in) when every workgroup gets at least two items
-        // and the augmented axis is I (+ one chunk holding the bias column); KF_PSG_PERSIST=0: one workgroup per item (A/B, fallback)
-        const char* persist_env = getenv("KF_PSG_PERSIST");
-        const bool persistent = !(persist_env && persist_env[0] == '0') && g.KT >= 2 && items >= 512 && (Ip == I || (append_ones && Ip == I + 8));
-        if (persistent) {
-            PsgTnItemsArgs v{};
-            v.p = g; v.ones = append_ones ? 1 : 0;
-            const int per_wg = 32, tiles = g.tiles_m * g.tiles_n;   // 256 workgroups: 32 per XCD
-            v.dm = per_wg % g.tiles_m; v.dn = (per_wg / g.tiles_m) % g.tiles_n; v.dz = per_wg / tiles;
-            with_tn_image([&](auto img) {
-                hipLaunchKernelGGL((psg_gemm_tn_items_kernel<decltype(img)::value>), dim3(256), dim3(pptn::THREADS), PSG_TN_ITEMS_SMEM, st, v);
-            });
-            if (launch_status() != KF_OK) return KF_ERR_LAUNCH_FAILED;
-            return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
-        }
         with_tn_image([&](auto img) {
             hipLaunchKernelGGL((psg_gemm_tn_kernel<decltype(img)::value>), dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pptn::THREADS), pptn::SMEM_BYTES, st, g);
         });
-        if (Ip > I) {
-            PsgBiasArgs c{};
-            c.out = psg; c.out_tile_stride = b * 64; c.G[0] = g.G[0]; c.G[1] = g.G[1]; c.b0 = g.b0;
-            c.O = g.O; c.I = g.I; c.Ip = g.Ip; c.T = static_cast<int>(R); c.ones = append_ones ? 1 : 0;
-            hipLaunchKernelGGL(psg_bias_cols_kernel, dim3(static_cast<unsigned>(cdiv(O, 256)), static_cast<unsigned>(b)), dim3(256), 0, st, c);
-        }
         if (launch_status() != KF_OK) return KF_ERR_LAUNCH_FAILED;
         return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
     }

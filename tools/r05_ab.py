@@ -3,8 +3,7 @@
     ab [score] [cov]      one process: the score entry point (kf_pairwise_score_rows2, two train micro-batches per call as the
                           tracker pairs them) and the covariance entry point (kf_syrk_rows_bf16: activations with the bias column,
                           output gradients) on the K-contiguous path (``KF_TN=0``: transpose_rows + the round-3 / 4 kernels) and
-                          on the K-major loop (``KF_TN=1``: one workgroup per item / persistent workgroups; LDS images); HIP events
-                          on the launch stream; results compared.
+                          on the K-major loop (``KF_TN=1``) with each LDS image; HIP events on the launch stream; results compared.
                           Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel averages.
     replay <workload> <entry> <meta.json>
                           the calls ONE train batch of the workload makes to one entry point (score | cov | lambda), one call per
@@ -52,9 +51,9 @@ def timed(fn, reps=5, warm=2):
     return s.elapsed_time(e) / reps
 
 
-def set_tn(tn, image=None, persist=None):
+def set_tn(tn, image=None):
     os.environ["KF_TN"] = str(tn)
-    for key, value in (("KF_TN_IMG", image), ("KF_PSG_PERSIST", persist)):
+    for key, value in (("KF_TN_IMG", image),):
         if value is None:
             os.environ.pop(key, None)
         else:
@@ -81,8 +80,8 @@ def score_ab():
         flops = 2.0 * q * b * o * (i + int(bias)) + 2.0 * b * t_len * o * (i + int(bias))
         second = (g[b0:], a[b0:]) if b1 else None
         line, outs = f"  {name:46s}", {}
-        for label, tn, image, persist in (("K-contig", 0, None, None), ("TN 1 wg/item", 1, 0, 0), ("TN persistent", 1, 0, None), ("persistent img2", 1, 2, None)):
-            set_tn(tn, image, persist)
+        for label, tn, image in (("K-contig", 0, None), ("TN img0", 1, 0), ("TN img1", 1, 1), ("TN img2", 1, 2)):
+            set_tn(tn, image)
             s = torch.zeros(q, b, device=DEV)
             t = timed(lambda: ops.pairwise_score_rows(s, 0, tiled, g[:b0], a[:b0], bias, second=second))
             s.zero_()

@@ -33,8 +33,7 @@ __global__ __launch_bounds__(pptn::THREADS) void tn_gemm_kernel(TnArgs a) {
         for (int jn = 0; jn < 2; ++jn)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    const int64_t step_a = static_cast<int64_t>(a.M) * 64, step_b = static_cast<int64_t>(a.N) * 64;
-    pptn::mainloop<IMG>(acc, sm, src, a.KT, wave, lane, [&](int t) { return t * step_a; }, [&](int t) { return t * step_b; });
+    pptn::mainloop<IMG>(acc, sm, src, a.KT, wave, lane, static_cast<int64_t>(a.M) * 64, static_cast<int64_t>(a.N) * 64);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
