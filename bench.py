@@ -199,7 +199,7 @@ class LlamaSlice(nn.Module):
 
 
 def llama_block() -> nn.Module:
-    return LlamaSlice(blocks=1)
+    return LlamaSlice(blocks=WORKLOADS["llama_block"].get("blocks", 1))
 
 
 class _BertLayer(nn.Module):
@@ -386,7 +386,7 @@ WORKLOADS = {
     # head is reduced to 32 000.
     "llama_block": dict(model=llama_block, kind="lm", vocab=32000, tokens=512, n_train=64, n_query=8, full_n_train=100_000,
                         full_n_query=1000, amp=torch.bfloat16, low_cov=True, factor_batch=8, train_batch=8, query_batch=4,
-                        low_rank=64, release_covariances=True, cpu_sample=dict(n_train=2, n_query=1, n_fit=1)),
+                        low_rank=64, release_covariances=True, blocks=1, cpu_sample=dict(n_train=2, n_query=1, n_fit=1)),
 }
 
 
@@ -407,14 +407,15 @@ def factor_arguments(spec):
     return FactorArguments(use_empirical_fisher=True, amp_dtype=amp, **extra)
 
 
-def score_arguments(spec, n_query: int, world: int, per_dev_q: int):
-    """ScoreArguments of a workload: every preconditioned query gradient held resident in HBM (P: n_query x D) -> ONE
-    train pass per step."""
+def score_arguments(spec, n_query: int, world: int, per_dev_q: int, passes: int = 1):
+    """ScoreArguments of a workload: the preconditioned query gradients held resident in HBM (P: n_query x D) -> ONE train pass per
+    step; ``passes`` > 1 when P does not fit (GPT-2-small at its stated 2 000 queries: 340 GB): the query batches are accumulated in
+    ``passes`` groups, each followed by its own train pass (reference score/pairwise.py:133-293)."""
     from kronfluence_amd import ScoreArguments
 
     amp = spec["amp"]
     low = amp == torch.bfloat16
-    accumulate = -(-n_query // (per_dev_q * world))
+    accumulate = -(-(-(-n_query // (per_dev_q * world))) // max(1, passes))
     return ScoreArguments(amp_dtype=amp, query_gradient_accumulation_steps=accumulate,
                           score_dtype=torch.bfloat16 if low else torch.float32,
                           precondition_dtype=torch.bfloat16 if low else torch.float32,
@@ -502,6 +503,52 @@ def _pmc_traffic(workload: str) -> Optional[dict]:
     return summary
 
 
+def _low_rank_parity(model, step: Callable[[int], object], n_sub: int) -> Optional[dict]:
+    """C5 parity inside the bench: one more pairwise pass over the first ``n_sub`` train samples with plain torch
+    hooks riding along; at every tracked layer's backward the hooked (activation, output gradient) and the low-rank factor pair the
+    product holds for ALL queries go through the oracle's fp64 restatement of ``"qik,qko,b...i,b...o->qb"`` (module/linear.py:83-99;
+    oracle/ekfac_ref.py, evaluated on the GPU in fp64), summed over layers, and are compared with the scores the pass returns.  The
+    checker, outside every timed region."""
+    try:
+        from kronfluence_amd.module.tracked_module import TrackedModule
+        from kronfluence_amd.utils.constants import ACCUMULATED_PRECONDITIONED_GRADIENT_NAME
+        from oracle import ekfac_ref as ref
+
+        want: Dict[str, torch.Tensor] = {}
+        handles, seen = [], {"layers": 0}
+        for m in [x for x in model.modules() if isinstance(x, TrackedModule)]:
+            def fwd(mod, inputs, output, m=m):
+                x = inputs[0].detach()
+
+                def bwd(grad, x=x, m=m):
+                    held = m.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
+                    if not isinstance(held, list):
+                        return
+                    left, right = held
+                    g = grad.detach().double()
+                    a = x.to(grad.dtype).double()   # the product consumes the activation in the gradient's (autocast) dtype
+                    block = ref.linear_pairwise_score_low_rank(left.double(), right.double(), a, g, m.original_module.bias is not None)
+                    want["sum"] = block if "sum" not in want else want["sum"] + block
+                    seen["layers"] += 1
+                output.register_hook(bwd)
+            handles.append(m.register_forward_hook(fwd))
+        try:
+            got = step(n_sub)["all_modules"].double()
+        finally:
+            for h in handles:
+                h.remove()
+        if "sum" not in want:
+            return {"error": "no layer held a low-rank factor pair"}
+        ref_scores = want["sum"].cpu()
+        err = float((got - ref_scores).norm() / ref_scores.norm())
+        return {"scores_rel_F_vs_fp64_low_rank_contraction": err, "queries": got.shape[0], "train_samples": got.shape[1],
+                "layer_batches_checked": seen["layers"],
+                "what": "scores of one extra pass vs the oracle's fp64 low-rank contraction (linear.py:83-99) on the hooked tensors and "
+                        "the very factor pairs the product held, all tracked layers summed"}
+    except Exception as error:
+        return {"error": f"{type(error).__name__}: {error}"[:200]}
+
+
 def _library_kernel_pattern():
     """Regex that matches the (demangled) name of a kernel of libkronfluence_hip.so: every ``*_kernel`` the HIP sources define, in
     the anonymous namespace or in ``kf::`` (torch's own kernels live in ``at::native::``)."""
@@ -563,7 +610,7 @@ def _device_busy(step: Callable[[int], object], count: int) -> Optional[dict]:
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int], steps: int, warmup: int,
                  factor_reps: int, cpu_baseline: bool, n_fit: Optional[int] = None, warm_n_train: Optional[int] = None,
-                 busy_n_train: Optional[int] = None) -> dict:
+                 busy_n_train: Optional[int] = None, query_passes: Optional[int] = None) -> dict:
     """``n_fit``: fit the factors on the first ``n_fit`` train samples only (the pairwise stage does not care how many samples
     the factors saw; used by the full-size extras to keep the default run within minutes -- reported in ``factor_fit.n_fit``).
     ``warm_n_train``: the warm-up steps score against the first ``warm_n_train`` train samples (one-time costs -- allocator
@@ -592,10 +639,14 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     low = amp == torch.bfloat16
     fargs = factor_arguments(spec)
     per_dev_q = max(1, min(spec["query_batch"], -(-n_query // world)))
-    sargs = score_arguments(spec, n_query, world, per_dev_q)
-    accumulate = sargs.query_gradient_accumulation_steps
     layers = tracked_shapes(model)
     D = sum(o * ip for o, ip in layers)
+    if query_passes is None:
+        # dense query gradients (2 bytes each in the bf16 presets) must fit beside the model's own passes: at most 62 % of the device
+        held = float(n_query) * D * (2 if low else 4) if not spec.get("low_rank") else 0.0
+        query_passes = max(1, int(-(-held // (0.62 * torch.cuda.get_device_properties(dev).total_memory))))
+    sargs = score_arguments(spec, n_query, world, per_dev_q, query_passes)
+    accumulate = sargs.query_gradient_accumulation_steps
 
     def barrier():
         torch.cuda.synchronize()
@@ -685,6 +736,9 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     busy = None
     if rank == 0 and world == 1 and os.environ.get("KF_BENCH_BUSY", "1") != "0":
         busy = _device_busy(step, min(n_train, max(4 * spec["train_batch"], busy_n_train or n_train)))
+    parity = None
+    if rank == 0 and world == 1 and spec.get("low_rank") and os.environ.get("KF_BENCH_PARITY", "1") != "0":
+        parity = _low_rank_parity(model, step, min(n_train, spec["train_batch"]))
     if os.environ.get("KF_BENCH_PROFILE") and rank == 0:
         # diagnostics only (outside the timed region): one more step under the torch profiler, per-kernel device totals to a file
         from torch.profiler import ProfilerActivity, profile
@@ -814,7 +868,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             "data": "synthetic",
             "config": {"workload": name, "n_train": n_train, "n_query": n_query, "tracked_layers": len(layers),
                        "D": D, "input_dtype": "bf16-autocast" if amp is not None else "f32",
-                       "score_dtype": str(sargs.score_dtype), "query_gradient_accumulation_steps": accumulate,
+                       "score_dtype": str(sargs.score_dtype), "query_gradient_accumulation_steps": accumulate, "query_passes": query_passes,
+                       **({"blocks": spec["blocks"]} if "blocks" in spec else {}),
                        "train_batch": spec["train_batch"], "query_batch": per_dev_q,
                        "parallelism": f"train-shard-dp{world}",
                        **({"warmup_n_train": min(warm_n_train, n_train)} if warm_n_train else {}),
@@ -839,6 +894,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             "peak_hbm_gib": round(peak_mem, 1),
             # where the wall time of a step goes on the device: hand-written kernels / the model's own kernels / idle (host bound)
             "device_busy": busy,
+            # low-rank workloads: the scores of one extra pass against the oracle's fp64 contraction on the hooked tensors
+            "parity": parity,
             # rank 0's collectives (RCCL over xGMI; all inside the timed regions): seconds are stream time between events
             # around each call -- for the query all-gather only the wait still exposed after overlapping with backward
             "exchanges": ({"backend": dist.get_backend(), "ranks": world, "factor_fit": fit_exchanges,
@@ -884,6 +941,10 @@ def main() -> None:
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
     ap.add_argument("--n-fit", type=int, default=None, help="fit the factors on the first N train samples only (default: all)")
     ap.add_argument("--warm-n-train", type=int, default=None, help="warm-up steps score against the first N train samples only")
+    ap.add_argument("--blocks", type=int, default=None, help="llama_block: decoder blocks of the slice (default 1; other_configs uses 2)")
+    ap.add_argument("--query-passes", type=int, default=None, help="groups the query batches are accumulated in, one train pass each "
+                    "(default: as few as fit 62 %% of the device memory)")
+    ap.add_argument("--busy-n-train", type=int, default=None, help="train samples of the two extra steps behind ``device_busy`` (default: all)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
                     "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
                     "907 -> 862 ms; nothing of the EK-FAC path is affected)")
@@ -892,6 +953,8 @@ def main() -> None:
         _respawn_under_torchrun(args.gpus)
     if args.train_batch:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
+    if args.blocks:
+        WORKLOADS["llama_block"]["blocks"] = args.blocks
     if not args.no_miopen_find:
         torch.backends.cudnn.benchmark = True
 
@@ -905,7 +968,8 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
     line = run_workload(args.workload, state, args.n_train, args.n_query, args.steps, args.warmup, args.factor_reps,
-                        cpu_baseline=not args.no_cpu_baseline, n_fit=args.n_fit, warm_n_train=args.warm_n_train)
+                        cpu_baseline=not args.no_cpu_baseline, n_fit=args.n_fit, warm_n_train=args.warm_n_train,
+                        query_passes=args.query_passes, busy_n_train=args.busy_n_train)
     default_run = (args.workload == "resnet9" and args.n_train is None and args.n_query is None and not args.no_extras
                    and os.environ.get("KF_BENCH_EXTRAS", "1") != "0")
     if default_run and world == 1:
@@ -930,19 +994,21 @@ def main() -> None:
                  "gpt2_small": dict(n_train=16384, n_fit=2048, warm_n_train=512, busy_n_train=2048),
                  # configs[4] as a one-block slice at full width (C5 proper is 32 blocks x 100k x 1k on 8 GPUs): ONE cold factor
                  # fit -- its 40 s are three 14336^2 eigendecompositions
-                 "llama_block": dict(n_train=64, n_fit=64, warm_n_train=16, factor_reps=0)}
+                 "llama_block": dict(n_train=64, n_fit=64, warm_n_train=16, factor_reps=0, blocks=2)}
         extras: Dict[str, dict] = {}
         for other in others:
             try:
                 # factor_reps=1: the reported fit is the second, warm one (the first GPT-2 covariance pass alone spends ~5 s in
                 # first-touch allocations and GEMM heuristics)
                 size = sizes[other]
+                if "blocks" in size:
+                    WORKLOADS[other]["blocks"] = size["blocks"]
                 r = run_workload(other, state, size["n_train"], None, steps=1, warmup=1, factor_reps=size.get("factor_reps", 1), cpu_baseline=False,
                                  n_fit=size["n_fit"], warm_n_train=size["warm_n_train"], busy_n_train=size.get("busy_n_train"))
                 if rank == 0:
                     extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline",
                                                       "roofline_cov", "roofline_cov_f32", "roofline_lambda", "roofline_lambda_update", "factor_fit",
-                                                      "exchanges", "peak_hbm_gib", "device_busy")}
+                                                      "exchanges", "peak_hbm_gib", "device_busy", "parity")}
             except Exception as error:  # an extra must never take the headline down with it
                 extras[other] = {"error": f"{type(error).__name__}: {error}"[:300]}
                 gc.collect()

@@ -4,6 +4,7 @@
 from __future__ import annotations
 
 import contextlib
+import os
 import threading
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
@@ -35,10 +36,18 @@ from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
 from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
-import os as _os
+def _eigh_streams() -> int:
+    """``KF_EIGH_STREAMS`` (default 8; 1 under rocprofv3, whose tracer does not survive eight launching threads)."""
+    value = os.environ.get("KF_EIGH_STREAMS", "8")
+    try:
+        return max(1, int(value))
+    except ValueError:
+        raise ValueError(f"KF_EIGH_STREAMS must be a positive integer, got {value!r}") from None
 
-EIGH_STREAMS = int(_os.environ.get("KF_EIGH_STREAMS", "8"))  # concurrent eigenproblems (HIP streams / host threads) per rank: the in-LDS solve of a round is latency
-                  # bound on a few dozen CUs, the other problems' streaming kernels fill the rest of the chip meanwhile
+
+# concurrent eigenproblems (HIP streams / host threads) per rank: the in-LDS solve of a round is latency bound on a few dozen CUs, the
+# other problems' streaming kernels fill the rest of the chip meanwhile
+EIGH_STREAMS = _eigh_streams()
 
 
 def eigendecomposition_save_path(output_dir: Path, factor_name: str) -> Path:
@@ -85,6 +94,10 @@ def lambda_matrices_exist(output_dir: Path, partition=None) -> bool:
     return all(lambda_matrices_save_path(output_dir, name, partition).exists() for name in LAMBDA_FACTOR_NAMES)
 
 
+# perform_eigendecomposition solves covariance matrices that are the same up to summation order once (False: every matrix on its own)
+DEDUPLICATE_COVARIANCES = True
+
+
 @torch.no_grad()
 def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module, state: State,
                                factor_args: FactorArguments, disable_tqdm: bool = False, cpu: bool = True,
@@ -108,7 +121,33 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
         ):
             jobs.append((module_name, cov_name, count_name, vec_name, val_name))
     world = state.num_processes if (state.use_distributed and dist.is_initialized()) else 1
-    mine = [job for index, job in enumerate(jobs) if world == 1 or index % world == state.process_index]
+    # Layers that consume the SAME tensor have the same activation covariance (query / key / value projections of an attention block,
+    # the gate / up projections of a SwiGLU MLP): the reference solves each -- from bit-identical matrices, so it gets identical
+    # results.  Here such a matrix is solved once and its eigendecomposition shared: two accumulations of one input differ only in
+    # the order of their fp32 atomics (relative 1e-7), so "the same" means equal counts and ||A - B||_F <= 1e-5 ||A||_F, screened by the
+    # diagonals first.  Every rank sees the same all-reduced covariances, hence takes the same decisions.
+    alias: Dict[int, int] = {}
+    if DEDUPLICATE_COVARIANCES:
+        seen: Dict[tuple, list] = {}
+        for index, (module_name, cov_name, count_name, _vec, _val) in enumerate(jobs):
+            cov = covariance_factors[cov_name][module_name]
+            count = int(covariance_factors[count_name][module_name].item())
+            key = (cov_name, tuple(cov.shape), cov.dtype, count)
+            diag = cov.diagonal().to(device=state.device, dtype=torch.float64)
+            for other in seen.setdefault(key, []):
+                rep_diag, rep_index = other
+                if float((diag - rep_diag).norm()) > 1e-5 * float(rep_diag.norm()):
+                    continue
+                rep = covariance_factors[cov_name][jobs[rep_index][0]]
+                a64, b64 = cov.to(device=state.device, dtype=torch.float32), rep.to(device=state.device, dtype=torch.float32)
+                if float((a64 - b64).norm()) <= 1e-5 * float(b64.norm()):
+                    alias[index] = rep_index
+                    break
+            else:
+                seen[key].append((diag, index))
+    solved = [index for index in range(len(jobs)) if index not in alias]   # dealt round-robin over the ranks
+    owner_of = {index: position % world for position, index in enumerate(solved)}
+    mine = [jobs[index] for index in solved if world == 1 or owner_of[index] == state.process_index]
 
     def solve(job, stream):
         module_name, cov_name, count_name, _vec, _val = job
@@ -160,9 +199,14 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
     # solver output, tensor broadcasts over RCCL (no pickling), one per matrix.
     for index, (module_name, cov_name, count_name, vec_name, val_name) in enumerate(jobs):
         original_dtype, d = meta[(module_name, cov_name)]
-        owner = index % world
         if release_covariances:
-            covariance_factors[cov_name].pop(module_name, None)   # (problems solved on other ranks)
+            covariance_factors[cov_name].pop(module_name, None)   # (problems solved on other ranks, shared solutions)
+        if index in alias:   # shares the solution of an earlier matrix (already exchanged): its own copy, as a caller may modify either
+            rep_name = jobs[alias[index]][0]
+            out[val_name][module_name] = out[val_name][rep_name].clone()
+            out[vec_name][module_name] = out[vec_name][rep_name].clone()
+            continue
+        owner = owner_of[index]
         if (module_name, cov_name) in results:
             evals, evecs = results.pop((module_name, cov_name))
         else:

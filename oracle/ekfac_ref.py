@@ -229,6 +229,18 @@ def linear_pairwise_score(p: torch.Tensor, a: torch.Tensor, g: torch.Tensor, has
     return torch.einsum("qio,bio->qb", p, psg)
 
 
+def linear_pairwise_score_low_rank(left: torch.Tensor, right: torch.Tensor, a: torch.Tensor, g: torch.Tensor,
+                                   has_bias: bool) -> torch.Tensor:
+    """module/linear.py:83-99 -- ``"qik,qko,b...i,b...o->qb"`` for a preconditioned query gradient held as the factor pair
+    ``[left [Q, O, k], right [Q, k, I']]`` of module/tracker/precondition.py:19-75 (the reference's labels: "i" = output dim,
+    "o" = input dim).  Written in the order that never forms an ``[O, I']`` block -- ``U = G L_q``, ``V = A' R_q^T``, then the sum
+    over (row, k) -- which equals the dense contraction with ``P_q = L_q R_q`` exactly (tests/test_oracle_golden.py)."""
+    a = _with_bias_column(a, has_bias)
+    u = torch.einsum("b...i,qik->qb...k", g, left)
+    v = torch.einsum("b...o,qko->qb...k", a, right)
+    return (u * v).flatten(2).sum(dim=2)
+
+
 def conv_pairwise_score(p: torch.Tensor, a: torch.Tensor, g: torch.Tensor, conv: nn.Conv2d) -> torch.Tensor:
     """module/conv2d.py:199-209 -- ``"qio,bti,bto->qb"``."""
     patches, grads = _conv_operands(a, g, conv)

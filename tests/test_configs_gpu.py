@@ -801,3 +801,58 @@ def test_low_rank_plan_takes_the_bf16_sequence_form_for_bf16_operands_only():
     # one row per sample: the fp32 skinny-GEMM form, whatever the dtype
     assert tracker._low_rank_plan(torch.empty(q, o, k, device=DEV), torch.empty(q, k, i, device=DEV), torch.empty(b, 1, o, device=DEV),
                                   torch.empty(b, 1, i, device=DEV), False) == "factored"
+
+
+@pytest.mark.parametrize("preset", ["bf16", "fp32"])
+def test_gpt2_query_passes_give_the_single_pass_scores(preset):
+    """configs[3] as stated has 2 000 queries: 340 GB of preconditioned gradients, i.e. TWO query passes on any rank count (reference
+    score/pairwise.py:133-293: the query batches are accumulated in groups of ``query_gradient_accumulation_steps``, each group
+    followed by its own pass over the train set).  A GPT-2-shaped decoder at reduced width (2 blocks, width 256, T = 128: every
+    tracked Linear takes the K-major sequence kernels in the bf16 preset), 10 queries in batches of 2: one pass (all five batches
+    held) against two passes (3 + 2 batches) -- the same scores up to the order of the score block's atomics -- and, in the fp32
+    preset, against the CPU oracle run in fp64 end to end (1e-3, heuristic damping)."""
+    import bench
+    from kronfluence_amd import FactorArguments, ScoreArguments, prepare_model
+    from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
+    from kronfluence_amd.factor.eigen import fit_lambda_matrices_with_loader, perform_eigendecomposition
+    from kronfluence_amd.score.pairwise import compute_pairwise_scores_with_loaders
+    from kronfluence_amd.utils.dataset import ResidentLoader
+    from kronfluence_amd.utils.state import State
+
+    state = State()
+    dev = state.device
+    torch.manual_seed(0)
+    raw = bench.GPT2(layers=2, width=256, heads=4, vocab=512, positions=128)
+    names = raw.tracked_names()
+    task = bench.make_lm_task(names)
+    model = prepare_model(raw, task).to(dev)
+    gen = torch.Generator().manual_seed(3)
+    train = (torch.randint(0, 512, (24, 128), generator=gen).to(dev),)
+    query = (torch.randint(0, 512, (10, 128), generator=gen).to(dev),)
+    low = preset == "bf16"
+    if low:
+        fargs = FactorArguments(use_empirical_fisher=True, amp_dtype=torch.bfloat16, per_sample_gradient_dtype=torch.bfloat16,
+                                lambda_dtype=torch.bfloat16, activation_covariance_dtype=torch.bfloat16, gradient_covariance_dtype=torch.bfloat16)
+        extra = dict(amp_dtype=torch.bfloat16, score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16)
+    else:
+        fargs, extra = FactorArguments(use_empirical_fisher=True), {}
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(train, 12), fargs)
+    eig = perform_eigendecomposition(cov, model, state, fargs)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 12), fargs, eig)
+
+    def run(accumulate):
+        sargs = ScoreArguments(damping_factor=None, query_gradient_accumulation_steps=accumulate, **extra)
+        return compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query, 2), 2,
+                                                    ResidentLoader(train, 8), sargs, fargs, None)["all_modules"].double()
+
+    one, two = run(5), run(3)
+    assert one.shape == (10, 24) and rel(two, one) <= (2e-3 if low else 1e-5), rel(two, one)
+    if not low:
+        engine = ref.OracleEngine(bench.GPT2(layers=2, width=256, heads=4, vocab=512, positions=128).double(), module_names=names)
+        engine.model.load_state_dict({k.replace(".original_module", ""): v.double().cpu() for k, v in model.state_dict().items() if "_constant" not in k})
+        chunks = lambda d, bs: [tuple(t[i:i + bs].cpu() for t in d) for i in range(0, d[0].shape[0], bs)]   # noqa: E731
+        cpu_eig = {k: {n: v.double().cpu() for n, v in d.items()} for k, d in eig.items()}
+        cpu_lam = {k: {n: (v.double() if v.is_floating_point() else v).cpu() for n, v in d.items()} for k, d in lam.items()}
+        want = engine.pairwise_scores(chunks(query, 2), chunks(train, 8), bench.lm_loss, bench.lm_loss, cpu_eig, cpu_lam, None)
+        print(f"reduced GPT-2, fp32 preset, two query passes vs fp64 oracle end to end: rel_F {rel(two, want):.2e}")
+        assert rel(two, want) <= 1e-3, rel(two, want)   # fp32 model + factors against an fp64 run: the reference's own fp32-vs-fp64 gap is 7e-5 on an MLP

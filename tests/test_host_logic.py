@@ -207,9 +207,11 @@ def test_low_rank_plan_picks_the_cheaper_exact_order():
 
     tracker = PairwiseScoreTracker.__new__(PairwiseScoreTracker)
 
-    def plan(q, o, i, k, b, r, ones, cuda=True):
+    def plan(q, o, i, k, b, r, ones, cuda=True, dtype=torch.bfloat16, factor_dtype=None):
         ip = i + int(ones)
-        return tracker._low_rank_plan(T(shape=(q, o, k)), T(shape=(q, k, ip)), T(shape=(b, r, o), is_cuda=cuda), T(shape=(b, r, i)), ones)
+        fd = factor_dtype or dtype
+        return tracker._low_rank_plan(T(shape=(q, o, k), dtype=fd), T(shape=(q, k, ip), dtype=fd), T(shape=(b, r, o), is_cuda=cuda, dtype=dtype),
+                                      T(shape=(b, r, i), dtype=dtype), ones)
 
     assert plan(100, 1024, 1024, 32, 250, 1, True) == "factored"          # one row per sample: always
     assert plan(872, 768, 768, 64, 512, 128, True) == "expand"             # BERT: narrow layer, large batch, expansion cached
@@ -219,6 +221,10 @@ def test_low_rank_plan_picks_the_cheaper_exact_order():
     assert plan(1000, 14336, 4096, 64, 256, 512, False) == "expand"        # the same layer against 256 sequences: flops win
     assert plan(1000, 14340, 4096, 64, 16, 512, False) == "expand"         # O not a multiple of 8: the GEMM path does not apply
     assert plan(1000, 14336, 4096, 64, 16, 512, False, cuda=False) == "expand"
+    # the sequence form holds its two row products in bf16: only for operands that already are bf16
+    assert plan(1000, 14336, 4096, 64, 16, 512, False, dtype=torch.float32) == "expand"
+    assert plan(1000, 14336, 4096, 64, 16, 512, False, factor_dtype=torch.float32) == "expand"
+    assert plan(100, 1024, 1024, 32, 250, 1, True, dtype=torch.float32) == "factored"   # one row per sample: the fp32 form
 
 
 

@@ -408,3 +408,49 @@ def test_borrowed_factors_and_score_directories_have_the_references_files(tmp_pa
     assert all(torch.equal(analyzer.load_lambda_matrices("h")[k][m], v) for k, d in analyzer.load_lambda_matrices("f").items() for m, v in d.items())
     analyzer.compute_pairwise_scores("s", "h", query, train, per_device_query_batch_size=2, per_device_train_batch_size=4)
     assert {"score_arguments.json", "factor_arguments.json", "pairwise_scores.safetensors"} <= set(os.listdir(analyzer.scores_output_dir("s")))
+
+
+@pytest.mark.parametrize("deduplicate", [True, False])
+def test_layers_that_share_an_input_share_one_eigendecomposition(tmp_path, cpu_engine, monkeypatch, deduplicate):
+    """Query / key / value-like projections consume the same tensor, so their activation covariances are the same matrix (up to
+    the order of the accumulation's atomics): ``perform_eigendecomposition`` solves it once and hands every layer its own copy --
+    what the reference gets from three bit-identical problems (factor/eigen.py:140-224).  Gradient covariances stay apart."""
+    from torch import nn
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, Task, ops, prepare_model
+    from kronfluence_amd.factor import eigen
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v, self.o = nn.Linear(6, 5), nn.Linear(6, 5), nn.Linear(6, 5), nn.Linear(5, 3)
+
+        def forward(self, x):
+            return self.o(torch.tanh(self.q(x)) * torch.tanh(self.k(x)) + self.v(x))
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return (model(batch[0]) - batch[1]).square().sum()
+
+        def compute_measurement(self, batch, model):
+            return self.compute_train_loss(batch, model)
+
+    monkeypatch.setattr(eigen, "DEDUPLICATE_COVARIANCES", deduplicate)
+    solved = []
+    real = ops.eigh
+    monkeypatch.setattr(ops, "eigh", lambda cov, *a, **k: (solved.append(tuple(cov.shape)), real(cov, *a, **k))[1])
+    torch.manual_seed(0)
+    task = T()
+    model = prepare_model(Attn(), task)
+    analyzer = Analyzer("t", model, task, output_dir=str(tmp_path), disable_tqdm=True)
+    gen = torch.Generator().manual_seed(1)
+    train = data.TensorDataset(torch.randn(40, 6, generator=gen), torch.randn(40, 3, generator=gen))
+    analyzer.fit_all_factors("f", train, per_device_batch_size=8, factor_args=FactorArguments(use_empirical_fisher=True))
+    # 4 layers x 2 sides = 8 problems; q, k, v share their 7 x 7 activation covariance
+    assert len(solved) == (6 if deduplicate else 8) and solved.count((7, 7)) == (1 if deduplicate else 3)
+    eig = analyzer.load_eigendecomposition("f")
+    for name in ("k", "v"):
+        assert torch.equal(eig["activation_eigenvectors"][name], eig["activation_eigenvectors"]["q"])
+        assert torch.equal(eig["activation_eigenvalues"][name], eig["activation_eigenvalues"]["q"])
+        assert not torch.equal(eig["gradient_eigenvalues"][name], eig["gradient_eigenvalues"]["q"])

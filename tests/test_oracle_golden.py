@@ -176,3 +176,19 @@ def test_oracle_strategies_and_self_scores_match_reference(kind, strategy):
     if strategy == "ekfac":
         measured = engine.self_scores(fx.batches(train, spec.train_batch), loss, eig, lam, None, measure_fn=measure)
         assert _relerr(measured, gold["self_measurement"]) <= tol
+
+
+def test_low_rank_contraction_equals_the_dense_one_on_the_product_of_the_factors():
+    """oracle.linear_pairwise_score_low_rank (module/linear.py:83-99) against oracle.linear_pairwise_score with P_q = L_q R_q, in
+    fp64: one row per sample and sequences, with and without a bias column -- the identity bench.py's C5 parity figure rests on."""
+    gen = torch.Generator().manual_seed(0)
+    q, o, i, k, b, t = 3, 7, 5, 2, 4, 6
+    for has_bias in (False, True):
+        left = torch.randn(q, o, k, generator=gen, dtype=torch.float64)
+        right = torch.randn(q, k, i + int(has_bias), generator=gen, dtype=torch.float64)
+        for shape in ((b,), (b, t)):
+            a = torch.randn(*shape, i, generator=gen, dtype=torch.float64)
+            g = torch.randn(*shape, o, generator=gen, dtype=torch.float64)
+            dense = ref.linear_pairwise_score(left @ right, a, g, has_bias)
+            low = ref.linear_pairwise_score_low_rank(left, right, a, g, has_bias)
+            assert low.shape == (q, b) and float((low - dense).abs().max()) <= 1e-12 * float(dense.abs().max())

@@ -4,6 +4,7 @@
 #             LDS images (tools/tn_gemm_test.py), the new kernel tests, tools/r05_ab.py ab under the kernel trace, and the PMC replays
 #             of the transformer entry points (before: KF_TN=0, after: KF_TN=1)
 #   check2    the persistent K-major gradient kernel: tests, A/B, counters, bounded GPT-2 / BERT bench lines
+#   check3    re-validation, query passes, 4-block C5 slice with parity, 8 ranks over gloo, GPT-2 100 000 x 2 000
 #   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -69,6 +70,22 @@ check2)
     python tools/bench_digest.py gpurun_out/r05_check2_gpt2.json || tail -c 2000 gpurun_out/r05_check2_gpt2.log
     ( timeout 600 python bench.py --workload bert_base --n-train 16384 --n-fit 2048 --warm-n-train 1024 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_check2_bert.json 2> gpurun_out/r05_check2_bert.log
     python tools/bench_digest.py gpurun_out/r05_check2_bert.json || tail -c 2000 gpurun_out/r05_check2_bert.log
+    ;;
+check3)
+    # folded bias columns (re-validation), query passes, multi-block C5 slice with parity, 8 ranks over gloo on one GPU, configs[3] at
+    # its stated size
+    ( timeout 900 python -m pytest tests/test_ops_gpu.py tests/test_layer_shapes_gpu.py -q -k "k_major or sequence_rows or rows_v2 or two_segments or layer_shape" --durations=5 ) > gpurun_out/r05_check3_ops.log 2>&1
+    tail -6 gpurun_out/r05_check3_ops.log
+    ( timeout 900 python -m pytest tests/test_configs_gpu.py -q -k "query_passes or plan_takes or low_rank or pairs" -s --durations=5 ) > gpurun_out/r05_check3_configs.log 2>&1
+    grep -v "^W0\|amdgpu.ids" gpurun_out/r05_check3_configs.log | tail -12
+    ( KF_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 8 --n-train 1003 --n-query 37 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_eight_ranks_gloo_resnet9.txt 2>&1
+    grep "^{" gpurun_out/r05_eight_ranks_gloo_resnet9.txt | python -c "import json,sys; r=json.loads(sys.stdin.readline()); print('8 ranks gloo resnet9', r['value'], r['n_gpus'], json.dumps(r['exchanges'])[:900])" || tail -5 gpurun_out/r05_eight_ranks_gloo_resnet9.txt
+    ( KF_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --workload gpt2_small --n-train 67 --n-query 19 --n-fit 35 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_eight_ranks_gloo_gpt2.txt 2>&1
+    grep "^{" gpurun_out/r05_eight_ranks_gloo_gpt2.txt | python -c "import json,sys; r=json.loads(sys.stdin.readline()); print('8 ranks gloo gpt2', r['value'], r['n_gpus'], json.dumps(r['exchanges'])[:900])" || tail -5 gpurun_out/r05_eight_ranks_gloo_gpt2.txt
+    ( timeout 900 python bench.py --workload llama_block --blocks 4 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bench_llama_4blocks.json 2> gpurun_out/r05_bench_llama_4blocks.log
+    python tools/bench_digest.py gpurun_out/r05_bench_llama_4blocks.json || tail -c 2000 gpurun_out/r05_bench_llama_4blocks.log
+    ( timeout 1500 python bench.py --workload gpt2_small --n-train 100000 --n-query 2000 --n-fit 2048 --warm-n-train 512 --busy-n-train 2048 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bench_gpt2_full_100k_x_2000.json 2> gpurun_out/r05_bench_gpt2_full_100k_x_2000.log
+    python tools/bench_digest.py gpurun_out/r05_bench_gpt2_full_100k_x_2000.json || tail -c 2000 gpurun_out/r05_bench_gpt2_full_100k_x_2000.log
     ;;
 pmc)
     for w in gpt2_small bert_base; do
