@@ -78,7 +78,7 @@ check3)
     tail -6 gpurun_out/r05_check3_ops.log
     ( timeout 900 python -m pytest tests/test_configs_gpu.py -q -k "query_passes or plan_takes or low_rank or pairs" -s --durations=5 ) > gpurun_out/r05_check3_configs.log 2>&1
     grep -v "^W0\|amdgpu.ids" gpurun_out/r05_check3_configs.log | tail -12
-    ( KF_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 8 --n-train 1003 --n-query 37 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_eight_ranks_gloo_resnet9.txt 2>&1
+    ( KF_DIST_BACKEND=gloo timeout 600 python bench.py --gpus 8 --n-train 1003 --n-query 37 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 --no-miopen-find ) > gpurun_out/r05_eight_ranks_gloo_resnet9.txt 2>&1
     grep "^{" gpurun_out/r05_eight_ranks_gloo_resnet9.txt | python -c "import json,sys; r=json.loads(sys.stdin.readline()); print('8 ranks gloo resnet9', r['value'], r['n_gpus'], json.dumps(r['exchanges'])[:900])" || tail -5 gpurun_out/r05_eight_ranks_gloo_resnet9.txt
     ( KF_DIST_BACKEND=gloo timeout 900 python bench.py --gpus 8 --workload gpt2_small --n-train 67 --n-query 19 --n-fit 35 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_eight_ranks_gloo_gpt2.txt 2>&1
     grep "^{" gpurun_out/r05_eight_ranks_gloo_gpt2.txt | python -c "import json,sys; r=json.loads(sys.stdin.readline()); print('8 ranks gloo gpt2', r['value'], r['n_gpus'], json.dumps(r['exchanges'])[:900])" || tail -5 gpurun_out/r05_eight_ranks_gloo_gpt2.txt
