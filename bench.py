@@ -596,7 +596,20 @@ def _device_busy(step: Callable[[int], object], count: int) -> Optional[dict]:
                 model += us
                 launches_model += e.count
         busy = (ours + model + copies) * 1e-6
+        # where the device waits: idle gaps (> 20 us) between consecutive device activities, summed by the activity that PRECEDES the gap
+        spans = sorted((e.time_range.start, e.time_range.end, e.name) for e in prof.events() if e.device_type == DeviceType.CUDA)
+        gaps: Dict[str, List[float]] = {}
+        frontier, last = None, ""
+        for start, end, name in spans:
+            if frontier is not None and start - frontier > 20.0:
+                gaps.setdefault(last, []).append(start - frontier)
+            if frontier is None or end > frontier:
+                frontier, last = end, name
+        top = sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:6]
+        gap_total = sum(sum(v) for v in gaps.values()) * 1e-6
         return {"n_train": count, "wall_s": wall, "kf_kernel_s": ours * 1e-6, "model_kernel_s": model * 1e-6, "copy_s": copies * 1e-6,
+                "idle_gaps_over_20us_s": gap_total,
+                "largest_idle_after": [{"after": k.replace("(anonymous namespace)::", "").split("(")[0][:70], "gaps": len(v), "seconds": sum(v) * 1e-6} for k, v in top],
                 "kf_kernel_launches": launches_ours, "model_kernel_launches": launches_model,
                 "device_busy_frac": busy / wall, "idle_frac": max(0.0, 1.0 - busy / wall),
                 "kf_kernel_frac": ours * 1e-6 / wall, "model_kernel_frac": model * 1e-6 / wall,

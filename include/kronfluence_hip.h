@@ -107,6 +107,18 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
 int64_t kf_syrk_rows_workspace_bytes(int64_t b, int64_t T, int64_t d_in, int append_ones);
 int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T, int64_t d_in, const void* mask, int mask_dtype,
                       int append_ones, float alpha, void* workspace, int64_t workspace_bytes, void* stream);
+/*
+ * kf_syrk_rows_f32 (ABI 12): C[d,d] += alpha * X'^T X' for FP32 rows X [n, d_in] (contiguous) -- the same mathematics as
+ * kf_syrk_accum on fp32 input (module/linear.py:30-46 + tracker/factor.py:58: rows and their bias one times the mask value, in
+ * fp32) -- on the bf16 MFMA engine: every value is split exactly into three bf16 terms (8 + 8 + 8 significand bits) and the
+ * covariance is the sum of six bf16 products with fp32 accumulation (the three dropped products are below 2^-23 of the result).
+ * LayerNorm outputs under autocast with fp32 factors (BERT) reach the covariance stage in fp32; the exact-fp32 MFMA instruction
+ * behind kf_syrk_accum runs them at 1/16 of the bf16 rate.  mask: nullable [n], KF_I64 / KF_I32 / KF_U8 / KF_F32.  Needs
+ * d_in % 8 == 0, 256 <= d_in < 32768; the row counter is the caller's business.
+ */
+int64_t kf_syrk_rows_f32_workspace_bytes(int64_t n, int64_t d_in);
+int kf_syrk_rows_f32(float* C, int64_t ldc, const void* X, int64_t n, int64_t d_in, const void* mask, int mask_dtype, int append_ones,
+                     float alpha, void* workspace, int64_t workspace_bytes, void* stream);
 int64_t kf_syrk_planes_workspace_bytes(int64_t d);
 int kf_syrk_planes_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t d, int64_t K, float alpha, void* workspace,
                         int64_t workspace_bytes, void* stream);

@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libkronfluence_hip.so"
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 KF_F32, KF_BF16, KF_F16, KF_F64, KF_I64, KF_I32, KF_U8 = range(7)
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "kf_syrk_accum": (_i, [_p, _i64, _p, _i, _i64, _i64, _i64, _i64, _i64, _i64, _p, _i, _i, _f, _p, _p]),
     "kf_syrk_rows_workspace_bytes": (_i64, [_i64, _i64, _i64, _i]),
     "kf_syrk_rows_bf16": (_i, [_p, _i64, _p, _i64, _i64, _i64, _p, _i, _i, _f, _p, _i64, _p]),
+    "kf_syrk_rows_f32_workspace_bytes": (_i64, [_i64, _i64]),
+    "kf_syrk_rows_f32": (_i, [_p, _i64, _p, _i64, _i64, _p, _i, _i, _f, _p, _i64, _p]),
     "kf_syrk_planes_workspace_bytes": (_i64, [_i64]),
     "kf_syrk_planes_bf16": (_i, [_p, _i64, _p, _i64, _i64, _i64, _f, _p, _i64, _p]),
     "kf_conv2d_cov_workspace_bytes": (_i64, [_i64] * 4 + [_i] * 8),

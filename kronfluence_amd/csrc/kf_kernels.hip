@@ -850,7 +850,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 11; }
+int kf_abi_version(void) { return 12; }
 
 const char* kf_status_string(int s) {
     switch (s) {

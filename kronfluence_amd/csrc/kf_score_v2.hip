@@ -1534,6 +1534,9 @@ struct CovTnArgs {
     const uint16_t* X; int64_t ld;   // [KT * 64][ld], columns [0, N) are used
     int N, KT, tiles, kchunk, kblocks, plain_store;
     float* ones_out; int64_t ldc; float alpha;   // non-null: the covariance itself, whose row / column N (the bias one) gets alpha * column sums
+    // split == 1 (fp32 rows as three bf16 planes, kf_syrk_rows_f32): X holds the planes H, M, L one behind the other (plane_stride
+    // elements apart) and the work items run over SIX products  H^T H, H^T M, H^T L, M^T H, M^T M, L^T H  (kblocks per product)
+    int split; int64_t plane_stride;
 };
 
 template <int IMG>
@@ -1545,18 +1548,26 @@ __global__ __launch_bounds__(pptn::THREADS) void cov_gemm_tn_kernel(CovTnArgs a)
     const int L = blockIdx.x, xcd = L & 7, jx = L >> 3;
     const int64_t item = static_cast<int64_t>(xcd) * per_xcd + jx;
     if (jx >= per_xcd || item >= items) return;
-    const int kb = static_cast<int>(item / pairs);
+    int kb = static_cast<int>(item / pairs);
     int t = static_cast<int>(item % pairs), ti = 0;
     while (t >= a.tiles - ti) { t -= a.tiles - ti; ++ti; }
     const int tj = ti + t;
     const int m0 = ti * 256, n0 = tj * 256;
+    int plane_a = 0, plane_b = 0;
+    if (a.split) {   // item = (product, k-tile range of it, tile pair); the sum of the six products is symmetric: upper pairs suffice
+        const int per = a.kblocks / 6, product = kb / per;
+        kb -= product * per;
+        plane_a = product < 3 ? 0 : product < 5 ? 1 : 2;                      // H H H M M L
+        plane_b = product < 3 ? product : product == 3 ? 0 : product == 4;     // H M L H M H
+    }
     const int kt_begin = kb * a.kchunk, kt_end = min(a.KT, kt_begin + a.kchunk);
     if (kt_begin >= kt_end) return;
 
-    const uint16_t* base = a.X + static_cast<int64_t>(kt_begin) * 64 * a.ld;
+    const uint16_t* base_a = a.X + plane_a * a.plane_stride + static_cast<int64_t>(kt_begin) * 64 * a.ld;
+    const uint16_t* base_b = a.X + plane_b * a.plane_stride + static_cast<int64_t>(kt_begin) * 64 * a.ld;
     pptn::Sources src;
-    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return base + min(m0 + f, a.N - 8); }, a.ld,
-                            [&](int f) { return base + min(n0 + f, a.N - 8); }, a.ld);
+    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return base_a + min(m0 + f, a.N - 8); }, a.ld,
+                            [&](int f) { return base_b + min(n0 + f, a.N - 8); }, a.ld);
     f32x16 acc[4][2];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
@@ -1587,6 +1598,63 @@ __global__ __launch_bounds__(pptn::THREADS) void cov_gemm_tn_kernel(CovTnArgs a)
         }
         if (tj == 0 && threadIdx.x == 0)
             atomicAdd(a.ones_out + static_cast<int64_t>(a.N) * a.ldc + a.N, a.alpha * 64.0f * static_cast<float>(kt_end - kt_begin));
+    }
+}
+
+// fp32 rows -> three bf16 planes (round 5, kf_syrk_rows_f32): x = h + m + l EXACTLY (h = bf16(x), m = bf16(x - h), l = bf16(x - h - m):
+// 8 + 8 + 8 significand bits), rows times their mask value first (module/linear.py:39-43, in fp32 as the reference's mul_ on an
+// fp32 activation).  The covariance of the rows is then six bf16 products on the MFMA engine -- H^T H + H^T M + M^T H + M^T M + H^T L +
+// L^T H; the three dropped ones are below 2^-23 of the result, the size of one fp32 rounding -- at ~20x the rate of the exact-fp32
+// MFMA instruction (LayerNorm outputs under autocast with fp32 factors: BERT's query / key / value / intermediate inputs ran at
+// 30 TFLOP/s).  The bias row / column of the covariance -- C[d][j] += alpha sum_r m_r (m_r x_rj), C[d][d] += alpha sum_r m_r^2 -- is
+// summed here in fp32 from the values the kernel reads anyway.  planes: [3][rows_pad][d]; rows >= n are zero.
+struct SplitArgs {
+    uint16_t* planes; int64_t plane_stride;
+    const float* x; int64_t n, rows_pad; int d;
+    const void* mask; int mask_dtype;   // nullable [n]: KF_I64 / KF_I32 / KF_U8 / KF_F32
+    float* C; int64_t ldc; int ones; float alpha;
+};
+
+__global__ __launch_bounds__(256) void split_rows_f32_kernel(SplitArgs a) {
+    // a block: 64 rows x 1024 columns (4 per thread); column sums of the masked rows stay in registers
+    const int c0 = blockIdx.x * 1024 + threadIdx.x * 4;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 64;
+    if (c0 >= a.d) return;   // d % 8 == 0: four columns are entirely in or out
+    float sum[4] = {0.0f, 0.0f, 0.0f, 0.0f}, count = 0.0f;
+    for (int64_t r = r0; r < min(a.rows_pad, r0 + 64); ++r) {
+        float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (r < a.n) {
+            float mv = 1.0f;
+            if (a.mask) mv = a.mask_dtype == F32 ? reinterpret_cast<const float*>(a.mask)[r] : mask_value(a.mask, a.mask_dtype, r);
+            if (mv != 0.0f) {
+                const float4 w = *reinterpret_cast<const float4*>(a.x + r * a.d + c0);
+                v[0] = w.x * mv; v[1] = w.y * mv; v[2] = w.z * mv; v[3] = w.w * mv;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] = fmaf(mv, v[e], sum[e]);
+                count = fmaf(mv, mv, count);
+            }
+        }
+        uint32_t h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const uint32_t hh = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            const float r1a = v[2 * e] - __uint_as_float(hh << 16), r1b = v[2 * e + 1] - __uint_as_float(hh & 0xffff0000u);
+            const uint32_t mm = pack_bf16x2(r1a, r1b);
+            const float r2a = r1a - __uint_as_float(mm << 16), r2b = r1b - __uint_as_float(mm & 0xffff0000u);
+            h[e] = hh; m[e] = mm; l[e] = pack_bf16x2(r2a, r2b);
+        }
+        uint16_t* dst = a.planes + r * a.d + c0;
+        *reinterpret_cast<uint2*>(dst) = uint2{h[0], h[1]};
+        *reinterpret_cast<uint2*>(dst + a.plane_stride) = uint2{m[0], m[1]};
+        *reinterpret_cast<uint2*>(dst + 2 * a.plane_stride) = uint2{l[0], l[1]};
+    }
+    if (a.ones) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(a.C + static_cast<int64_t>(a.d) * a.ldc + c0 + e, a.alpha * sum[e]);
+            atomicAdd(a.C + static_cast<int64_t>(c0 + e) * a.ldc + a.d, a.alpha * sum[e]);
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(a.C + static_cast<int64_t>(a.d) * a.ldc + a.d, a.alpha * count);
     }
 }
 
@@ -1678,10 +1746,13 @@ int launch_cov_v2(CovV2Args& c, CovFinalizeArgs& f, hipStream_t st) {
 }
 
 // covariance of unmasked K-major rows X[rows][ld] (columns [0, N)) on the K-major loop: C[0..N)[0..N) += alpha X^T X
-int launch_cov_tn(float* stage, const uint16_t* X, int64_t ld, int64_t rows, int64_t N, CovFinalizeArgs& f, bool ones, hipStream_t st) {
+int launch_cov_tn(float* stage, const uint16_t* X, int64_t ld, int64_t rows, int64_t N, CovFinalizeArgs& f, bool ones, hipStream_t st,
+                  int64_t split_plane_stride = 0) {
     CovTnArgs c{};
     c.stage = stage; c.X = X; c.ld = ld; c.N = static_cast<int>(N); c.KT = static_cast<int>(rows / 64);
     c.ones_out = ones ? f.out : nullptr; c.ldc = f.ldc; c.alpha = f.alpha;
+    c.split = split_plane_stride != 0; c.plane_stride = split_plane_stride;
+    const int64_t products = c.split ? 6 : 1;
     c.tiles = static_cast<int>(cdiv(N, 256));
     c.np = c.tiles * 256;
     const int64_t pairs = static_cast<int64_t>(c.tiles) * (c.tiles + 1) / 2, steps = c.KT;
@@ -1690,11 +1761,12 @@ int launch_cov_tn(float* stage, const uint16_t* X, int64_t ld, int64_t rows, int
     int64_t kblocks = 1, best = INT64_MAX;
     c.kchunk = c.KT;
     for (int rounds = 1; rounds <= 4; ++rounds) {
-        const int64_t want = std::max<int64_t>(1, std::min<int64_t>({steps, rounds * 256 / pairs, steps / 16}));
+        const int64_t want = std::max<int64_t>(1, std::min<int64_t>({steps, rounds * 256 / (pairs * products), steps / 16}));
         const int64_t chunk = cdiv(steps, want), blocks = cdiv(steps, chunk);
-        const int64_t cost = cdiv(blocks * pairs, 256) * (chunk + 12);
+        const int64_t cost = cdiv(blocks * pairs * products, 256) * (chunk + 12);
         if (cost < best) { best = cost; kblocks = blocks; c.kchunk = static_cast<int>(chunk); }
     }
+    kblocks *= products;   // (split: every product has its own k-tile ranges)
     c.kblocks = static_cast<int>(kblocks);
     c.plain_store = kblocks == 1;
     const dim3 grid(static_cast<unsigned>(8 * cdiv(kblocks * pairs, 8)));
@@ -2074,6 +2146,26 @@ int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_til
     g.M = static_cast<int>(O); g.N = static_cast<int>(c.Ipp); g.K = static_cast<int>(c.Pp); g.batch = static_cast<int>(b);
     g.conv = 1; g.C = static_cast<int>(c.Cp); g.k2 = k2; g.O2 = static_cast<int>(c.O2p); g.s1 = s1; g.d1 = d1; g.s2 = s2; g.d2 = d2;
     g.Wq = static_cast<int>(c.Wq); g.plane = static_cast<int>(c.Hp * c.Wq); g.phase_stride = b * c.Cp * c.Hp * c.Wq;
+    // KF_CONV_CHUNKS = n (measurements only: profiles/r05_conv_chunk_pipeline_negative.log): the gradient -> score hand-over in n
+    // chunks of output channels through ONE chunk-sized region of the workspace, so that a chunk written by the gradient kernel is
+    // still in the 256 MB Infinity Cache when the score GEMM reads it.  Chunk boundaries are whole k-tiles (o_lo * Ipp % 64 == 0).
+    int chunks_env = 1;
+    if (const char* e = getenv("KF_CONV_CHUNKS")) chunks_env = std::max(1, atoi(e));
+    if (chunks_env > 1) {
+        int64_t align_o = 1;
+        while ((align_o * c.Ipp) % 64 != 0) align_o *= 2;
+        const int64_t per = cdiv(cdiv(O, chunks_env), align_o) * align_o;
+        for (int64_t o_lo = 0; o_lo < O; o_lo += per) {
+            const int64_t o_n = std::min<int64_t>(per, O - o_lo), kt0 = o_lo * c.Ipp / 64;
+            PsgV2Args gc = g;
+            gc.A = gsrc + o_lo * c.Pp; gc.M = static_cast<int>(o_n); gc.out = psg;   // every chunk through the same region
+            const int rc = launch_psg_v2(gc, st);
+            if (rc != KF_OK) return rc;
+            const int rs = launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled) + kt0 * Q * 64, psg, Q, b, o_n * c.Ipp, scale, st);
+            if (rs != KF_OK) return rs;
+        }
+        return KF_OK;
+    }
     int rc = launch_psg_v2(g, st);
     if (rc != KF_OK) return rc;
     return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, c.D, scale, st);
@@ -2303,6 +2395,32 @@ int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T
     CovFinalizeArgs f{};
     f.out = C; f.ldc = ldc; f.d = static_cast<int>(d); f.conv = 0; f.alpha = alpha;
     return launch_cov_v2(c, f, st);
+}
+
+int64_t kf_syrk_rows_f32_workspace_bytes(int64_t n, int64_t d_in) {
+    const int64_t rows_pad = cdiv(n, 64) * 64;
+    return align256(3 * 2 * rows_pad * d_in) + cov_stage_bytes(d_in);
+}
+
+int kf_syrk_rows_f32(float* C, int64_t ldc, const void* X, int64_t n, int64_t d_in, const void* mask, int mask_dtype, int append_ones,
+                     float alpha, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!C || !X || n < 0 || d_in <= 0) return KF_ERR_INVALID_ARGUMENT;
+    if (d_in % 8 != 0 || d_in < 256 || d_in >= 32768 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || n >= (1LL << 30)) return KF_ERR_INVALID_ARGUMENT;
+    if (mask && mask_dtype != KF_I64 && mask_dtype != KF_I32 && mask_dtype != KF_U8 && mask_dtype != KF_F32) return KF_ERR_UNSUPPORTED_DTYPE;
+    if (!workspace || workspace_bytes < kf_syrk_rows_f32_workspace_bytes(n, d_in)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (n == 0) return KF_OK;
+    if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
+    hipStream_t st = as_stream(stream);
+    const int64_t rows_pad = cdiv(n, 64) * 64, plane = rows_pad * d_in;
+    SplitArgs sp{};
+    sp.planes = reinterpret_cast<uint16_t*>(workspace); sp.plane_stride = plane;
+    sp.x = reinterpret_cast<const float*>(X); sp.n = n; sp.rows_pad = rows_pad; sp.d = static_cast<int>(d_in);
+    sp.mask = mask; sp.mask_dtype = mask_dtype; sp.C = C; sp.ldc = ldc; sp.ones = append_ones ? 1 : 0; sp.alpha = alpha;
+    hipLaunchKernelGGL(split_rows_f32_kernel, dim3(static_cast<unsigned>(cdiv(d_in, 1024)), static_cast<unsigned>(rows_pad / 64)), dim3(256), 0, st, sp);
+    CovFinalizeArgs f{};
+    f.out = C; f.ldc = ldc; f.d = static_cast<int>(d_in); f.conv = 0; f.alpha = alpha;
+    float* stage = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(workspace) + align256(3 * 2 * plane));
+    return launch_cov_tn(stage, sp.planes, d_in, rows_pad, d_in, f, false, st, plane);
 }
 
 int64_t kf_syrk_planes_workspace_bytes(int64_t d) { return cov_stage_bytes(d); }

@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes
 import math
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -122,6 +123,34 @@ def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Ten
     return True
 
 
+# fp32 rows of at least this many rows go through the exact three-term bf16 split (kf_syrk_rows_f32); KF_COV_F32_SPLIT=0: A/B, fallback
+COV_F32_SPLIT_MIN_ROWS = 2048
+
+
+def _syrk_rows_f32(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor], has_bias: bool, alpha: float) -> bool:
+    """fp32 ``[..., d]`` rows (LayerNorm outputs under autocast with fp32 factors) on the bf16 MFMA engine through an EXACT split into
+    three bf16 terms (kf_syrk_rows_f32: six bf16 products, fp32 accumulation; the dropped products are below one fp32 rounding);
+    ``False`` when the shape / dtype is not eligible -- the exact-fp32 MFMA engine of ``syrk_accum`` takes those."""
+    d_in = x.shape[-1]
+    n = x.numel() // max(d_in, 1)
+    if not (x.is_cuda and x.dtype == torch.float32 and d_in % 8 == 0 and 256 <= d_in < COV_STAGED_MAX_DIM and n >= COV_F32_SPLIT_MIN_ROWS
+            and x.data_ptr() % 16 == 0 and os.environ.get("KF_COV_F32_SPLIT", "1") != "0"
+            and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool, torch.float32))):
+        return False
+    mask = _contig(mask) if mask is not None else None
+    ws_bytes = nat.lib().kf_syrk_rows_f32_workspace_bytes(n, d_in)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
+    d = d_in + int(has_bias)
+    with _Timed("syrk_accum", x.device, float(n) * d * (d + 1), float(n) * d_in * 4):
+        nat.check(
+            nat.lib().kf_syrk_rows_f32(cov.data_ptr(), cov.shape[1], x.data_ptr(), n, d_in, _ptr(mask),
+                                       nat.dtype_code(mask.dtype) if mask is not None else 0, int(has_bias), alpha, ws.data_ptr(),
+                                       ws_bytes, nat.stream_ptr(x.device)),
+            "kf_syrk_rows_f32",
+        )
+    return True
+
+
 def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor],
                           has_bias: bool) -> None:
     """Flatten + mask + ones column + ``addmm_`` of module/linear.py:30-46 and tracker/factor.py:58, fused."""
@@ -130,7 +159,7 @@ def linear_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tenso
     n = x.numel() // d_in
     if mask is not None and mask.numel() != n:
         mask = None  # linear.py:33 -- the mask applies only when it matches the row count
-    if _syrk_rows_bf16(cov, x, mask, has_bias, 1.0):
+    if _syrk_rows_bf16(cov, x, mask, has_bias, 1.0) or _syrk_rows_f32(cov, x, mask, has_bias, 1.0):
         count.add_(mask.sum().to(torch.int64) if mask is not None else n)
         return
     if mask is not None and mask.dtype not in (torch.float32, torch.int64, torch.uint8, torch.bool):
@@ -145,7 +174,7 @@ def linear_gradient_cov(cov: torch.Tensor, count: torch.Tensor, g: torch.Tensor,
     g = _contig(g, align=_vector_engines(g))
     d = g.shape[-1]
     n = g.numel() // d
-    if not _syrk_rows_bf16(cov, g, None, False, alpha):
+    if not (_syrk_rows_bf16(cov, g, None, False, alpha) or _syrk_rows_f32(cov, g, None, False, alpha)):
         syrk_accum(cov, g, n, d, max(n, 1), 0, d, 1, None, False, alpha, None)
     if mask is not None and mask.numel() == n:
         count.add_(mask.sum().to(torch.int64))

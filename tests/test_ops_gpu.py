@@ -1229,3 +1229,47 @@ def test_score_gemm_mixed_row_tiling(ops, q, b, mixed, monkeypatch):
         scores = torch.zeros(q, b, device=DEV)
         ops.pairwise_score(scores, 0, TiledQueries(ps, 0), gs, as_, False)
         assert rel(scores, want_s) <= 1e-5, (short, rel(scores, want_s))
+
+
+@pytest.mark.parametrize("b,t,d,bias,mask_kind", [(32, 128, 768, True, None), (20, 250, 264, False, "int64"), (3, 700, 1024, True, "float32"),
+                                                 (16, 512, 3072, True, "bool"), (9, 256, 256, True, "int64")])
+def test_fp32_rows_covariance_three_term_split(ops, b, t, d, bias, mask_kind, monkeypatch):
+    """kf_syrk_rows_f32: fp32 rows (LayerNorm outputs under autocast with fp32 factors: BERT) through an EXACT split into three bf16
+    terms and six bf16 MFMA products (module/linear.py:30-46 + tracker/factor.py:58).  Against the fp64 oracle at the fp32 factor
+    tolerance -- including a constant column whose low significand bits would add up coherently if a term were lost, 0/1 and
+    weighted masks (rows AND their bias one times the mask value, in fp32), row counts that are no multiple of 64 -- and against the
+    exact-fp32 MFMA engine (``KF_COV_F32_SPLIT=0``)."""
+    x = _rand(b, t, d)
+    x[..., 0] = 1.2345678
+    x[..., 1] = x[..., 1] * 1e-3 + 0.3333333
+    mask = None
+    if mask_kind is not None:
+        gen = torch.Generator().manual_seed(3)
+        if mask_kind == "float32":
+            mask = torch.rand(b, t, generator=gen) * (torch.rand(b, t, generator=gen) < 0.8)
+        else:
+            lengths = torch.randint(1, t + 1, (b,), generator=gen)
+            mask = (torch.arange(t)[None] < lengths[:, None]).to(getattr(torch, mask_kind))
+    flat, count = ref.linear_flat_activation(x.double(), None if mask is None else mask.double(), bias)
+    want = torch.zeros(d + bias, d + bias, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    xd, md = x.to(DEV), None if mask is None else mask.to(DEV)
+
+    def run():
+        cov, cnt = torch.zeros(d + bias, d + bias, device=DEV), torch.zeros(1, dtype=torch.int64, device=DEV)
+        if bias:
+            ops.linear_activation_cov(cov, cnt, xd, md, True)
+        else:
+            ops.linear_gradient_cov(cov, cnt, xd, md, 1.0)
+        return cov, cnt
+
+    cov, cnt = run()
+    if not bias:   # gradient rows are never masked, only counted (linear.py:48-54)
+        want = x.double().flatten(0, 1).t() @ x.double().flatten(0, 1)
+    assert rel(cov, want) <= 2e-6, rel(cov, want)   # well inside the fp32 factor tolerance (2e-5)
+    assert rel(cov, cov.t()) <= 1e-6
+    if mask is not None and mask.dtype != torch.float32:
+        assert int(cnt) == int(mask.sum())
+    monkeypatch.setenv("KF_COV_F32_SPLIT", "0")
+    exact, _ = run()
+    assert rel(cov, exact) <= 2e-6, rel(cov, exact)

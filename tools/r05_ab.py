@@ -5,6 +5,7 @@
                           output gradients) on the K-contiguous path (``KF_TN=0``: transpose_rows + the round-3 / 4 kernels) and
                           on the K-major loop (``KF_TN=1``) with each LDS image; HIP events on the launch stream; results compared.
                           Run it under ``rocprofv3 --kernel-trace --stats`` for the per-kernel averages.
+    ab convchunks         the convolution score entry point with its gradient -> score hand-over in 1 / 2 / 3 / 4 / 6 chunks (KF_CONV_CHUNKS)
     replay <workload> <entry> <meta.json>
                           the calls ONE train batch of the workload makes to one entry point (score | cov | lambda), one call per
                           distinct layer shape weighted as the model has them, for ``rocprofv3 --pmc`` passes: every dispatch of the
@@ -124,7 +125,69 @@ def cov_ab():
     set_tn(1)
 
 
+RESNET9 = [  # (name, cin, cout, k, stride, padding, H): the eight convolutions of bench.py's ResNet-9
+    ("conv0 3->64", 3, 64, 3, 1, 1, 32), ("conv1 64->128 k5 s2", 64, 128, 5, 2, 2, 32), ("conv2 128->128", 128, 128, 3, 1, 1, 16),
+    ("conv3 128->128", 128, 128, 3, 1, 1, 16), ("conv4 128->256", 128, 256, 3, 1, 1, 16), ("conv5 256->256 8x8", 256, 256, 3, 1, 1, 8),
+    ("conv6 256->256 8x8", 256, 256, 3, 1, 1, 8), ("conv7 256->128 6x6", 256, 128, 3, 1, 0, 8),
+]
+
+
+def conv_case(cin, cout, k, s, p, h, q=1000, b=1000):
+    from torch import nn
+
+    conv = nn.Conv2d(cin, cout, k, stride=s, padding=p, bias=False)
+    x = rand(b, cin, h, h)
+    o = (h + 2 * p - k) // s + 1
+    g = rand(b, cout, o, o)
+    ip = cin * k * k
+    tiled = TiledQueries(rand(q, cout, ip), 0, conv_channels=cin)
+    flops = 2.0 * q * b * cout * ip + 2.0 * b * o * o * cout * ip
+    nbytes = b * (cout * o * o + cin * h * h) * 2 + q * cout * ip * 2 + 2.0 * q * b * 4
+    return conv, x, g, tiled, flops, nbytes
+
+
+def conv_chunks():
+    """the convolution gradient -> score hand-over in D-chunks through one chunk-sized workspace region
+    (``KF_CONV_CHUNKS``), so that a chunk is still in the 256 MB Infinity Cache when the score GEMM reads it."""
+    print("== kf_pairwise_score_conv2d, Q = b = 1000: gradient -> score hand-over in n chunks of output channels (ms per call)")
+    total = {n: 0.0 for n in (1, 2, 3, 4, 6)}
+    for name, cin, cout, k, s, p, h in RESNET9:
+        conv, x, g, tiled, flops, _ = conv_case(cin, cout, k, s, p, h)
+        line, outs = f"  {name:22s}", {}
+        for n in total:
+            os.environ["KF_CONV_CHUNKS"] = str(n)
+            sc = torch.zeros(1000, 1000, device=DEV)
+            t = timed(lambda: ops.pairwise_score_conv2d(sc, 0, tiled, g, x, conv))
+            sc.zero_()
+            ops.pairwise_score_conv2d(sc, 0, tiled, g, x, conv)
+            outs[n] = sc.clone()
+            total[n] += t
+            line += f" {n}: {t:6.3f} ({flops / t / 1e9:4.0f} TF/s) |"
+        d = max(float((outs[n] - outs[1]).norm() / outs[1].norm()) for n in outs)
+        print(f"{line} max rel diff {d:.1e}{'' if d < 1e-4 else '   <-- MISMATCH'}", flush=True)
+        del x, g, tiled
+        torch.cuda.empty_cache()
+    os.environ.pop("KF_CONV_CHUNKS", None)
+    print("  all eight layers: " + ", ".join(f"{n} chunk(s) {t:.3f} ms" for n, t in total.items()))
+
+
 def replay(workload, entry, meta_path):
+    if workload == "resnet9":   # one kf_pairwise_score_conv2d call per convolution (KF_CONV_CHUNKS from the environment)
+        calls, alg_bytes, alg_flops = 0, 0.0, 0.0
+        for _, cin, cout, k, s, p, h in RESNET9:
+            conv, x, g, tiled, flops, nbytes = conv_case(cin, cout, k, s, p, h)
+            sc = torch.zeros(1000, 1000, device=DEV)
+            ops.pairwise_score_conv2d(sc, 0, tiled, g, x, conv)
+            torch.cuda.synchronize()
+            calls += 1
+            alg_bytes += nbytes
+            alg_flops += flops
+            del x, g, tiled
+            torch.cuda.empty_cache()
+        with open(meta_path, "w", encoding="utf-8") as handle:
+            json.dump({"workload": workload, "entry": entry, "calls": calls, "algorithmic_bytes_per_call": alg_bytes / calls,
+                       "algorithmic_flops_per_call": alg_flops / calls, "KF_CONV_CHUNKS": os.environ.get("KF_CONV_CHUNKS", "1")}, handle)
+        return
     spec = LAYERS[workload]
     t_len, q = spec["T"], spec["q"]
     calls, alg_bytes, alg_flops = 0, 0.0, 0.0
@@ -192,7 +255,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "replay":
         replay(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
-        which = [w for w in sys.argv[1:] if w in ("score", "cov")] or ["score", "cov"]
+        which = [w for w in sys.argv[1:] if w in ("score", "cov", "convchunks")] or ["score", "cov"]
+        if "convchunks" in which:
+            conv_chunks()
         if "score" in which:
             score_ab()
         if "cov" in which:
