@@ -454,3 +454,54 @@ def test_layers_that_share_an_input_share_one_eigendecomposition(tmp_path, cpu_e
         assert torch.equal(eig["activation_eigenvectors"][name], eig["activation_eigenvectors"]["q"])
         assert torch.equal(eig["activation_eigenvalues"][name], eig["activation_eigenvalues"]["q"])
         assert not torch.equal(eig["gradient_eigenvalues"][name], eig["gradient_eigenvalues"]["q"])
+
+
+def test_layers_that_share_an_input_share_its_covariance_increment(tmp_path, cpu_engine, monkeypatch):
+    """CovarianceTracker: the query / key / value-like projections of the model above are handed the same tensor object, so from
+    the second batch on the first of them forms the increment ``X'^T X'`` once and the other two add it (reference
+    tracker/factor.py:98-112 computes three identical ``addmm_``).  Kernel calls are counted; the factors equal the un-shared run's."""
+    from torch import nn
+    from torch.utils import data
+
+    from kronfluence_amd import Analyzer, FactorArguments, Task, ops, prepare_model
+    from kronfluence_amd.module.tracker.factor import CovarianceTracker
+
+    class Attn(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.q, self.k, self.v, self.o = nn.Linear(6, 5), nn.Linear(6, 5), nn.Linear(6, 5, bias=False), nn.Linear(5, 3)
+
+        def forward(self, x):
+            return self.o(torch.tanh(self.q(x)) * torch.tanh(self.k(x)) + self.v(x))
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return (model(batch[0]) - batch[1]).square().sum()
+
+        def compute_measurement(self, batch, model):
+            return self.compute_train_loss(batch, model)
+
+    gen = torch.Generator().manual_seed(1)
+    train = data.TensorDataset(torch.randn(40, 6, generator=gen), torch.randn(40, 3, generator=gen))
+    results = {}
+    for share in (True, False):
+        monkeypatch.setattr(CovarianceTracker, "SHARE_INPUT_INCREMENTS", share)
+        calls = []
+        real = ops.linear_activation_cov
+        monkeypatch.setattr(ops, "linear_activation_cov", lambda cov, *a, **k: (calls.append(tuple(cov.shape)), real(cov, *a, **k))[1])
+        torch.manual_seed(0)
+        task = T()
+        analyzer = Analyzer("t", prepare_model(Attn(), task), task, output_dir=str(tmp_path / str(share)), disable_tqdm=True)
+        analyzer.fit_covariance_matrices("f", train, per_device_batch_size=8, factor_args=FactorArguments(use_empirical_fisher=True))
+        monkeypatch.setattr(ops, "linear_activation_cov", real)
+        results[share] = (calls, analyzer.load_covariance_matrices("f"))
+    shared_calls, plain_calls = results[True][0], results[False][0]
+    # 5 batches x 4 layers un-shared; shared: the first batch in full, then q (7 x 7, leader), v's bias-free 6 x 6 and o per batch --
+    # k follows q; v has no bias column, so its increment is a different matrix and is never shared
+    assert len(plain_calls) == 20 and len(shared_calls) == 4 + 4 * 3, (len(plain_calls), len(shared_calls))
+    for name, want in results[False][1]["activation_covariance"].items():
+        got = results[True][1]["activation_covariance"][name]
+        assert float((got - want).abs().max()) <= 1e-5 * float(want.abs().max()), name
+    for key in ("num_activation_covariance_processed", "gradient_covariance", "num_gradient_covariance_processed"):
+        for name, want in results[False][1][key].items():
+            assert torch.equal(results[True][1][key][name], want), (key, name)
