@@ -562,9 +562,9 @@ def _library_kernel_pattern():
     return re.compile(r"^(?:void )?(?:\(anonymous namespace\)::|kf::)(?:" + "|".join(sorted(names)) + r")\b")
 
 
-def _device_busy(step: Callable[[int], object], count: int) -> Optional[dict]:
+def _device_busy(step: Callable[[int, int], object], count: int, queries: int) -> Optional[dict]:
     """Where a pairwise step spends its wall time on the device: one step over the first ``count`` train samples
-    un-profiled (wall clock), the same step again under the torch profiler (device activity only: roctracer kernel records), kernel
+    and the first ``queries`` queries un-profiled (wall clock), the same step again under the torch profiler (device activity only: roctracer kernel records), kernel
     durations summed by owner.  Everything runs on one stream, so the sum IS the busy time: ``device_busy_frac`` = all kernels and
     copies / wall; ``idle_frac`` = the rest -- the GPU waiting for the host (Python hooks, autograd, ctypes launches).  Outside
     the timed region; MIOpen / hipBLASLt heuristics are warm by then."""
@@ -575,11 +575,11 @@ def _device_busy(step: Callable[[int], object], count: int) -> Optional[dict]:
         pattern = _library_kernel_pattern()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        step(count)
+        step(count, queries)
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            step(count)
+            step(count, queries)
             torch.cuda.synchronize()
         ours = model = copies = 0.0
         launches_ours = launches_model = 0
@@ -607,7 +607,7 @@ def _device_busy(step: Callable[[int], object], count: int) -> Optional[dict]:
                 frontier, last = end, name
         top = sorted(gaps.items(), key=lambda kv: -sum(kv[1]))[:6]
         gap_total = sum(sum(v) for v in gaps.values()) * 1e-6
-        return {"n_train": count, "wall_s": wall, "kf_kernel_s": ours * 1e-6, "model_kernel_s": model * 1e-6, "copy_s": copies * 1e-6,
+        return {"n_train": count, "n_query": queries, "wall_s": wall, "kf_kernel_s": ours * 1e-6, "model_kernel_s": model * 1e-6, "copy_s": copies * 1e-6,
                 "idle_gaps_over_20us_s": gap_total,
                 "largest_idle_after": [{"after": k.replace("(anonymous namespace)::", "").split("(")[0][:70], "gaps": len(v), "seconds": sum(v) * 1e-6} for k, v in top],
                 "kf_kernel_launches": launches_ours, "model_kernel_launches": launches_model,
@@ -689,13 +689,13 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         idx = list(DistributedSamplerWithStack(range(count), world, rank)) if world > 1 else None
         return ResidentLoader(subset, spec["train_batch"], idx)
 
-    def query_loader():
+    def query_loader(count: int = n_query):
         if world > 1:
             from torch.utils.data import DistributedSampler
 
-            idx = list(DistributedSampler(range(n_query), world, rank, shuffle=False, drop_last=False))
+            idx = list(DistributedSampler(range(count), world, rank, shuffle=False, drop_last=False))
         else:
-            idx = None
+            idx = None if count == n_query else list(range(count))
         return ResidentLoader(query, per_dev_q, idx)
 
     # -- factor fit (cov + eigen + lambda), timed per sub-stage.  Every exchange (factor all-reduce, eigenvector
@@ -723,8 +723,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     fit_total = sum(fit_times.values())
 
     # -- pairwise stage: W warm-up steps, K timed steps ------------------------------------------------
-    def step(count: int = n_train):
-        return compute_pairwise_scores_with_loaders(factors, model, state, task, query_loader(), per_dev_q,
+    def step(count: int = n_train, queries: int = n_query):
+        return compute_pairwise_scores_with_loaders(factors, model, state, task, query_loader(queries), per_dev_q,
                                                     train_loader(count), sargs, fargs, None)
 
     for _ in range(warmup):
@@ -746,9 +746,13 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     elapsed = time.perf_counter() - t0
     new_segments = torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0
     gc.enable()
+    score_events, ops.EVENT_LOG = ops.EVENT_LOG, None          # the timed region's calls only (the diagnostics below run more steps)
+    score_exchanges, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
     busy = None
     if rank == 0 and world == 1 and os.environ.get("KF_BENCH_BUSY", "1") != "0":
-        busy = _device_busy(step, min(n_train, max(4 * spec["train_batch"], busy_n_train or n_train)))
+        # a MINIATURE step -- at most 16 train batches against at most 4 query batches: the profiler drops device records on long
+        # steps (GPT-2 at 2 048 x 2 000: 28 k of ~60 k kernels came back) -- with both phases of the stage in it
+        busy = _device_busy(step, min(n_train, busy_n_train or 16 * spec["train_batch"]), min(n_query, 4 * per_dev_q))
     parity = None
     if rank == 0 and world == 1 and spec.get("low_rank") and os.environ.get("KF_BENCH_PARITY", "1") != "0":
         parity = _low_rank_parity(model, step, min(n_train, spec["train_batch"]))
@@ -779,8 +783,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    score_events, ops.EVENT_LOG = ops.EVENT_LOG, None
-    score_exchanges, comm.EXCHANGE_LOG = comm.summary(comm.EXCHANGE_LOG), None
+    torch.cuda.synchronize()
     pairs = float(n_query) * float(n_train) * steps
     value = pairs / elapsed
     if rank == 0:

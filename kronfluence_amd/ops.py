@@ -124,7 +124,7 @@ def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Ten
 
 
 # fp32 rows of at least this many rows go through the exact three-term bf16 split (kf_syrk_rows_f32); KF_COV_F32_SPLIT=0: A/B, fallback
-COV_F32_SPLIT_MIN_ROWS = 2048
+COV_F32_SPLIT_MIN_ROWS = 1024
 
 
 def _syrk_rows_f32(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor], has_bias: bool, alpha: float) -> bool:

@@ -790,7 +790,7 @@ def test_low_rank_plan_takes_the_bf16_sequence_form_for_bf16_operands_only():
     from kronfluence_amd.module.tracker.pairwise_score import PairwiseScoreTracker
 
     tracker = PairwiseScoreTracker.__new__(PairwiseScoreTracker)
-    q, o, k, i, b, r = 8, 4096, 64, 4096, 16, 512   # a Llama projection: the factored order is ~3x cheaper by the model
+    q, o, k, i, b, r = 1000, 14336, 64, 4096, 16, 512   # C5's up projection, 16 sequences: the factored order is ~3x cheaper by the model
     for dtype, want in ((torch.bfloat16, "factored"), (torch.float32, "expand")):
         left, right = torch.empty(q, o, k, dtype=dtype, device=DEV), torch.empty(q, k, i, dtype=dtype, device=DEV)
         g, a = torch.empty(b, r, o, dtype=dtype, device=DEV), torch.empty(b, r, i, dtype=dtype, device=DEV)
@@ -799,7 +799,7 @@ def test_low_rank_plan_takes_the_bf16_sequence_form_for_bf16_operands_only():
                                    torch.empty(b, r, o, dtype=torch.bfloat16, device=DEV), torch.empty(b, r, i, dtype=torch.bfloat16, device=DEV), False)
     assert mixed == "expand"
     # one row per sample: the fp32 skinny-GEMM form, whatever the dtype
-    assert tracker._low_rank_plan(torch.empty(q, o, k, device=DEV), torch.empty(q, k, i, device=DEV), torch.empty(b, 1, o, device=DEV),
+    assert tracker._low_rank_plan(torch.empty(8, o, k, device=DEV), torch.empty(8, k, i, device=DEV), torch.empty(b, 1, o, device=DEV),
                                   torch.empty(b, 1, i, device=DEV), False) == "factored"
 
 

@@ -22,7 +22,7 @@ def show(name, r, indent=""):
         else:
             print(f"{indent}  device_busy: busy {busy['device_busy_frac']:.3f} (kf kernels {busy['kf_kernel_frac']:.3f}, model kernels "
                   f"{busy['model_kernel_frac']:.3f}) idle {busy['idle_frac']:.3f} of a {busy['wall_s']:.2f} s step over {busy['n_train']} "
-                  f"train samples; launches kf {busy['kf_kernel_launches']} model {busy['model_kernel_launches']}")
+                  f"train x {busy.get('n_query')} query samples; launches kf {busy['kf_kernel_launches']} model {busy['model_kernel_launches']}")
             for g in busy.get("largest_idle_after", [])[:4]:
                 print(f"{indent}    idle {g['seconds']:.3f} s in {g['gaps']} gaps after {g['after']}")
     if r.get("parity"):

@@ -5,6 +5,7 @@
 #             of the transformer entry points (before: KF_TN=0, after: KF_TN=1)
 #   check2    the persistent K-major gradient kernel: tests, A/B, counters, bounded GPT-2 / BERT bench lines
 #   check3    re-validation, query passes, 4-block C5 slice with parity, 8 ranks over gloo, GPT-2 100 000 x 2 000
+#   check4    fp32-row split, shared covariance increments, conv chunk experiment + counters, 4-block C5 slice, BERT / ResNet-9 lines
 #   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -86,6 +87,30 @@ check3)
     python tools/bench_digest.py gpurun_out/r05_bench_llama_4blocks.json || tail -c 2000 gpurun_out/r05_bench_llama_4blocks.log
     ( timeout 1500 python bench.py --workload gpt2_small --n-train 100000 --n-query 2000 --n-fit 2048 --warm-n-train 512 --busy-n-train 2048 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bench_gpt2_full_100k_x_2000.json 2> gpurun_out/r05_bench_gpt2_full_100k_x_2000.log
     python tools/bench_digest.py gpurun_out/r05_bench_gpt2_full_100k_x_2000.json || tail -c 2000 gpurun_out/r05_bench_gpt2_full_100k_x_2000.log
+    ;;
+check4)
+    # fp32 rows on the bf16 engine, shared-input covariance increments (through the assembled BERT / GPT-2 pipelines), the conv
+    # gradient -> score chunk experiment with counters, the 4-block C5 slice, BERT / ResNet-9 bench lines
+    ( timeout 900 python -m pytest tests/test_ops_gpu.py -q -k "fp32_rows or activation_cov or gradient_cov or sequence_covariance" --durations=5 ) > gpurun_out/r05_check4_ops.log 2>&1
+    tail -6 gpurun_out/r05_check4_ops.log
+    ( timeout 1200 python -m pytest tests/test_configs_gpu.py -q -k "plan_takes or assembled_model or late_layers" -s --durations=5 ) > gpurun_out/r05_check4_configs.log 2>&1
+    grep -v "^W0\|amdgpu.ids" gpurun_out/r05_check4_configs.log | tail -14
+    ( timeout 300 python tools/r05_ab.py convchunks ) > gpurun_out/r05_conv_chunks.log 2>&1
+    grep -v "^W0\|amdgpu.ids" gpurun_out/r05_conv_chunks.log | tail -12
+    for n in 1 3; do
+        export KF_CONV_CHUNKS=$n
+        replay_pmc gpurun_out/r05_pmc_chunks$n resnet9 score
+        unset KF_CONV_CHUNKS
+        ( python tools/pmc_entry_summary.py resnet9 gpurun_out/r05_pmc_resnet9_chunks$n.json gpurun_out/r05_pmc_chunks$n ) > gpurun_out/r05_pmc_chunks${n}_summary.log 2>&1
+        grep "^==" gpurun_out/r05_pmc_chunks${n}_summary.log
+    done
+    find gpurun_out/r05_pmc_chunks1 gpurun_out/r05_pmc_chunks3 -name "*.csv" -size +2M -delete
+    ( timeout 900 python bench.py --workload llama_block --blocks 4 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bench_llama_4blocks.json 2> gpurun_out/r05_bench_llama_4blocks.log
+    python tools/bench_digest.py gpurun_out/r05_bench_llama_4blocks.json || tail -c 2000 gpurun_out/r05_bench_llama_4blocks.log
+    ( timeout 600 python bench.py --workload bert_base --n-train 16384 --n-fit 2048 --warm-n-train 1024 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_check4_bert.json 2> gpurun_out/r05_check4_bert.log
+    python tools/bench_digest.py gpurun_out/r05_check4_bert.json || tail -c 2000 gpurun_out/r05_check4_bert.log
+    ( timeout 600 python bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1 ) > gpurun_out/r05_check4_resnet9.json 2> gpurun_out/r05_check4_resnet9.log
+    python tools/bench_digest.py gpurun_out/r05_check4_resnet9.json || tail -c 2000 gpurun_out/r05_check4_resnet9.log
     ;;
 pmc)
     for w in gpt2_small bert_base; do
