@@ -510,7 +510,7 @@ def _low_rank_parity(model, step: Callable[[int], object], n_sub: int) -> Option
     oracle/ekfac_ref.py, evaluated on the GPU in fp64), summed over layers, and are compared with the scores the pass returns.  The
     checker, outside every timed region."""
     try:
-        from kronfluence_amd.module.tracked_module import TrackedModule
+        from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
         from kronfluence_amd.utils.constants import ACCUMULATED_PRECONDITIONED_GRADIENT_NAME
         from oracle import ekfac_ref as ref
 
@@ -522,8 +522,8 @@ def _low_rank_parity(model, step: Callable[[int], object], n_sub: int) -> Option
 
                 def bwd(grad, x=x, m=m):
                     held = m.storage[ACCUMULATED_PRECONDITIONED_GRADIENT_NAME]
-                    if not isinstance(held, list):
-                        return
+                    if m.current_mode != ModuleMode.PAIRWISE_SCORE or not isinstance(held, list):
+                        return   # (the query passes run the same model: only the train pass is checked)
                     left, right = held
                     g = grad.detach().double()
                     a = x.to(grad.dtype).double()   # the product consumes the activation in the gradient's (autocast) dtype
@@ -854,10 +854,20 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             roofline["traffic"] = traffic.get("kf_pairwise_score_bytes_per_launch")
             roofline["traffic_source"] = traffic.get("source")
             roofline["mfma_util"] = traffic.get("mfma_util")
+            # counter bytes over algorithmic bytes of the SAME calls (the replayed entry points carry their own algorithmic figure: one
+            # train batch against all queries; the timed region's average launch may differ, e.g. BERT's ragged last batch)
+            algorithmic = traffic.get("kf_pairwise_score_algorithmic_bytes_per_launch") or roofline["algorithmic_bytes_per_launch"]
+            if roofline["traffic"] and algorithmic:
+                roofline["traffic_over_algorithmic"] = roofline["traffic"] / algorithmic
         roofline_cov = _event_summary(fit_events.get("syrk_accum", []), peak, "covariance calls: kf_syrk_accum | kf_syrk_rows_bf16 | "
                                       "kf_conv2d_cov_accum | kf_syrk_planes_bf16 (pad / transpose + cov_gemm_v2_kernel + cov_finalize_kernel; "
                                       "algorithmic bytes = one read of the rows handed over)", fit_times["covariance"])
-        if roofline_cov is not None and traffic is not None and traffic.get("cov_gemm_bytes_per_launch") is not None:
+        if roofline_cov is not None and traffic is not None and traffic.get("cov_call_bytes_per_launch") is not None:
+            roofline_cov["traffic"] = traffic["cov_call_bytes_per_launch"]
+            roofline_cov["traffic_over_algorithmic"] = traffic["cov_call_bytes_per_launch"] / traffic["cov_call_algorithmic_bytes_per_launch"]
+            roofline_cov["traffic_source"] = "all kernels of a covariance call (memset + cov_gemm + finalize), per call: " + str(traffic.get("source"))
+            roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
+        elif roofline_cov is not None and traffic is not None and traffic.get("cov_gemm_bytes_per_launch") is not None:
             roofline_cov["traffic"] = traffic["cov_gemm_bytes_per_launch"]
             roofline_cov["traffic_source"] = "the covariance GEMM kernel with the most launches alone (cov_gemm_v3_kernel / cov_gemm_v2_kernel; per launch), same PMC passes as roofline.traffic"
             roofline_cov["mfma_util"] = traffic.get("cov_gemm_mfma_util")
