@@ -6,6 +6,7 @@
 #   check2    the persistent K-major gradient kernel: tests, A/B, counters, bounded GPT-2 / BERT bench lines
 #   check3    re-validation, query passes, 4-block C5 slice with parity, 8 ranks over gloo, GPT-2 100 000 x 2 000
 #   check4    fp32-row split, shared covariance increments, conv chunk experiment + counters, 4-block C5 slice, BERT / ResNet-9 lines
+#   final     the record: full GPU suite + smoke, traces, counters, default bench line, 4-block C5 slice
 #   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -111,6 +112,48 @@ check4)
     python tools/bench_digest.py gpurun_out/r05_check4_bert.json || tail -c 2000 gpurun_out/r05_check4_bert.log
     ( timeout 600 python bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1 ) > gpurun_out/r05_check4_resnet9.json 2> gpurun_out/r05_check4_resnet9.log
     python tools/bench_digest.py gpurun_out/r05_check4_resnet9.json || tail -c 2000 gpurun_out/r05_check4_resnet9.log
+    ;;
+final)
+    # the record of the round on the final sources: full GPU suite + smoke, kernel traces, counter passes (ResNet-9: the bench command
+    # itself; GPT-2 / BERT: the replayed entry points), then -- with those summaries in place -- the default bench line and the
+    # 4-block C5 slice
+    ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r05_pytest_gpu.log 2>&1
+    tail -18 gpurun_out/r05_pytest_gpu.log
+    ( timeout 300 python -c "import __graft_entry__ as g; g.smoke()" ) > gpurun_out/r05_smoke.log 2>&1
+    tail -2 gpurun_out/r05_smoke.log
+    CMD="python $R/bench.py --n-train 4000 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 1"
+    ( cd /tmp && KF_BENCH_BUSY=0 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r05_trace" -- $CMD ) > gpurun_out/r05_trace.log 2>&1
+    find gpurun_out/r05_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r05_resnet9_n4000_kernel_stats.csv \;
+    rm -rf gpurun_out/r05_trace
+    for spec in "fetch FETCH_SIZE" "write WRITE_SIZE" "mfma SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
+        set -- $spec; tag="$1"; shift
+        ( cd /tmp && KF_BENCH_BUSY=0 timeout 400 rocprofv3 --pmc "$@" --output-format csv -d "$R/gpurun_out/r05_pmc_r9_$tag" -- $CMD ) > "gpurun_out/r05_pmc_r9_$tag.log" 2>&1
+    done
+    ( python tools/pmc_summary.py resnet9 profiles/pmc_resnet9.json gpurun_out/r05_pmc_r9_fetch gpurun_out/r05_pmc_r9_write gpurun_out/r05_pmc_r9_mfma ) > gpurun_out/r05_pmc_resnet9_summary.log 2>&1
+    cp profiles/pmc_resnet9.json gpurun_out/r05_pmc_resnet9.json
+    head -c 1500 gpurun_out/r05_pmc_resnet9_summary.log
+    find gpurun_out/r05_pmc_r9_fetch gpurun_out/r05_pmc_r9_write gpurun_out/r05_pmc_r9_mfma -name "*.csv" -size +2M -delete
+    rm -rf gpurun_out/r05_pmc
+    for w in gpt2_small bert_base; do
+        for e in score cov lambda; do replay_pmc gpurun_out/r05_pmc $w $e; done
+        ( python tools/pmc_entry_summary.py $w profiles/pmc_$w.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_${w}_summary.log 2>&1
+        cp profiles/pmc_$w.json gpurun_out/r05_pmc_$w.json
+        grep "^==" gpurun_out/r05_pmc_${w}_summary.log
+    done
+    find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
+    export KF_EIGH_STREAMS=1   # rocprofv3 segfaults when eight host threads launch the eigensolver's kernels at once
+    for w in bert_base:2048 gpt2_small:1024; do
+        name="${w%%:*}"; n="${w##*:}"
+        ( cd /tmp && KF_BENCH_BUSY=0 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r05_trace_$name" -- \
+            python "$R/bench.py" --workload "$name" --n-train "$n" --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > "gpurun_out/r05_trace_$name.log" 2>&1
+        find "gpurun_out/r05_trace_$name" -name "*kernel_stats.csv" -exec cp {} "gpurun_out/r05_${name}_n${n}_kernel_stats.csv" \;
+        rm -rf "gpurun_out/r05_trace_$name"
+    done
+    unset KF_EIGH_STREAMS
+    ( timeout 1800 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.log
+    python tools/bench_digest.py gpurun_out/r05_bench_default.json || tail -c 3000 gpurun_out/r05_bench_default.log
+    ( timeout 900 python bench.py --workload llama_block --blocks 4 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bench_llama_4blocks.json 2> gpurun_out/r05_bench_llama_4blocks.log
+    python tools/bench_digest.py gpurun_out/r05_bench_llama_4blocks.json || tail -c 2000 gpurun_out/r05_bench_llama_4blocks.log
     ;;
 pmc)
     for w in gpt2_small bert_base; do

@@ -24,11 +24,11 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCORE_GEMM = ("score_gemm_v2_kernel", "score_gemm_v3_kernel", "score_gemm_v4_kernel", "score_gemm_v5_kernel")
-PSG = ("psg_gemm_v2_kernel", "psg_gemm_v3_kernel", "psg_gemm_pp_kernel")
+PSG = ("psg_gemm_v2_kernel", "psg_gemm_v3_kernel", "psg_gemm_pp_kernel", "psg_gemm_tn_kernel")
 # instantiations of the persistent gradient kernel that serve OTHER entry points: <1, .> rows for the dense-form Lambda, <2, .> the
 # query-side preconditioner
 PSG_NOT_SCORE = ("psg_gemm_v3_kernel<1", "psg_gemm_v3_kernel<2")
-COV_GEMM = ("cov_gemm_v2_kernel", "cov_gemm_v3_kernel")
+COV_GEMM = ("cov_gemm_v2_kernel", "cov_gemm_v3_kernel", "cov_gemm_tn_kernel")
 SCORE_KERNELS = SCORE_GEMM + PSG + ("conv_pad_phases_kernel", "pad_grid_kernel", "transpose_rows_kernel", "score_r1_kernel")
 
 
@@ -56,7 +56,7 @@ def score_call_bytes(kernels: dict, calls: int) -> float:
     (``psg_gemm_v3_kernel<0, .>`` / ``psg_gemm_pp_kernel`` / ``psg_gemm_v2_kernel``; see PSG_NOT_SCORE for the others) with
     one conv_pad_phases_kernel (convolution) or two transpose_rows_kernel (sequence rows) -- kernels that also serve the
     covariance / Lambda entry points when the profiled command ran the factor fit, so only that share of their launches counts."""
-    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG) and not n.startswith(PSG_NOT_SCORE) and not n.startswith("psg_gemm_pp"))
+    psg = sum(e["launches"] for n, e in kernels.items() if n.startswith(PSG) and not n.startswith(PSG_NOT_SCORE) and not n.startswith(("psg_gemm_pp", "psg_gemm_tn")))
     total = 0.0
     for n, e in kernels.items():
         if not n.startswith(SCORE_KERNELS) or n.startswith(PSG_NOT_SCORE):
