@@ -234,16 +234,21 @@ def test_assembled_model_stages_match_oracle(name, n_train, n_query):
     assert corr(total, sum(v.double() for v in per16.values())) >= 0.9
 
 
-LATE_LAYERS = ["layers.11.attn_out", "layers.11.intermediate", "layers.11.output", "pooler", "classifier"]
+LATE = {"bert_base": dict(layers=["layers.11.attn_out", "layers.11.intermediate", "layers.11.output", "pooler", "classifier"], n_fit=2048, fit_batch=256,
+                          n_train=24, n_query=4),
+        # configs[3], the north-star scaling config: the last block's four projections, factors fitted on 256
+        # sequences of 512 tokens (131 072 token rows per factor)
+        "gpt2_small": dict(layers=["h.11.c_attn", "h.11.attn_proj", "h.11.c_fc", "h.11.mlp_proj"], n_fit=256, fit_batch=64, n_train=8, n_query=3)}
 
 
-def test_assembled_bert_late_layers_bf16_preset_with_full_rank_factors():
+@pytest.mark.parametrize("name", ["bert_base", "gpt2_small"])
+def test_assembled_bert_late_layers_bf16_preset_with_full_rank_factors(name):
     """The layers the test above can only print (BERT's last block, the one-row pooler, the 2-row classifier: with 24 train
-    sequences their Lambda is rank <= 24 and the bf16 preset's scores there are rounding noise) with factors fitted by the PRODUCT
-    on 2 048 sequences -- every Lambda coordinate populated, the heuristic damping 10x below the mean instead of 1e4x above most
+    sequences their Lambda is rank <= 24 and the bf16 preset's scores there are rounding noise; GPT-2's last block likewise) with
+    factors fitted by the PRODUCT on 2 048 (BERT) / 256 (GPT-2: 512 tokens each) sequences -- every Lambda coordinate populated, the heuristic damping 10x below the mean instead of 1e4x above most
     entries.  The bench's bf16 preset end to end (bf16 eigenvectors, bf16 P, bf16 gradients) against the fp64 oracle fed the same
     factors (eigenvectors rounded to bf16 as the preset does) on the tensors hooked during the product's own passes: rel_F and
-    correlation ASSERTED for all five layers."""
+    correlation ASSERTED for every listed layer."""
     import bench
     from kronfluence_amd import prepare_model
     from kronfluence_amd.factor.covariance import fit_covariance_matrices_with_loader
@@ -255,20 +260,21 @@ def test_assembled_bert_late_layers_bf16_preset_with_full_rank_factors():
 
     state = State()
     dev = state.device
-    spec = bench.WORKLOADS["bert_base"]
+    spec = bench.WORKLOADS[name]
+    LATE_LAYERS = LATE[name]["layers"]
     torch.manual_seed(0)
     raw = spec["model"]()
     task, make_data, _, _, _, _ = bench.workload_parts(spec, raw)
     model = prepare_model(raw, task).to(dev)
     by_name = {m.name: m for m in model.modules() if isinstance(m, TrackedModule)}
-    n_fit, n_train, n_query = 2048, 24, 4
+    n_fit, n_train, n_query, fit_batch = LATE[name]["n_fit"], LATE[name]["n_train"], LATE[name]["n_query"], LATE[name]["fit_batch"]
     fit, query = make_data(spec, n_fit, 1, dev), make_data(spec, n_query, 2, dev)
     train = tuple(t[:n_train] for t in fit)
     fargs = bench.factor_arguments(spec)
-    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(fit, 256), fargs, cpu=False)
+    _, cov = fit_covariance_matrices_with_loader(model, state, task, ResidentLoader(fit, fit_batch), fargs, cpu=False)
     eig = perform_eigendecomposition(cov, model, state, fargs, cpu=False)
     del cov
-    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(fit, 256), fargs, eig, cpu=False)
+    _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(fit, fit_batch), fargs, eig, cpu=False)
     sargs = bench.score_arguments(spec, n_query, 1, n_query)
     sargs.compute_per_module_scores = True
     sargs.damping_factor = None
@@ -290,7 +296,7 @@ def test_assembled_bert_late_layers_bf16_preset_with_full_rank_factors():
         a, b = got[mod].double().cpu().flatten(), want.flatten()
         ac, bc = a - a.mean(), b - b.mean()
         measured[mod] = (rel(got[mod], want), float((ac @ bc) / (ac.norm() * bc.norm())))
-    print("bert_base late layers, bf16 preset, factors fitted on 2 048 sequences: (rel_F, correlation)",
+    print(f"{name} late layers, bf16 preset, factors fitted on {n_fit} sequences: (rel_F, correlation)",
           {k: (f"{e:.1e}", f"{c:.4f}") for k, (e, c) in measured.items()})
     assert max(e for e, _ in measured.values()) <= 8e-2, measured   # measured 4.7e-3 ... 4.2e-2
     assert min(c for _, c in measured.values()) >= 0.99, measured   # measured >= 0.9991
