@@ -93,14 +93,19 @@ class Analyzer:
         self.output_dir = Path(output_dir).joinpath(analysis_name).resolve()
         if self.state.is_main_process:
             os.makedirs(self.output_dir, exist_ok=True)
-        if self.state.is_main_process and not disable_model_save:
-            self._save_model()
+        if not disable_model_save:
+            # every rank compares (read-only) with an existing file, so a mismatch raises on ALL of them instead of leaving the others
+            # blocked in the barrier below (the reference raises on rank 0 only); rank 0 alone writes a new file
+            existed = (self.output_dir / "model.safetensors").exists()
+            self.state.wait_for_everyone()
+            if existed or self.state.is_main_process:
+                self._save_model(write=self.state.is_main_process)
         self._dataloader_params = DataLoaderKwargs()
         self.timings: Dict[str, float] = {}
         self.state.wait_for_everyone()
 
     # -- helpers -----------------------------------------------------------------------------------
-    def _save_model(self) -> None:
+    def _save_model(self, write: bool = True) -> None:
         """``disable_model_save=False`` (reference analyzer.py:107-143): the first Analyzer of an output directory stores the model's
         state dict as ``model.safetensors``; every later one compares its model with that file and refuses to go on with a
         different one (factors and scores under this name belong to the stored model)."""
@@ -120,6 +125,8 @@ class Analyzer:
                 self.logger.error(message)
                 raise ValueError(message)
             self.logger.info(f"Found existing saved model at `{path}`.")
+            return
+        if not write:
             return
         save_file({key: value.detach().to("cpu").clone().contiguous() for key, value in state_dict.items()}, str(path))
         self.logger.info(f"Saved model at `{path}`.")

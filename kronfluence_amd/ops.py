@@ -9,6 +9,7 @@ from PyTorch's caching allocator.
 from __future__ import annotations
 
 import ctypes
+import logging
 import math
 import os
 from typing import Optional, Tuple
@@ -392,6 +393,9 @@ def eigh(cov: torch.Tensor, count: float, max_sweeps: int = 0, noise_rel: float 
 EIGH_SMALL_MAX = 96
 
 
+_EIGH_SMALL_SLOW_WARNED = False
+
+
 def eigh_small(g: torch.Tensor, inv_sqrt: bool = False, floor_rel: float = 1e-12) -> Tuple[torch.Tensor, torch.Tensor]:
     """Batched eigendecomposition of ``[batch, l, l]`` fp32 symmetric matrices (kf_eigh_small_batched for ``l <= 96``, one
     ``kf_eigh_f64`` problem per matrix above):
@@ -403,6 +407,12 @@ def eigh_small(g: torch.Tensor, inv_sqrt: bool = False, floor_rel: float = 1e-12
     if l > EIGH_SMALL_MAX:
         # beyond the in-LDS solver (ranks above 88): one kf_eigh_f64 problem per matrix -- slower (a host read-back per sweep
         # below d = 256), same result
+        global _EIGH_SMALL_SLOW_WARNED
+        if not _EIGH_SMALL_SLOW_WARNED:
+            _EIGH_SMALL_SLOW_WARNED = True
+            logging.getLogger("kronfluence_amd").warning(
+                "query_gradient_low_rank above %d: the %d x %d Gram eigenproblems of the range finder are solved one at a time "
+                "(kf_eigh_f64) instead of batched in LDS -- expect a slow query stage.", EIGH_SMALL_MAX - 8, l, l)
         evals = torch.empty((batch, l), dtype=torch.float32, device=g.device)
         evecs = torch.empty((batch, l, l), dtype=torch.float32, device=g.device)
         for j in range(batch):
