@@ -1854,7 +1854,9 @@ void launch_score_rows(float* scores, int64_t ld, const uint16_t* P, const uint1
     // one workgroup per CU: ONE round of work items over the 256 CUs (measured 4-6 % faster than two rounds of half the
     // length: fewer atomic epilogues and pipeline fills), at least 16 k-steps per item
     static const int64_t target = [] { const char* e = getenv("KF_SCORE_ITEMS"); return e ? std::max<int64_t>(1, atoll(e)) : 256; }();
-    int64_t ksplit = std::max<int64_t>(1, std::min<int64_t>(cdiv(target, tiles), s.KT / 16));
+    // ... ONE round: never more items than the target (cdiv(256, 6 tiles) = 43 chunks made 258 items -- two stragglers in a second
+    // round doubled the launch: BERT's 768-row part ran 1 232 us instead of ~740, profiles/r05_bert_base_n2048_kernel_stats.csv)
+    int64_t ksplit = std::max<int64_t>(1, std::min<int64_t>(tiles <= target ? target / tiles : 1, s.KT / 16));
     const int64_t kchunk = cdiv(s.KT, ksplit);
     ksplit = cdiv(s.KT, kchunk);
     s.ksplit = static_cast<int>(ksplit); s.kchunk = static_cast<int>(kchunk); s.alpha = scale;
@@ -1876,11 +1878,13 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
                     float scale, hipStream_t st) {
     // Mixed row tiling: Q = 256 a + r with 0 < r <= 128 and a wide train side (BERT: 872 queries against 512 sequences) would pad
     // its last 256-row tile more than half -- `a` row tiles on the 256 x 256 loop and ONE launch of 128 x 256 tiles (64 x 64
-    // waves, kf_pingpong64.h) for the last r rows instead: 896 instead of 1 024 padded rows.  KF_SCORE_MIXED=0 switches it off.
+    // waves, kf_pingpong64.h) for the last r rows instead: 896 instead of 1 024 padded rows.  OPT-IN (KF_SCORE_MIXED=1): measured on
+    // BERT (872 x 512) the 128 x 256 launch costs 253 us for an eighth of the work -- 740 + 253 us against 970 us for one launch over
+    // 1 024 padded rows: no gain.
     const int64_t rest = Q % 256;
     const char* mixed_env = getenv("KF_SCORE_MIXED");
     const bool mixed = Q > 256 && rest > 0 && rest <= 128 && b > 128 && engine_generation() == 3 && half_tile_engine() == 4 &&
-                       !getenv("KF_SCORE_SHAPE") && !(mixed_env && atoi(mixed_env) == 0);
+                       !getenv("KF_SCORE_SHAPE") && mixed_env && atoi(mixed_env) == 1;
     if (mixed) {
         launch_score_rows(scores, ld, P, psg, Q, 0, Q - rest, b, D, scale, 0, st);
         launch_score_rows(scores, ld, P, psg, Q, Q - rest, rest, b, D, scale, 2, st);

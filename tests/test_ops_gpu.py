@@ -1202,14 +1202,13 @@ def test_k_major_loop_race_screen(ops, tn_env, image):
 @pytest.mark.parametrize("q,b", [(872, 512), (600, 256), (385, 300), (1100, 129)])
 @pytest.mark.parametrize("mixed", [True, False])
 def test_score_gemm_mixed_row_tiling(ops, q, b, mixed, monkeypatch):
-    """Round 5: a query count of 256 a + r, 0 < r <= 128, against a wide train side (BERT: 872 queries x 512 sequences) runs ``a``
-    row tiles on the 256 x 256 loop and ONE launch of 128 x 256 tiles for the last ``r`` rows (896 instead of 1 024 padded rows);
-    both launches add into the same score block.  Against torch on the same bf16 per-sample gradients, with the split switched off
+    """Round 5 (opt-in, ``KF_SCORE_MIXED=1``): a query count of 256 a + r, 0 < r <= 128, against a wide train side (BERT: 872 queries x
+    512 sequences) runs ``a`` row tiles on the 256 x 256 loop and ONE launch of 128 x 256 tiles for the last ``r`` rows (896 instead of
+    1 024 padded rows); both launches add into the same score block.  Against torch on the same bf16 per-sample gradients, with the split switched off
     (``KF_SCORE_MIXED=0``) as the control; long split-K chunks and 1 / 2 / 3 / 5 k-tiles per item."""
     from kronfluence_amd.module.tracker.pairwise_score import TiledQueries
 
-    if not mixed:
-        monkeypatch.setenv("KF_SCORE_MIXED", "0")
+    monkeypatch.setenv("KF_SCORE_MIXED", "1" if mixed else "0")   # opt-in: measured no faster than one launch over the padded rows
     r, o, i = 16, 128, 1152
     p = _rand(q, o, i, seed=7).to(torch.bfloat16).to(DEV)
     g, a = _rand(b, r, o, dtype=torch.bfloat16).to(DEV), _rand(b, r, i, dtype=torch.bfloat16, seed=1).to(DEV)

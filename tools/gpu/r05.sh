@@ -7,6 +7,7 @@
 #   check3    re-validation, query passes, 4-block C5 slice with parity, 8 ranks over gloo, GPT-2 100 000 x 2 000
 #   check4    fp32-row split, shared covariance increments, conv chunk experiment + counters, 4-block C5 slice, BERT / ResNet-9 lines
 #   final     the record: full GPU suite + smoke, traces, counters, default bench line, 4-block C5 slice
+#   final2    the same without the 4-block slice and the GPT-2 trace (re-record after the split-K rounding fix)
 #   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -113,7 +114,7 @@ check4)
     ( timeout 600 python bench.py --no-extras --no-cpu-baseline --steps 3 --warmup 1 ) > gpurun_out/r05_check4_resnet9.json 2> gpurun_out/r05_check4_resnet9.log
     python tools/bench_digest.py gpurun_out/r05_check4_resnet9.json || tail -c 2000 gpurun_out/r05_check4_resnet9.log
     ;;
-final)
+final|final2)
     # the record of the round on the final sources: full GPU suite + smoke, kernel traces, counter passes (ResNet-9: the bench command
     # itself; GPT-2 / BERT: the replayed entry points), then -- with those summaries in place -- the default bench line and the
     # 4-block C5 slice
@@ -142,7 +143,9 @@ final)
     done
     find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
     export KF_EIGH_STREAMS=1   # rocprofv3 segfaults when eight host threads launch the eigensolver's kernels at once
-    for w in bert_base:2048 gpt2_small:1024; do
+    traced="bert_base:2048 gpt2_small:1024"
+    [ "$what" = "final2" ] && traced="bert_base:2048"   # (the re-record after the split-K fix: GPT-2's launches are unchanged)
+    for w in $traced; do
         name="${w%%:*}"; n="${w##*:}"
         ( cd /tmp && KF_BENCH_BUSY=0 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r05_trace_$name" -- \
             python "$R/bench.py" --workload "$name" --n-train "$n" --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > "gpurun_out/r05_trace_$name.log" 2>&1
@@ -152,6 +155,7 @@ final)
     unset KF_EIGH_STREAMS
     ( timeout 1800 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.log
     python tools/bench_digest.py gpurun_out/r05_bench_default.json || tail -c 3000 gpurun_out/r05_bench_default.log
+    [ "$what" = "final2" ] && exit 0
     ( timeout 900 python bench.py --workload llama_block --blocks 4 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bench_llama_4blocks.json 2> gpurun_out/r05_bench_llama_4blocks.log
     python tools/bench_digest.py gpurun_out/r05_bench_llama_4blocks.json || tail -c 2000 gpurun_out/r05_bench_llama_4blocks.log
     ;;
