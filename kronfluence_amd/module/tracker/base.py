@@ -75,6 +75,22 @@ def _remove_all(handles: List[RemovableHandle]) -> List[RemovableHandle]:
     return []
 
 
+def _device_tensors(value, _depth: int = 0):
+    """Every GPU tensor reachable from ``value`` through dicts / lists / tuples and the tensor attributes of plain holder
+    objects (``TiledQueries`` and the like), two levels deep."""
+    if isinstance(value, torch.Tensor):
+        if value.is_cuda:
+            yield value
+    elif isinstance(value, dict):
+        for item in value.values():
+            yield from _device_tensors(item, _depth)
+    elif isinstance(value, (list, tuple)):
+        for item in value:
+            yield from _device_tensors(item, _depth)
+    elif value is not None and _depth < 2 and hasattr(value, "__dict__"):
+        yield from _device_tensors(vars(value), _depth + 1)
+
+
 class BaseTracker:
     def __init__(self, module: "torch.nn.Module") -> None:
         self.module = module
@@ -123,8 +139,9 @@ class BaseTracker:
     # referenced until the layer's next call: autograd accumulates later gradient contributions IN PLACE into a buffer it
     # alone owns (the output gradient of a projection feeding a residual sum is that sum's gradient), which would race with
     # kernels that have not run yet.
-    _SIDE: dict = {}
+    _SIDE: dict = {}    # device -> its side stream (a stream is never replaced while events recorded on it are pending)
     _side_done = None   # event: this layer's kernels of the previous hook call on the side stream
+    _side_used = None   # the stream that event was recorded on
     _side_keep = None   # the hooked tensors of that call
     _use_side = None    # this layer's decision for the current pass
     SIDE_STREAM_MIN_FREE = 0.5
@@ -143,10 +160,10 @@ class BaseTracker:
                 self._use_side = mode == "1"
         if not self._use_side:
             return None
-        stream = BaseTracker._SIDE.get("stream")
-        if stream is None or stream.device != device:
-            stream = torch.cuda.Stream(device=device)
-            BaseTracker._SIDE["stream"] = stream
+        key = (device.type, torch.cuda.current_device() if device.index is None else device.index)
+        stream = BaseTracker._SIDE.get(key)
+        if stream is None:
+            stream = BaseTracker._SIDE[key] = torch.cuda.Stream(device=device)
         return stream
 
     def _run_beside(self, device, hooked, work) -> None:
@@ -165,17 +182,26 @@ class BaseTracker:
         with torch.cuda.stream(side):
             work()
             self._side_done = side.record_event()
+        self._side_used = side
         for tensor in hooked:
             if tensor.is_cuda:
                 tensor.record_stream(side)
         self._side_keep = tuple(hooked)
 
     def _join_side(self) -> None:
-        """End of a pass: the caller's stream waits for the side stream; the decision is taken anew next pass."""
-        side = BaseTracker._SIDE.get("stream") if self._side_done is not None else None
+        """End of a pass: the caller's stream waits for the side stream; the decision is taken anew next pass.  What the hooks
+        allocated while the side stream was current (the accumulators a mode creates on first use: covariances, Lambda, score
+        blocks) belongs to the side stream's pool of the caching allocator but is read on the caller's stream from here on:
+        every tensor the layer keeps in ``module.storage`` is marked as in use there, so that a later free cannot hand its
+        memory out while a main-stream reader is still pending."""
+        side = self._side_used if self._side_done is not None else None
         if side is not None:
-            torch.cuda.current_stream(side.device).wait_stream(side)
+            main = torch.cuda.current_stream(side.device)
+            main.wait_stream(side)
+            for tensor in _device_tensors(self.module.storage):
+                tensor.record_stream(main)
             self._side_done = None
+        self._side_used = None
         self._side_keep = None
         self._use_side = None
 

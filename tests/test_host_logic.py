@@ -464,3 +464,24 @@ def test_conv_layout_helpers_are_exact_relayouts():
     p = torch.arange(3 * 4 * 32, dtype=torch.float32).reshape(3, 4, 32)   # [rows, ...] with 128 elements per row
     tiled = ops.k_tile_major(p)
     assert tiled.shape == (2, 3, 64) and torch.equal(tiled.transpose(0, 1).reshape(3, 128), p.reshape(3, 128))
+
+
+def test_side_stream_join_finds_every_tensor_a_layer_keeps():
+    """what a hook allocates while the side stream is current is read on the caller's stream after the join, so the
+    join marks every tensor of ``module.storage`` as in use there.  The walk that finds them is host logic: tensors, lists of
+    tensors, dicts and the tensor attributes of holder objects (``TiledQueries``); CPU tensors and scalars are skipped."""
+    from types import SimpleNamespace
+
+    from kronfluence_amd.module.tracker import base
+
+    class FakeDeviceTensor(torch.Tensor):
+        is_cuda = True
+
+    def on_device(*shape):
+        return torch.zeros(*shape).as_subclass(FakeDeviceTensor)
+
+    a, b, c, d = on_device(2), on_device(3), on_device(4), on_device(5)
+    holder = SimpleNamespace(tiled=c, num_queries=7, nested=SimpleNamespace(block=d, deeper=SimpleNamespace(never=on_device(1))))
+    storage = {"covariance": a, "count": 3, "host": torch.zeros(2), "none": None, "list": [b, torch.zeros(1)], "queries": holder}
+    found = list(base._device_tensors(storage))
+    assert [t.shape[0] for t in found] == [2, 3, 4, 5]   # two levels of holder objects, not a third
