@@ -212,7 +212,7 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
         else:
             evals = torch.empty(d, dtype=original_dtype, device=state.device)
             evecs = torch.empty((d, d), dtype=original_dtype, device=state.device)
-        if world > 1:
+        if world > 1 or (state.use_distributed and dist.is_initialized()):   # (one forced rank: KF_DIST_FORCE)
             with exchange("eigen_broadcast", (evals.numel() + evecs.numel()) * evecs.element_size()):
                 dist.broadcast(evals, src=owner)
                 dist.broadcast(evecs, src=owner)

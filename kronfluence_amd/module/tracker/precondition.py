@@ -17,6 +17,7 @@ from kronfluence_amd import ops
 from kronfluence_amd.factor.config import FactorConfig
 from kronfluence_amd.module.tracker.base import BaseTracker, QueryBlocks, QueryBuffer
 from kronfluence_amd.utils.comm import exchange
+from kronfluence_amd.utils.state import force_exchanges
 from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME,
     AGGREGATED_GRADIENT_NAME,
@@ -91,7 +92,7 @@ class PreconditionTracker(BaseTracker):
         preconditioned = preconditioned.contiguous()
         self.module.storage[PRECONDITIONED_GRADIENT_NAME] = preconditioned
         if (from_hook and self.ASYNC_QUERY_GATHER and self.module.async_query_gather and dist.is_available() and dist.is_initialized()
-                and dist.get_world_size() > 1):
+                and (dist.get_world_size() > 1 or force_exchanges())):
             if self._pending is not None:   # never drop a collective in flight
                 self._pending[0].wait()
             local = preconditioned

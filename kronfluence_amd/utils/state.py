@@ -13,6 +13,14 @@ import torch
 import torch.distributed as dist
 
 
+def force_exchanges() -> bool:
+    """``KF_DIST_FORCE=1`` (test hook): a ONE-rank process group still runs every exchange of the sharded path -- factor
+    all-reduce, eigendecomposition broadcasts, query all-gather, score gather, barriers -- so that the collective library
+    (RCCL on the GPU box, which has a single GPU) executes the very calls a multi-rank job makes; with one rank they are
+    identities and the results must equal the plain single-process run."""
+    return os.environ.get("KF_DIST_FORCE", "0") == "1"
+
+
 class State:
     """Shared (Borg) view of the launch environment."""
 
@@ -30,7 +38,7 @@ class State:
         if dist.is_available() and dist.is_initialized():
             self.num_processes, self.process_index = dist.get_world_size(), dist.get_rank()
             self.local_process_index = max(local_rank, 0)
-        elif world > 1 and local_rank >= 0:
+        elif (world > 1 or force_exchanges()) and local_rank >= 0:
             backend = "gloo" if cpu or not torch.cuda.is_available() else "nccl"  # "nccl" == RCCL on ROCm
             backend = os.environ.get("KF_DIST_BACKEND", backend)  # test hook: 2 ranks sharing one GPU need gloo
             if torch.cuda.is_available() and not cpu:
@@ -58,7 +66,7 @@ class State:
 
     @property
     def use_distributed(self) -> bool:
-        return self.num_processes > 1
+        return self.num_processes > 1 or (force_exchanges() and dist.is_available() and dist.is_initialized())
 
     @property
     def is_main_process(self) -> bool:

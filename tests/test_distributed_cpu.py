@@ -303,9 +303,10 @@ def _pipeline_many_ranks(rank, world, out_dir):
         torch.save({"fit_log": fit_log, "score_log": score_log}, os.path.join(out_dir, f"log_rank{rank}.pt"))
 
 
-@pytest.mark.parametrize("world", [3, 8])
-def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world):
-    """P = 3 and P = 8 with N = 45 train samples (N % P != 0: the contiguous train shards are wrap-padded to ceil(N / P),
+@pytest.mark.parametrize("world", [1, 3, 8])
+def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world, monkeypatch):
+    """(P = 1: ONE rank with ``KF_DIST_FORCE=1`` -- every exchange still issued, each an identity; the form in which RCCL runs this
+    path on the one-GPU test box, tests/test_distributed_gpu.py.)  P = 3 and P = 8 with N = 45 train samples (N % P != 0: the contiguous train shards are wrap-padded to ceil(N / P),
     utils/dataset.py:181-196, and the gathered score blocks cut back with ``cat[:, :N]``), Q = 11 queries at 2 per rank (Q % (q P) !=
     0: the strided query sampler pads with duplicates and the last round is truncated, score/pairwise.py:239-246), the 2 L = 6
     eigenproblems of the 3-layer fixture dealt over 8 ranks (two ranks own none), the factor fit strided without padding -- all
@@ -318,6 +319,8 @@ def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world):
 
     c = _MANY
     (tmp_path / "many").mkdir()
+    if world == 1:
+        monkeypatch.setenv("KF_DIST_FORCE", "1")
     _run("_pipeline_many_ranks", tmp_path / "many", world=world)
     got = torch.load(tmp_path / "many" / "many_ranks.pt")
     task = make_task(c["kind"])
@@ -356,7 +359,8 @@ def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world):
     rounds = -(-c["n_query"] // (c["q"] * world))
     score = got["score_log"]
     assert score["query_all_gather"]["calls"] == rounds * layers
-    assert score["query_all_gather"]["bytes"] == rounds * world * c["q"] * lam_floats * 4
+    # (every rank holds ceil(Q / P) queries after the sampler's wrap-around padding; the last round may be a partial batch)
+    assert score["query_all_gather"]["bytes"] == world * (-(-c["n_query"] // world)) * lam_floats * 4
     # one train pass (and one gather) per query round; the rounds' blocks add up to [Q, ceil(N / P)] (the last round truncated)
     assert score["score_gather"]["calls"] == rounds
     assert score["score_gather"]["bytes"] == c["n_query"] * (-(-c["n_train"] // world)) * 4

@@ -66,17 +66,24 @@ def _pipeline(world, rank, out_path):
                                                   sargs, fargs, None)
     cpu = lambda d: {k: {n: v.cpu() for n, v in m.items()} for k, m in d.items()}  # noqa: E731
     if rank == 0:
-        torch.save({"cov": cpu(cov), "lam": cpu(lam), "scores": scores["all_modules"]}, out_path)
+        from kronfluence_amd.utils import comm
+
+        torch.cuda.synchronize()
+        torch.save({"cov": cpu(cov), "lam": cpu(lam), "scores": scores["all_modules"], "exchanges": comm.summary(comm.EXCHANGE_LOG),
+                    "backend": dist.get_backend() if dist.is_initialized() else None}, out_path)
     elif world > 1:  # the other rank holds the same sums
         torch.save({"cov": cpu(cov), "lam": cpu(lam)}, out_path + f".rank{rank}")
 
 
-def _worker(rank, world, port, out_path, backend="gloo"):
+def _worker(rank, world, port, out_path, backend="gloo", force=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank if backend == "nccl" else 0), KF_DIST_BACKEND=backend,
-                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", KF_DIST_FORCE="1" if force else "0")
     import torch.distributed as dist
 
+    from kronfluence_amd.utils import comm
+
+    comm.EXCHANGE_LOG = {}
     try:
         _pipeline(world, rank, out_path)
     finally:
@@ -90,7 +97,8 @@ def rel(a, b):
 
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
 def test_two_rank_pipeline_matches_single_process(tmp_path, backend):
-    if backend == "nccl" and torch.cuda.device_count() < 2:
+    if backend == "nccl" and torch.cuda.device_count() < 2 and os.environ.get("KF_TEST_RCCL_SHARED_GPU") != "1":
+        # (KF_TEST_RCCL_SHARED_GPU=1: try both ranks on the one GPU anyway -- RCCL refuses duplicate devices; kept for the record)
         pytest.skip("RCCL variant needs two visible GPUs (the 1-GPU test box runs the gloo variant)")
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -114,3 +122,28 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, backend):
         assert rel(two["lam"]["lambda_matrix"][module], want) <= 1e-4, module
         assert torch.equal(two["lam"]["num_lambda_processed"][module], one["lam"]["num_lambda_processed"][module])
     assert rel(two["scores"], one["scores"]) <= 1e-4, rel(two["scores"], one["scores"])
+
+
+def test_one_rank_over_rccl_runs_every_exchange(tmp_path):
+    """The test box has ONE GPU, so the two-rank RCCL variant above never runs there.  This one does: a one-rank process group on
+    backend "nccl" (= RCCL) with ``KF_DIST_FORCE=1`` sends the sharded path through every collective a multi-rank job issues --
+    bucketed factor all-reduce, eigendecomposition broadcasts, (asynchronous) query all-gather + interleave, score-block gather,
+    barriers -- with the very tensors (dtypes, strides, sizes) the product hands to RCCL.  With one rank each exchange is an
+    identity: factors and scores must equal the plain single-process run bit for bit, and the exchange log must show the calls."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    plain, forced = str(tmp_path / "plain.pt"), str(tmp_path / "forced.pt")
+    mp.spawn(_worker, args=(1, port, plain, "nccl", False), nprocs=1, join=True)
+    mp.spawn(_worker, args=(1, port + 1, forced, "nccl", True), nprocs=1, join=True)
+    one, two = torch.load(plain), torch.load(forced)
+    assert one["backend"] is None and two["backend"] == "nccl"
+    assert not one["exchanges"]
+    kinds = two["exchanges"]
+    for kind in ("factor_all_reduce", "eigen_broadcast", "query_all_gather", "score_gather"):
+        assert kinds.get(kind, {}).get("calls", 0) > 0 and kinds[kind]["bytes"] > 0, (kind, kinds)
+    for group in ("cov", "lam"):
+        for name, per_module in one[group].items():
+            for module, want in per_module.items():
+                assert torch.equal(two[group][name][module], want), (group, name, module)
+    assert torch.equal(two["scores"], one["scores"])

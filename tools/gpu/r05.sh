@@ -8,6 +8,7 @@
 #   check4    fp32-row split, shared covariance increments, conv chunk experiment + counters, 4-block C5 slice, BERT / ResNet-9 lines
 #   final     the record: full GPU suite + smoke, traces, counters, default bench line, 4-block C5 slice
 #   final2    the same without the 4-block slice and the GPT-2 trace (re-record after the split-K rounding fix)
+#   rccl      RCCL with ONE forced rank (KF_DIST_FORCE=1), side-stream test, two ranks on one GPU for the record, Llama cov / Lambda counters
 #   pmc       only the PMC replays (after a kernel change) -> profiles/pmc_gpt2_small.json, pmc_bert_base.json
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -165,6 +166,23 @@ pmc)
         ( python tools/pmc_entry_summary.py $w gpurun_out/r05_pmc_$w.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_${w}_summary.log 2>&1
         grep "^==" gpurun_out/r05_pmc_${w}_summary.log
     done
+    find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
+    ;;
+rccl)
+    # RCCL on the one-GPU box: a ONE-rank "nccl" group with every exchange forced (KF_DIST_FORCE=1), the gloo two-rank variant beside
+    # it, the opt-in side-stream test; then -- for the record -- both ranks of the two-rank RCCL variant on the one GPU
+    ( timeout 600 python -m pytest tests/test_distributed_gpu.py -q --durations=5 ) > gpurun_out/r05_rccl_one_rank.log 2>&1
+    tail -12 gpurun_out/r05_rccl_one_rank.log
+    ( timeout 400 python -m pytest tests/test_pipeline_gpu.py -q -k "side" ) > gpurun_out/r05_side_stream.log 2>&1
+    tail -3 gpurun_out/r05_side_stream.log
+    ( KF_TEST_RCCL_SHARED_GPU=1 NCCL_DEBUG=WARN timeout -k 10 240 python -m pytest tests/test_distributed_gpu.py -q -x -k "two_rank and nccl" ) \
+        > gpurun_out/r05_rccl_two_ranks_one_gpu.log 2>&1
+    echo "two ranks on one GPU over RCCL: rc $?"
+    grep -i -m 12 "duplicate\|invalid usage\|ncclInvalid\|passed\|failed\|error" gpurun_out/r05_rccl_two_ranks_one_gpu.log | cut -c1-300
+    # counters for the Llama slice's covariance / Lambda calls (its score path is the low-rank contraction: no dense score entry)
+    for e in cov lambda; do replay_pmc gpurun_out/r05_pmc llama_block $e; done
+    ( python tools/pmc_entry_summary.py llama_block gpurun_out/r05_pmc_llama_block.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_llama_block_summary.log 2>&1
+    grep "^==" gpurun_out/r05_pmc_llama_block_summary.log || tail -5 gpurun_out/r05_pmc_llama_block_summary.log
     find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
     ;;
 *)
