@@ -185,6 +185,27 @@ rccl)
     grep "^==" gpurun_out/r05_pmc_llama_block_summary.log || tail -5 gpurun_out/r05_pmc_llama_block_summary.log
     find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
     ;;
+tb)
+    # BERT: train batch 512 (the bench's) against 1024 -- P is read once per launch, the item prologues / epilogues amortise
+    for tb in 512 1024; do
+        ( KF_BENCH_BUSY=0 timeout 500 python bench.py --workload bert_base --n-train 16384 --n-fit 2048 --warm-n-train 1024 --train-batch $tb \
+            --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r05_bert_tb$tb.json 2> gpurun_out/r05_bert_tb$tb.log
+        python tools/bench_digest.py gpurun_out/r05_bert_tb$tb.json | grep "pairs/s\|roofline:" || tail -5 gpurun_out/r05_bert_tb$tb.log
+    done
+    ;;
+eig2)
+    for lanes in 6 3 2; do
+        ( timeout 400 python tools/eigh_bench.py multi 14336 6 $lanes ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee -a gpurun_out/r05_eigh_lanes_14336.log
+    done
+    ;;
+eig)
+    # does keeping several 14 336^2 eigenproblems in flight pay?  three problems on one lane / on three lanes (tools/eigh_bench.py multi)
+    ( timeout 600 python -m pytest tests/test_distributed_gpu.py -q --durations=5 ) > gpurun_out/r05_rccl_one_rank.log 2>&1
+    tail -4 gpurun_out/r05_rccl_one_rank.log
+    for lanes in 1 3; do
+        ( timeout 400 python tools/eigh_bench.py multi 14336 3 $lanes ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee -a gpurun_out/r05_eigh_lanes_14336.log
+    done
+    ;;
 *)
     echo "unknown sub-command $what"; exit 2 ;;
 esac
