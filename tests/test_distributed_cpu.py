@@ -370,6 +370,84 @@ def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world, monkeypatc
         assert {k: (v["calls"], v["bytes"]) for k, v in other["score_log"].items()} == {k: (v["calls"], v["bytes"]) for k, v in score.items()}
 
 
+# ---- layers that share an input, on two ranks: one eigendecomposition per distinct covariance, dealt over the ranks ------------
+class _Attn(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        lin = torch.nn.Linear
+        self.q, self.k, self.v, self.o = lin(6, 5), lin(6, 5), lin(6, 5), lin(5, 3)
+
+    def forward(self, x):
+        return self.o(torch.tanh(self.q(x)) * torch.tanh(self.k(x)) + self.v(x))
+
+
+def _attn_task():
+    from kronfluence_amd import Task
+
+    class T(Task):
+        def compute_train_loss(self, batch, model, sample=False):
+            return (model(batch[0]) - batch[1]).square().sum()
+
+        def compute_measurement(self, batch, model):
+            return self.compute_train_loss(batch, model)
+
+    return T()
+
+
+def _attn_data():
+    from torch.utils import data
+
+    gen = torch.Generator().manual_seed(1)
+    train = data.TensorDataset(torch.randn(41, 6, generator=gen), torch.randn(41, 3, generator=gen))
+    query = data.TensorDataset(torch.randn(5, 6, generator=gen), torch.randn(5, 3, generator=gen))
+    return train, query
+
+
+def _attn_run(out_dir, solved=None):
+    import cpu_engine
+    from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, ops, prepare_model
+
+    if solved is not None:
+        cpu_engine.install_in_worker()
+        real = ops.eigh
+        ops.eigh = lambda cov, *a, **k: (solved.append(tuple(cov.shape)), real(cov, *a, **k))[1]
+    torch.manual_seed(0)
+    task = _attn_task()
+    analyzer = Analyzer("t", prepare_model(_Attn(), task), task, output_dir=out_dir, disable_tqdm=True)
+    train, query = _attn_data()
+    analyzer.fit_all_factors("f", train, per_device_batch_size=8, factor_args=FactorArguments(use_empirical_fisher=True))
+    scores = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=2, per_device_train_batch_size=7,
+                                              score_args=ScoreArguments(damping_factor=None))
+    return analyzer, scores
+
+
+def _attn_two_ranks(rank, world, out_dir):
+    solved = []
+    analyzer, scores = _attn_run(out_dir, solved)
+    torch.save({"solved": solved, "scores": None if scores is None else scores["all_modules"],
+                "eig": analyzer.load_eigendecomposition("f") if rank == 0 else None}, os.path.join(out_dir, f"attn_rank{rank}.pt"))
+
+
+def test_shared_input_layers_on_two_ranks(tmp_path, cpu_engine):
+    """q / k / v consume one tensor: their covariance increments are shared on every rank (tracker/factor.py), the all-reduced
+    activation covariances are recognised as one matrix by every rank alike, the 6 distinct eigenproblems (of 8) are dealt 3 + 3 over
+    the two ranks, the aliases take their owner's broadcast result -- and the scores equal the single-process run's."""
+    (tmp_path / "two").mkdir()
+    _run("_attn_two_ranks", tmp_path / "two", world=2)
+    r0, r1 = torch.load(tmp_path / "two" / "attn_rank0.pt"), torch.load(tmp_path / "two" / "attn_rank1.pt")
+    assert len(r0["solved"]) == 3 and len(r1["solved"]) == 3
+    assert (r0["solved"] + r1["solved"]).count((7, 7)) == 1          # q = k = v: solved once, on one rank
+    eig = r0["eig"]
+    for name in ("k", "v"):
+        assert torch.equal(eig["activation_eigenvectors"][name], eig["activation_eigenvectors"]["q"])
+        assert torch.equal(eig["activation_eigenvalues"][name], eig["activation_eigenvalues"]["q"])
+    assert r1["scores"] is None
+    _, want = _attn_run(str(tmp_path / "one"))
+    got, want = r0["scores"].double(), want["all_modules"].double()
+    assert got.shape == want.shape == (5, 41)
+    assert float((got - want).abs().max() / want.abs().max()) <= 2e-5
+
+
 # ---- the reference's launch idiom: prepare_model -> apply_ddp -> Analyzer ---------------------------------------------------
 def _worker_without_group(rank: int, world: int, port: int, out_dir: str) -> None:
     import cpu_engine
