@@ -896,7 +896,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                        "D": D, "input_dtype": "bf16-autocast" if amp is not None else "f32",
                        "score_dtype": str(sargs.score_dtype), "query_gradient_accumulation_steps": accumulate, "query_passes": query_passes,
                        **({"blocks": spec["blocks"]} if "blocks" in spec else {}),
-                       "train_batch": spec["train_batch"], "query_batch": per_dev_q,
+                       "train_batch": spec["train_batch"], "factor_batch": spec["factor_batch"], "query_batch": per_dev_q,
                        "parallelism": f"train-shard-dp{world}",
                        **({"warmup_n_train": min(warm_n_train, n_train)} if warm_n_train else {}),
                        **({"scaled_from": {"n_train": spec.get("full_n_train"), "n_query": spec.get("full_n_query", spec["n_query"])}}
@@ -965,6 +965,7 @@ def main() -> None:
     ap.add_argument("--no-extras", action="store_true", help="skip targets.mnist_mlp / other_configs in the default run")
     ap.add_argument("--factor-reps", type=int, default=1)
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
+    ap.add_argument("--factor-batch", type=int, default=None, help="override the workload's factor-fit batch size")
     ap.add_argument("--n-fit", type=int, default=None, help="fit the factors on the first N train samples only (default: all)")
     ap.add_argument("--warm-n-train", type=int, default=None, help="warm-up steps score against the first N train samples only")
     ap.add_argument("--blocks", type=int, default=None, help="llama_block: decoder blocks of the slice (default 1; other_configs uses 2)")
@@ -979,6 +980,8 @@ def main() -> None:
         _respawn_under_torchrun(args.gpus)
     if args.train_batch:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
+    if args.factor_batch:
+        WORKLOADS[args.workload]["factor_batch"] = args.factor_batch
     if args.blocks:
         WORKLOADS["llama_block"]["blocks"] = args.blocks
     if not args.no_miopen_find:

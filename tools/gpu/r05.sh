@@ -193,6 +193,16 @@ tb)
         python tools/bench_digest.py gpurun_out/r05_bert_tb$tb.json | grep "pairs/s\|roofline:" || tail -5 gpurun_out/r05_bert_tb$tb.log
     done
     ;;
+fb)
+    # factor-fit batch: GPT-2 64 -> 128 sequences, BERT 256 -> 512 (the covariance / Lambda calls' prologues, epilogues and the
+    # memset / finalize launches amortise over twice the rows); same n_fit as the default line, tiny score stage
+    ( KF_BENCH_BUSY=0 timeout 500 python bench.py --workload gpt2_small --n-train 256 --n-query 64 --factor-batch 128 --steps 1 --warmup 1 \
+        --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_gpt2_fb128.json 2> gpurun_out/r05_gpt2_fb128.log
+    python tools/bench_digest.py gpurun_out/r05_gpt2_fb128.json | grep "factor_fit\|roofline_cov:\|roofline_lambda" || tail -5 gpurun_out/r05_gpt2_fb128.log
+    ( KF_BENCH_BUSY=0 timeout 500 python bench.py --workload bert_base --n-train 1024 --n-query 109 --n-fit 8192 --factor-batch 512 --steps 1 --warmup 1 \
+        --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_bert_fb512.json 2> gpurun_out/r05_bert_fb512.log
+    python tools/bench_digest.py gpurun_out/r05_bert_fb512.json | grep "factor_fit\|roofline_cov\|roofline_lambda" || tail -5 gpurun_out/r05_bert_fb512.log
+    ;;
 eig2)
     for lanes in 6 3 2; do
         ( timeout 400 python tools/eigh_bench.py multi 14336 6 $lanes ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee -a gpurun_out/r05_eigh_lanes_14336.log
