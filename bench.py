@@ -374,10 +374,10 @@ WORKLOADS = {
                     amp=torch.bfloat16, factor_batch=1000, train_batch=1000, query_batch=250,
                     cpu_sample=dict(n_train=192, n_query=32, n_fit=64)),
     "bert_base": dict(model=bert_base, kind="glue", vocab=28996, tokens=128, n_train=8192, n_query=872, full_n_train=67_349,
-                      amp=torch.bfloat16, fp32_factors=True, factor_batch=256, train_batch=512, query_batch=109,
+                      amp=torch.bfloat16, fp32_factors=True, factor_batch=512, train_batch=512, query_batch=109,
                       cpu_sample=dict(n_train=16, n_query=4, n_fit=8)),
     "gpt2_small": dict(model=gpt2_small, kind="lm", vocab=50257, tokens=512, n_train=2048, n_query=1024,
-                       full_n_train=100_000, full_n_query=2000, amp=torch.bfloat16, low_cov=True, factor_batch=64, train_batch=128,
+                       full_n_train=100_000, full_n_query=2000, amp=torch.bfloat16, low_cov=True, factor_batch=128, train_batch=128,
                        query_batch=32, cpu_sample=dict(n_train=8, n_query=2, n_fit=4)),
     # configs[4] (OpenWebText Llama-3-8B, Linear layers only, 100k x 1k on 8 GPUs, AMP bf16) as a ONE-BLOCK slice at full
     # width: all seven projections tracked, T = 512, the reference's rank-64 low-rank query gradients

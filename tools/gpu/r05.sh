@@ -203,6 +203,27 @@ fb)
         --no-cpu-baseline --factor-reps 1 ) > gpurun_out/r05_bert_fb512.json 2> gpurun_out/r05_bert_fb512.log
     python tools/bench_digest.py gpurun_out/r05_bert_fb512.json | grep "factor_fit\|roofline_cov\|roofline_lambda" || tail -5 gpurun_out/r05_bert_fb512.log
     ;;
+fb2)
+    for fb in 2000 1000; do
+        ( KF_BENCH_BUSY=0 timeout 300 python bench.py --factor-batch $fb --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 1 ) \
+            > gpurun_out/r05_resnet9_fb$fb.json 2> gpurun_out/r05_resnet9_fb$fb.log
+        python tools/bench_digest.py gpurun_out/r05_resnet9_fb$fb.json | grep "pairs/s\|factor_fit\|roofline_cov:\|roofline_lambda:" || tail -5 gpurun_out/r05_resnet9_fb$fb.log
+    done
+    ;;
+final3)
+    # re-record after the factor batches of GPT-2 / BERT doubled (kernel sources unchanged: the ResNet-9 summary stays): the replayed
+    # entry points under the counters at the new batch sizes, then the default bench line with those summaries in place
+    rm -rf gpurun_out/r05_pmc
+    for w in gpt2_small bert_base; do
+        for e in score cov lambda; do replay_pmc gpurun_out/r05_pmc $w $e; done
+        ( python tools/pmc_entry_summary.py $w profiles/pmc_$w.json gpurun_out/r05_pmc ) > gpurun_out/r05_pmc_${w}_summary.log 2>&1
+        cp profiles/pmc_$w.json gpurun_out/r05_pmc_$w.json
+        grep "^==" gpurun_out/r05_pmc_${w}_summary.log
+    done
+    find gpurun_out/r05_pmc -name "*.csv" -size +2M -delete
+    ( timeout 1800 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.log
+    python tools/bench_digest.py gpurun_out/r05_bench_default.json || tail -c 3000 gpurun_out/r05_bench_default.log
+    ;;
 eig2)
     for lanes in 6 3 2; do
         ( timeout 400 python tools/eigh_bench.py multi 14336 6 $lanes ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee -a gpurun_out/r05_eigh_lanes_14336.log
