@@ -224,6 +224,10 @@ final3)
     ( timeout 1800 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.log
     python tools/bench_digest.py gpurun_out/r05_bench_default.json || tail -c 3000 gpurun_out/r05_bench_default.log
     ;;
+suite)
+    ( timeout 2400 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r05_pytest_gpu.log 2>&1
+    tail -18 gpurun_out/r05_pytest_gpu.log
+    ;;
 eig2)
     for lanes in 6 3 2; do
         ( timeout 400 python tools/eigh_bench.py multi 14336 6 $lanes ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee -a gpurun_out/r05_eigh_lanes_14336.log
