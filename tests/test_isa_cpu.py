@@ -87,3 +87,53 @@ def test_role_split_loops_wait_on_counts_not_on_everything(kernels):
         checked += 1
     # score (3 schedules), rotations (2 x 3), per-sample gradients (3), covariance (3), K-major gradients / covariance (3 images each)
     assert checked == 3 + 6 + 3 + 3 + 3 + 3, checked
+
+
+def segments_of(loop):
+    """The k-tile loop cut at its raw barriers: per segment (fragment reads, MFMAs, LDS-DMA requests, counted vm waits)."""
+    segs = [[]]
+    for x in loop:
+        if x[1] == "s_barrier":
+            segs.append([])
+        else:
+            segs[-1].append(x)
+    out = []
+    for seg in segs:
+        ops = [x[1] for x in seg]
+        out.append((sum(op.startswith("ds_read") for op in ops), sum(op.startswith("v_mfma") for op in ops),
+                    sum(op.startswith("global_load_lds") for op in ops),
+                    [int(re.search(r"vmcnt\((\d+)\)", x[2]).group(1)) for x in seg if x[1] == "s_waitcnt" and "vmcnt" in x[2]]))
+    # the loop's first and last pieces belong to one segment (the back edge sits inside it)
+    first, last = out[0], out[-1]
+    merged = (first[0] + last[0], first[1] + last[1], first[2] + last[2], last[3] + first[3])
+    return [merged] + out[1:-1]
+
+
+def test_compiled_segments_are_the_ones_the_interval_model_checks(kernels):
+    """tools/pp_schedule_check.py proves the RAW / WAR ordering of a request schedule that was transcribed BY HAND from
+    kf_pingpong.h; this ties the transcription to the compiled code: for every kernel on the 256 x 256 loops the k-tile loop, cut at its
+    four barriers, must be L M L M with -- segment by segment -- the model's number of requests (two DMA instructions per piece and
+    wave) and the model's counted wait, fragment reads only in the L segments and 16 MFMAs in each M segment."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import pp_schedule_check as model
+
+    checked = 0
+    for name, body in kernels.items():
+        m = re.search(r"(score_gemm_v3|rotate_gemm_v3|psg_gemm_pp|cov_gemm_v3|psg_gemm_tn|cov_gemm_tn)_kernel", name)
+        if not m:
+            continue
+        issue = 1 if m.group(1).endswith("_tn") else template_ints(name)[-1]
+        program = model.program(issue, 8)
+        steady = program[1 + 4 * 3: 1 + 4 * 4]          # the four segments of k-tile 3: both look-aheads exist
+        want = [(kind, 2 * len(issues), wait) for kind, _reads, issues, wait in steady]
+        segs = segments_of(k_tile_loop(body))
+        assert len(segs) == 4, (name, len(segs))
+        got = [("L" if reads and not mfma else "M" if mfma == 16 and not reads else "?", dma, waits[0] if waits else None)
+               for reads, mfma, dma, waits in segs]
+        assert all(len(waits) <= 1 for _, _, _, waits in segs), name
+        rotations = [got[k:] + got[:k] for k in range(4)]   # the compiler may start the loop at any barrier
+        assert want in rotations, (name, got, want)
+        checked += 1
+    assert checked == 21, checked
