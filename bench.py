@@ -938,6 +938,147 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     return result
 
 
+# ------------------------------------------------------------------------------------------------
+# the printed line: compact by construction (the driver parses the LAST stdout line; r05's 30 KB object was not parsed)
+# ------------------------------------------------------------------------------------------------
+LINE_TARGET_BYTES = 8192
+LINE_HARD_CAP_BYTES = 16384
+EXTRAS_FILE = "bench_extras.json"
+
+_ROOFLINE_KEYS = ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "mfma_util", "launches",
+                  "avg_launch_ms", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "kernel_share_of_region",
+                  "model_share_of_region")
+
+
+def _sig(x, digits: int = 6):
+    """Floats to ``digits`` significant digits (a 17-digit double is 2-3x the characters and none of the information)."""
+    if isinstance(x, float):
+        return float(f"{x:.{digits}g}") if x == x and abs(x) != float("inf") else None
+    if isinstance(x, dict):
+        return {k: _sig(v, digits) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_sig(v, digits) for v in x]
+    return x
+
+
+def _compact_roofline(r: Optional[dict], keys=_ROOFLINE_KEYS) -> Optional[dict]:
+    """Numbers only (+ the two one-word strings ``bound`` / ``unit``): the kernel / method prose lives in DESIGN.md section 7."""
+    if not isinstance(r, dict):
+        return None
+    return {k: r[k] for k in keys if k in r and (k in ("bound", "unit") or not isinstance(r[k], (str, dict, list)))}
+
+
+def _compact_fit(f: Optional[dict]) -> Optional[dict]:
+    if not isinstance(f, dict):
+        return None
+    return {"samples_per_sec": f.get("samples_per_sec"), "n_fit": f.get("n_fit"), "seconds": f.get("seconds"),
+            "covariance_samples_per_sec": f.get("covariance_samples_per_sec"), "lambda_samples_per_sec": f.get("lambda_samples_per_sec")}
+
+
+def _compact_busy(b: Optional[dict]) -> Optional[dict]:
+    if not isinstance(b, dict):
+        return None
+    if "error" in b:
+        return {"error": str(b["error"])[:120]}
+    return {k: b.get(k) for k in ("idle_frac", "kf_kernel_frac", "model_kernel_frac")}
+
+
+def _compact_exchanges(e: Optional[dict]) -> Optional[dict]:
+    """``{backend, ranks, query_exchange, <stage>: {<kind>: [calls, bytes, seconds]}}``."""
+    if not isinstance(e, dict):
+        return None
+    out = {k: e[k] for k in ("backend", "ranks", "query_exchange") if k in e}
+    for stage in ("factor_fit", "pairwise_timed_steps"):
+        if isinstance(e.get(stage), dict):
+            out[stage] = {kind: [v.get("calls"), v.get("bytes"), v.get("seconds")] for kind, v in e[stage].items()}
+    return out
+
+
+def compact_line(full: dict) -> dict:
+    """The ONE JSON object ``bench.py`` prints: the contract's headline keys, ``config``, numeric ``roofline`` (of the headline
+    entry point) + the three factor-fit roofline fractions, ``cpu_baseline``, ``factor_fit``, ``targets.mnist_mlp`` and one short record per
+    ``other_configs`` entry.  Everything else ``run_workload`` measures (per-kernel prose, ``device_busy`` gap tables, the extra
+    rooflines, ``eigh_paths`` ...) is the FULL object, written to ``bench_extras.json`` beside this script and to stderr."""
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                     "scaling", "vs_baseline", "dtype", "data")}
+    cfg = dict(full.get("config") or {})
+    cfg.pop("scaled_from", None)
+    line["config"] = cfg
+    line["roofline"] = _compact_roofline(full.get("roofline"))
+    if isinstance(full.get("roofline"), dict) and line["roofline"] is not None:
+        line["roofline"]["kernel"] = "kf_pairwise_score* (entry point: per-sample-gradient GEMM + score GEMM)"
+    cpu = full.get("cpu_baseline")
+    line["cpu_baseline"] = (None if not isinstance(cpu, dict) else
+                            {**{k: cpu.get(k) for k in ("value", "unit", "cores", "kind")}, "sample": str(cpu.get("sample", ""))[:160],
+                             **({"factor_fit_samples_per_sec": cpu["factor_fit_samples_per_sec"]} if "factor_fit_samples_per_sec" in cpu else {})})
+    line["factor_fit"] = _compact_fit(full.get("factor_fit"))
+    for key in ("roofline_cov", "roofline_lambda", "roofline_lambda_update"):
+        line[key] = _compact_roofline(full.get(key), ("frac", "traffic_over_algorithmic", "mfma_util", "avg_launch_ms"))
+    line["device_busy"] = _compact_busy(full.get("device_busy"))
+    line["peak_hbm_gib"] = full.get("peak_hbm_gib")
+    if full.get("exchanges") is not None:
+        line["exchanges"] = _compact_exchanges(full["exchanges"])
+    mnist = (full.get("targets") or {}).get("mnist_mlp")
+    if isinstance(mnist, dict):
+        line["targets"] = {"mnist_mlp": {k: mnist.get(k) for k in ("ratio", "target_ratio", "scores_rel_F_vs_cpu_oracle", "target_rel",
+                                                                  "gpu_pairs_per_sec", "cpu_pairs_per_sec", "cpu_cores", "ms_per_step")}}
+    others = full.get("other_configs")
+    if isinstance(others, dict):
+        short = {}
+        for name, r in others.items():
+            if not isinstance(r, dict) or "error" in r:
+                short[name] = {"error": str((r or {}).get("error"))[:160]}
+                continue
+            rc, roof = r.get("config") or {}, r.get("roofline") or {}
+            parity = r.get("parity")
+            short[name] = {
+                "value": r.get("value"), "unit": r.get("unit"), "n_gpus": r.get("n_gpus"), "ms_per_step": r.get("ms_per_step"),
+                "config": {k: rc[k] for k in ("workload", "n_train", "n_query", "blocks", "query_passes", "parallelism") if k in rc},
+                "roofline": {k: roof.get(k) for k in ("frac", "traffic_over_algorithmic", "mfma_util") if k in roof},
+                "roofline_cov_frac": (r.get("roofline_cov") or {}).get("frac"),
+                "roofline_lambda_update_frac": (r.get("roofline_lambda_update") or {}).get("frac"),
+                "factor_fit": {"n_fit": (r.get("factor_fit") or {}).get("n_fit"), "seconds": (r.get("factor_fit") or {}).get("seconds")},
+                "device_busy": _compact_busy(r.get("device_busy")),
+            }
+            if isinstance(parity, dict):
+                short[name]["parity"] = ({"error": str(parity["error"])[:120]} if "error" in parity else
+                                         {k: parity.get(k) for k in ("scores_rel_F_vs_fp64_low_rank_contraction", "bound", "ok", "queries", "train_samples")
+                                          if k in parity})
+            if r.get("exchanges") is not None:
+                short[name]["exchanges"] = _compact_exchanges(r["exchanges"])
+        line["other_configs"] = short
+    line["extras_file"] = EXTRAS_FILE
+    return _sig(line)
+
+
+def render_line(full: dict) -> str:
+    """``json.dumps(compact_line(full))``, checked: one line, parses back, under the hard cap (sections are dropped in order of
+    dispensability if an unforeseen entry ever pushes it over -- the headline keys, ``roofline`` and ``cpu_baseline`` never are)."""
+    line = compact_line(full)
+    text = json.dumps(line, separators=(",", ":"))
+    for dispensable in ("other_configs", "exchanges", "targets", "device_busy", "roofline_lambda_update", "roofline_lambda", "roofline_cov"):
+        if len(text) <= LINE_HARD_CAP_BYTES:
+            break
+        line[dispensable] = {"moved_to": EXTRAS_FILE}
+        text = json.dumps(line, separators=(",", ":"))
+    assert "\n" not in text and len(text) <= LINE_HARD_CAP_BYTES, len(text)
+    assert json.loads(text)["metric"] == full.get("metric")
+    return text
+
+
+def emit(full: dict) -> None:
+    """Full object -> ``bench_extras.json`` (beside this script; best effort) and stderr; compact line -> the LAST stdout line."""
+    blob = json.dumps(full, default=str)
+    try:
+        with open(os.path.join(ROOT, EXTRAS_FILE), "w", encoding="utf-8") as handle:
+            handle.write(blob + "\n")
+    except OSError as error:
+        print(f"[bench] could not write {EXTRAS_FILE}: {error}", file=sys.stderr)
+    print("[bench extras] " + blob, file=sys.stderr, flush=True)
+    sys.stdout.flush()
+    print(render_line(full), flush=True)
+
+
 def _respawn_under_torchrun(gpus: int) -> None:
     """``python bench.py --gpus N`` typed WITHOUT a launcher (no ``WORLD_SIZE``): re-execute this very command line as
     N ranks of one node under ``torch.distributed.run`` (one process per GPU, RCCL) and relay its output -- rank 0 of the
@@ -1048,7 +1189,7 @@ def main() -> None:
         if rank == 0:
             line["other_configs"] = extras
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
