@@ -689,14 +689,31 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
         idx = list(DistributedSamplerWithStack(range(count), world, rank)) if world > 1 else None
         return ResidentLoader(subset, spec["train_batch"], idx)
 
+    # N > 1, the query side (score/query_exchange.py): strided query shard + per-layer all-gather over xGMI ("gather", the
+    # reference's way) or every rank preconditioning all queries itself ("replicate"); planned from bytes against flops
+    exchange_plan = None
+    if world > 1:
+        from kronfluence_amd.score import query_exchange as qx
+
+        def one_query_forward():
+            with torch.autocast(device_type="cuda", enabled=amp is not None, dtype=amp):
+                task.compute_measurement(batch=tuple(t[:1] for t in query), model=model)
+        exchange_plan = qx.plan_query_exchange(
+            layers, qx.probe_rows(model, one_query_forward), n_query, world,
+            score_dtype=torch.bfloat16 if low else torch.float32, precondition_dtype=torch.bfloat16 if low else torch.float32,
+            low_rank=spec.get("low_rank"), backend=dist.get_backend())
+    replicate_queries = exchange_plan is not None and exchange_plan.mode == "replicate"
+
     def query_loader(count: int = n_query):
-        if world > 1:
+        subset = query if count == n_query else tuple(t[:count] for t in query)
+        idx = None
+        if world > 1 and not replicate_queries:
             from torch.utils.data import DistributedSampler
 
             idx = list(DistributedSampler(range(count), world, rank, shuffle=False, drop_last=False))
-        else:
-            idx = None if count == n_query else list(range(count))
-        return ResidentLoader(query, per_dev_q, idx)
+        loader = ResidentLoader(subset, per_dev_q, idx)
+        loader.kf_replicated_queries = replicate_queries
+        return loader
 
     # -- factor fit (cov + eigen + lambda), timed per sub-stage.  Every exchange (factor all-reduce, eigenvector
     #    broadcasts) happens INSIDE the timed calls; every rank keeps the reduced factors in HBM (no host round trip).
@@ -927,7 +944,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             "parity": parity,
             # rank 0's collectives (RCCL over xGMI; all inside the timed regions): seconds are stream time between events
             # around each call -- for the query all-gather only the wait still exposed after overlapping with backward
-            "exchanges": ({"backend": dist.get_backend(), "ranks": world, "factor_fit": fit_exchanges,
+            "exchanges": ({"backend": dist.get_backend(), "ranks": world, "query_exchange": exchange_plan.mode,
+                           "query_exchange_plan": exchange_plan.to_dict(), "factor_fit": fit_exchanges,
                            "pairwise_timed_steps": score_exchanges} if world > 1 else None),
             "cpu_baseline": cpu,
         }

@@ -35,6 +35,9 @@ from kronfluence_amd.module.utils import get_tracked_module_names, make_modules_
 from kronfluence_amd.score.pairwise import (
     compute_pairwise_query_aggregated_scores_with_loaders, compute_pairwise_scores_with_loaders, load_pairwise_scores, pairwise_scores_exist, save_pairwise_scores,
 )
+from kronfluence_amd.score.query_exchange import (
+    backend_name, layer_shapes, mark_replicated, plan_query_exchange, probe_rows, requested_mode,
+)
 from kronfluence_amd.score.self import (
     compute_self_measurement_scores_with_loaders, compute_self_scores_with_loaders, load_self_scores, save_self_scores,
     self_scores_exist,
@@ -43,6 +46,7 @@ from kronfluence_amd.task import Task
 from kronfluence_amd.utils.constants import FACTOR_SAVE_PREFIX, FACTOR_TYPE, SCORE_SAVE_PREFIX, SCORE_TYPE
 from kronfluence_amd.utils.dataset import (
     DataLoaderKwargs, DistributedEvalSampler, DistributedSamplerWithStack, find_executable_batch_size, make_indices_partition,
+    send_to_device,
 )
 from kronfluence_amd.utils.exceptions import FactorsNotFoundError, TrackedModuleNotFoundError
 from kronfluence_amd.utils.save import load_file as load_safetensors
@@ -182,11 +186,14 @@ class Analyzer:
 
     def _get_dataloader(self, dataset: data.Dataset, per_device_batch_size: int, dataloader_params: Dict,
                         indices: Optional[Sequence[int]] = None, allow_duplicates: bool = False,
-                        stack: bool = False) -> data.DataLoader:
-        """Sampler choice as reference ``computer/computer.py:193-239``."""
+                        stack: bool = False, replicate: bool = False) -> data.DataLoader:
+        """Sampler choice as reference ``computer/computer.py:193-239``; ``replicate``: every rank iterates the whole dataset in
+        order (the replicated query side of ``score/query_exchange.py``)."""
         if indices is not None:
             dataset = data.Subset(dataset=dataset, indices=indices)
-        if self.state.use_distributed and not allow_duplicates:
+        if self.state.use_distributed and replicate:
+            sampler = SequentialSampler(dataset)
+        elif self.state.use_distributed and not allow_duplicates:
             sampler = DistributedEvalSampler(dataset, num_replicas=self.state.num_processes, rank=self.state.process_index)
         elif self.state.use_distributed and stack:
             sampler = DistributedSamplerWithStack(dataset, num_replicas=self.state.num_processes, rank=self.state.process_index)
@@ -651,8 +658,10 @@ class Analyzer:
 
                 train_batch = self._find_executable_batch_size(
                     probe, min(initial_per_device_train_batch_size_attempt, len(train_dataset) // score_args.data_partitions))
-            query_loader = self._get_dataloader(query_dataset, per_device_query_batch_size, params,
-                                                allow_duplicates=not score_args.aggregate_query_gradients)
+            replicate = self._replicate_queries(query_dataset, per_device_query_batch_size, params, score_args, factor_args, module_names)
+            query_loader = mark_replicated(self._get_dataloader(query_dataset, per_device_query_batch_size, params,
+                                                                allow_duplicates=not score_args.aggregate_query_gradients,
+                                                                replicate=replicate), replicate)
             train_loader = self._get_dataloader(train_dataset, train_batch, params, indices=list(range(start, end)),
                                                 allow_duplicates=not score_args.aggregate_train_gradients,
                                                 stack=not score_args.aggregate_train_gradients)
@@ -671,6 +680,33 @@ class Analyzer:
             self.state.wait_for_everyone()
         self._write_profile_summary(f"scores_{scores_name}_pairwise")
         return scores if self.state.is_main_process else None
+
+    def _replicate_queries(self, query_dataset: data.Dataset, per_device_query_batch_size: int, params: Dict,
+                           score_args: ScoreArguments, factor_args: FactorArguments, module_names: Optional[List[str]]) -> bool:
+        """Multi-rank runs: whether every rank preconditions ALL queries itself instead of all-gathering them
+        (``score/query_exchange.py``: ``KF_QUERY_EXCHANGE``, or in "auto" the bytes-against-flops plan from the layer shapes and the
+        rows per sample one no-grad forward of a single query shows).  The decision is the same on every rank (shapes, sizes and
+        the backend are) and is logged."""
+        if not self.state.use_distributed or score_args.aggregate_query_gradients:
+            return False
+        mode = requested_mode()
+        shapes = layer_shapes(self.model, module_names)
+        rows = [1] * len(shapes)
+        if mode == "auto":
+            first = next(iter(self._get_dataloader(query_dataset, 1, params, indices=[0], replicate=True)))
+            first = send_to_device(first, self.state.device)
+            enable_amp = score_args.amp_dtype is not None
+
+            def measure() -> None:
+                with torch.autocast(device_type=self.state.device.type, enabled=enable_amp, dtype=score_args.amp_dtype):
+                    self.task.compute_measurement(batch=first, model=self.model)
+            rows = probe_rows(self.model, measure, module_names)
+        plan = plan_query_exchange(shapes, rows, len(query_dataset), self.state.num_processes, score_dtype=score_args.score_dtype,
+                                   precondition_dtype=score_args.precondition_dtype, low_rank=score_args.query_gradient_low_rank,
+                                   backend=backend_name(), mode=mode)
+        self.logger.info(f"Query exchange: {plan.mode} ({plan.reason}).")
+        self.last_query_exchange_plan = plan
+        return plan.mode == "replicate"
 
     def aggregate_pairwise_scores(self, scores_name: str) -> Optional[SCORE_TYPE]:
         """Aggregates the partitioned score files once all of them exist (reference ``score_computer.py:466-482``)."""

@@ -20,6 +20,7 @@ from kronfluence_amd.module.utils import (
     update_factor_args,
     update_score_args,
 )
+from kronfluence_amd.score.query_exchange import is_replicated
 from kronfluence_amd.score.dot_product import (
     compute_aggregated_dot_products_with_loader, compute_dot_products_with_loader,
 )
@@ -68,9 +69,19 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
     prepare_modules(model, tracked_module_names, state.device)
 
     chunks: Dict[str, List[torch.Tensor]] = {}
-    total_query_batch_size = per_device_query_batch_size * state.num_processes
+    # Multi-rank query side (score/query_exchange.py): ``gather`` -- the reference's strided query shard + per-layer all-gather
+    # (precondition.py:166-214) -- or ``replicate`` -- the loader hands EVERY rank all queries in dataset order and nothing is
+    # exchanged.  Either way a window holds ``accumulation_steps x P x q`` queries per train pass, so the score chunks are the same.
+    replicated = bool(state.use_distributed and is_replicated(query_loader))
+    total_query_batch_size = per_device_query_batch_size * (1 if replicated else state.num_processes)
+    steps_per_window = score_args.query_gradient_accumulation_steps * (state.num_processes if replicated else 1)
     query_remainder = len(query_loader.dataset) % total_query_batch_size
     num_batches = len(query_loader)
+    expected = -(-len(query_loader.dataset) // total_query_batch_size)
+    if state.use_distributed and num_batches != expected:
+        raise ValueError(f"The query loader yields {num_batches} batches where {expected} are expected of a "
+                         f"{'replicated (unsharded)' if replicated else 'rank-sharded'} loader: build it with the sampler that matches "
+                         "`query_exchange.mark_replicated`.")
     enable_amp = score_args.amp_dtype is not None
     scale = _loss_scale(factor_args) if (enable_amp and factor_args.amp_dtype == torch.float16) else 1.0
     if scale != 1.0:
@@ -78,9 +89,9 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
 
     held = 0
     remaining = len(query_loader.dataset)  # queries still to be preconditioned (each rank ends up holding all of them)
-    window = score_args.query_gradient_accumulation_steps * total_query_batch_size
+    window = steps_per_window * total_query_batch_size
     set_query_capacity(model, tracked_module_names, min(window, remaining))
-    set_async_query_gather(model, tracked_module_names, bool(state.use_distributed))
+    set_async_query_gather(model, tracked_module_names, bool(state.use_distributed and not replicated))
     try:
         for query_index, query_batch in enumerate(query_loader):
             query_batch = send_to_device(query_batch, state.device)
@@ -91,14 +102,14 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
                 (measurement * scale if scale != 1.0 else measurement).backward()
             if factor_args.has_shared_parameters:
                 finalize_iteration(model, tracked_module_names)
-            if state.use_distributed:
+            if state.use_distributed and not replicated:
                 synchronize_modules(model, tracked_module_names, num_processes=state.num_processes)  # C4
                 if query_index == num_batches - 1 and query_remainder > 0:
                     truncate(model, tracked_module_names, keep_size=query_remainder)
             accumulate_iterations(model, tracked_module_names)
             del query_batch, measurement
             held += 1
-            if held < score_args.query_gradient_accumulation_steps and query_index != num_batches - 1:
+            if held < steps_per_window and query_index != num_batches - 1:
                 continue
             dot_products = (compute_aggregated_dot_products_with_loader if score_args.aggregate_train_gradients
                             else compute_dot_products_with_loader)

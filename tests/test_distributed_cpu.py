@@ -303,14 +303,18 @@ def _pipeline_many_ranks(rank, world, out_dir):
         torch.save({"fit_log": fit_log, "score_log": score_log}, os.path.join(out_dir, f"log_rank{rank}.pt"))
 
 
+@pytest.mark.parametrize("mode", ["gather", "replicate"])
 @pytest.mark.parametrize("world", [1, 3, 8])
-def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world, monkeypatch):
+def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world, mode, monkeypatch):
     """(P = 1: ONE rank with ``KF_DIST_FORCE=1`` -- every exchange still issued, each an identity; the form in which RCCL runs this
     path on the one-GPU test box, tests/test_distributed_gpu.py.)  P = 3 and P = 8 with N = 45 train samples (N % P != 0: the contiguous train shards are wrap-padded to ceil(N / P),
     utils/dataset.py:181-196, and the gathered score blocks cut back with ``cat[:, :N]``), Q = 11 queries at 2 per rank (Q % (q P) !=
     0: the strided query sampler pads with duplicates and the last round is truncated, score/pairwise.py:239-246), the 2 L = 6
     eigenproblems of the 3-layer fixture dealt over 8 ranks (two ranks own none), the factor fit strided without padding -- all
-    against the single-process run; and the bytes every exchange moved against the section-8(e) volumes BY FORMULA."""
+    against the single-process run; and the bytes every exchange moved against the section-8(e) volumes BY FORMULA.
+    ``mode``: the query side of the pairwise stage (score/query_exchange.py) -- ``gather`` is the reference's strided query shard +
+    per-layer all-gather, ``replicate`` has every rank precondition all queries itself: same scores, same train passes and score
+    gathers, and NOT ONE query byte exchanged."""
     from torch.utils import data
 
     from kronfluence_amd import Analyzer, FactorArguments, ScoreArguments, prepare_model
@@ -321,7 +325,9 @@ def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world, monkeypatc
     (tmp_path / "many").mkdir()
     if world == 1:
         monkeypatch.setenv("KF_DIST_FORCE", "1")
+    monkeypatch.setenv("KF_QUERY_EXCHANGE", mode)
     _run("_pipeline_many_ranks", tmp_path / "many", world=world)
+    monkeypatch.delenv("KF_QUERY_EXCHANGE")
     got = torch.load(tmp_path / "many" / "many_ranks.pt")
     task = make_task(c["kind"])
     model = prepare_model(fx.make_model(c["kind"]), task)
@@ -358,9 +364,12 @@ def test_whole_stages_on_odd_world_sizes(tmp_path, cpu_engine, world, monkeypatc
     # queries: ceil(Q / (q P)) rounds, each an all-gather of P q gradients per layer
     rounds = -(-c["n_query"] // (c["q"] * world))
     score = got["score_log"]
-    assert score["query_all_gather"]["calls"] == rounds * layers
-    # (every rank holds ceil(Q / P) queries after the sampler's wrap-around padding; the last round may be a partial batch)
-    assert score["query_all_gather"]["bytes"] == world * (-(-c["n_query"] // world)) * lam_floats * 4
+    if mode == "gather":
+        assert score["query_all_gather"]["calls"] == rounds * layers
+        # (every rank holds ceil(Q / P) queries after the sampler's wrap-around padding; the last round may be a partial batch)
+        assert score["query_all_gather"]["bytes"] == world * (-(-c["n_query"] // world)) * lam_floats * 4
+    else:
+        assert "query_all_gather" not in score   # replicated query side: zero calls, zero bytes
     # one train pass (and one gather) per query round; the rounds' blocks add up to [Q, ceil(N / P)] (the last round truncated)
     assert score["score_gather"]["calls"] == rounds
     assert score["score_gather"]["bytes"] == c["n_query"] * (-(-c["n_train"] // world)) * 4
@@ -507,3 +516,56 @@ def test_apply_ddp_then_analyzer_on_two_ranks(tmp_path, cpu_engine):
     assert one == two   # same files; module names carry no "module." prefix
     with pytest.raises(NotImplementedError, match="apply_ddp"):
         apply_fsdp(None, 0, 0, 1)
+
+
+# ---- the query-exchange plan: bytes over the interconnect against redundant flops (score/query_exchange.py) -----------------
+_GPT2 = [(2304, 769), (768, 769), (3072, 769), (768, 3073)] * 12
+
+
+def test_query_exchange_plan_prices_bytes_against_flops(monkeypatch):
+    from kronfluence_amd.score import query_exchange as qx
+
+    monkeypatch.delenv("KF_QUERY_EXCHANGE", raising=False)
+    monkeypatch.delenv("KF_XGMI_GBPS", raising=False)
+    rows = [512] * len(_GPT2)
+    bf16 = dict(score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16)
+    plan = qx.plan_query_exchange(_GPT2, rows, 1024, 8, backend="nccl", **bf16)
+    d = sum(o * i for o, i in _GPT2)
+    assert d == 85_017_600
+    assert plan.inbound_bytes == pytest.approx(1024 * d * 2 * 7 / 8)              # 152 GB inbound per rank (170 MB / query)
+    assert plan.gather_exchange_seconds == pytest.approx(plan.inbound_bytes / 350e9)   # ~0.44 s over xGMI -- seconds, not minutes
+    assert 0.3 < plan.gather_exchange_seconds < 0.6
+    assert plan.mode == "gather" and plan.replicate_seconds > 3 * plan.gather_seconds
+    assert 3e-3 < plan.replicate_seconds / 1024 < 8e-3                            # ~5 ms per GPT-2 query (measured r05)
+    # the same job over a host transport (gloo): the exchange would take minutes -> every rank preconditions all queries itself
+    slow = qx.plan_query_exchange(_GPT2, rows, 1024, 8, backend="gloo", **bf16)
+    assert slow.mode == "replicate" and slow.gather_exchange_seconds > 60
+    # forced modes are taken as they are; one rank never exchanges
+    assert qx.plan_query_exchange(_GPT2, rows, 1024, 8, backend="nccl", mode="replicate", **bf16).mode == "replicate"
+    assert qx.plan_query_exchange(_GPT2, rows, 1024, 1, backend="gloo", **bf16).mode == "gather"
+    monkeypatch.setenv("KF_XGMI_GBPS", "10")
+    assert qx.plan_query_exchange(_GPT2, rows, 1024, 8, backend="nccl", **bf16).mode == "replicate"
+    monkeypatch.setenv("KF_QUERY_EXCHANGE", "bogus")
+    with pytest.raises(ValueError):
+        qx.requested_mode()
+    # rank-64 factor pairs (C5): k (O + I') elements per layer and query
+    llama = [(14336, 4096), (14336, 4096), (4096, 14336)]
+    assert qx.held_elements_per_query(llama, 64) == 3 * 64 * (14336 + 4096)
+    assert qx.held_elements_per_query([(10, 1025)], 64) == 10 * 1025             # min(O, I') <= k: kept dense
+
+
+def test_a_sharded_loader_is_refused_in_replicated_mode(cpu_engine, monkeypatch):
+    """The stage loop checks the loader against the mode it was marked with (a rank-sharded loader marked replicated would
+    silently score a subset of the queries)."""
+    from kronfluence_amd.score.query_exchange import is_replicated, mark_replicated, probe_rows, layer_shapes
+
+    model = _model()
+    assert layer_shapes(model) == [(16, 11), (16, 17), (1, 17)] or len(layer_shapes(model)) == 3
+    x = fx.make_data("mlp", 4, seed=3)[0]
+    assert probe_rows(model, lambda: model(x)) == [1, 1, 1]
+    loader = [1, 2, 3]
+
+    class L(list):
+        pass
+    loader = mark_replicated(L(loader))
+    assert is_replicated(loader) and not is_replicated(L())
