@@ -623,7 +623,7 @@ def _device_busy(step: Callable[[int, int], object], count: int, queries: int) -
 # ------------------------------------------------------------------------------------------------
 def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int], steps: int, warmup: int,
                  factor_reps: int, cpu_baseline: bool, n_fit: Optional[int] = None, warm_n_train: Optional[int] = None,
-                 busy_n_train: Optional[int] = None, query_passes: Optional[int] = None) -> dict:
+                 busy_n_train: Optional[int] = None, query_passes: Optional[int] = None, phase_split: bool = False) -> dict:
     """``n_fit``: fit the factors on the first ``n_fit`` train samples only (the pairwise stage does not care how many samples
     the factors saw; used by the full-size extras to keep the default run within minutes -- reported in ``factor_fit.n_fit``).
     ``warm_n_train``: the warm-up steps score against the first ``warm_n_train`` train samples (one-time costs -- allocator
@@ -758,12 +758,17 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     t0 = time.perf_counter()
     scores = None
     step_ms = []
+    from kronfluence_amd.score import pairwise as pairwise_stage
+    # the extras (one timed step of tens of seconds) also split the step into its query phase and train passes: ONE more device
+    # synchronisation per held-query window; the headline's timed region is left untouched
+    pairwise_stage.STAGE_LOG = {} if phase_split else None
     for _ in range(steps):
         ts = time.perf_counter()
         scores = step()
         step_ms.append(1e3 * (time.perf_counter() - ts))
     barrier()
     elapsed = time.perf_counter() - t0
+    phases, pairwise_stage.STAGE_LOG = pairwise_stage.STAGE_LOG, None
     new_segments = torch.cuda.memory_stats().get("segment.all.allocated", 0) - seg0
     gc.enable()
     score_events, ops.EVENT_LOG = ops.EVENT_LOG, None          # the timed region's calls only (the diagnostics below run more steps)
@@ -910,6 +915,8 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
             "metric": "pairwise_influence_pairs_per_sec", "value": value, "unit": "pairs/s", "n_gpus": world,
             "steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps,
             "step_ms": [round(x, 2) for x in step_ms], "hipmalloc_segments_in_timed_region": new_segments,
+            # wall seconds of the timed steps by phase (rank 0; only where ``phase_split``): the two terms of DESIGN.md section 6's time model
+            "phase_seconds": ({k: v / steps for k, v in phases.items()} if phases else None),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16" if low else "f32",
             "data": "synthetic",
             "config": {"workload": name, "n_train": n_train, "n_query": n_query, "tracked_layers": len(layers),
@@ -1051,6 +1058,7 @@ def compact_line(full: dict) -> dict:
             parity = r.get("parity")
             short[name] = {
                 "value": r.get("value"), "unit": r.get("unit"), "n_gpus": r.get("n_gpus"), "ms_per_step": r.get("ms_per_step"),
+                "phase_seconds": r.get("phase_seconds"),
                 "config": {k: rc[k] for k in ("workload", "n_train", "n_query", "blocks", "query_passes", "parallelism") if k in rc},
                 "roofline": {k: roof.get(k) for k in ("frac", "traffic_over_algorithmic", "mfma_util") if k in roof},
                 "roofline_cov_frac": (r.get("roofline_cov") or {}).get("frac"),
@@ -1134,6 +1142,8 @@ def main() -> None:
     ap.add_argument("--query-passes", type=int, default=None, help="groups the query batches are accumulated in, one train pass each "
                     "(default: as few as fit 62 %% of the device memory)")
     ap.add_argument("--busy-n-train", type=int, default=None, help="train samples of the two extra steps behind ``device_busy`` (default: all)")
+    ap.add_argument("--phase-split", action="store_true", help="also report the step's query-phase / train-pass wall seconds (one more "
+                    "device synchronisation per held-query window inside the timed region)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
                     "searches its convolution kernels for the MODEL's own forward / backward during warm-up; ResNet-9 stage "
                     "907 -> 862 ms; nothing of the EK-FAC path is affected)")
@@ -1160,7 +1170,7 @@ def main() -> None:
 
     line = run_workload(args.workload, state, args.n_train, args.n_query, args.steps, args.warmup, args.factor_reps,
                         cpu_baseline=not args.no_cpu_baseline, n_fit=args.n_fit, warm_n_train=args.warm_n_train,
-                        query_passes=args.query_passes, busy_n_train=args.busy_n_train)
+                        query_passes=args.query_passes, busy_n_train=args.busy_n_train, phase_split=args.phase_split)
     default_run = (args.workload == "resnet9" and args.n_train is None and args.n_query is None and not args.no_extras
                    and os.environ.get("KF_BENCH_EXTRAS", "1") != "0")
     if default_run and world == 1:
@@ -1195,9 +1205,9 @@ def main() -> None:
                 if "blocks" in size:
                     WORKLOADS[other]["blocks"] = size["blocks"]
                 r = run_workload(other, state, size["n_train"], None, steps=1, warmup=1, factor_reps=size.get("factor_reps", 1), cpu_baseline=False,
-                                 n_fit=size["n_fit"], warm_n_train=size["warm_n_train"], busy_n_train=size.get("busy_n_train"))
+                                 n_fit=size["n_fit"], warm_n_train=size["warm_n_train"], busy_n_train=size.get("busy_n_train"), phase_split=True)
                 if rank == 0:
-                    extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "scaling", "config", "roofline",
+                    extras[other] = {k: r[k] for k in ("value", "unit", "n_gpus", "ms_per_step", "phase_seconds", "scaling", "config", "roofline",
                                                       "roofline_cov", "roofline_cov_f32", "roofline_lambda", "roofline_lambda_update", "factor_fit",
                                                       "exchanges", "peak_hbm_gib", "device_busy", "parity")}
             except Exception as error:  # an extra must never take the headline down with it

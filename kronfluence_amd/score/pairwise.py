@@ -30,6 +30,24 @@ from kronfluence_amd.utils.dataset import send_to_device
 from kronfluence_amd.utils.state import State, no_sync, paused_gc
 
 
+# Measurement hook (bench.py): when a dict, the stage adds the wall seconds of its two phases -- query phase (measurement passes +
+# preconditioner + exchange) and train passes -- to ``query_s`` / ``train_s``, with ONE device synchronisation per held-query window.
+STAGE_LOG: Optional[Dict[str, float]] = None
+
+
+def _mark(key: Optional[str], since: float) -> float:
+    import time
+
+    if STAGE_LOG is None:
+        return since
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    now = time.perf_counter()
+    if key is not None:
+        STAGE_LOG[key] = STAGE_LOG.get(key, 0.0) + (now - since)
+    return now
+
+
 def pairwise_scores_save_path(output_dir: Path, partition=None) -> Path:
     if partition is not None:
         return output_dir / f"pairwise_scores_data_partition{partition[0]}_module_partition{partition[1]}.safetensors"
@@ -92,6 +110,7 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
     window = steps_per_window * total_query_batch_size
     set_query_capacity(model, tracked_module_names, min(window, remaining))
     set_async_query_gather(model, tracked_module_names, bool(state.use_distributed and not replicated))
+    mark = _mark(None, 0.0)
     try:
         for query_index, query_batch in enumerate(query_loader):
             query_batch = send_to_device(query_batch, state.device)
@@ -113,8 +132,10 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
                 continue
             dot_products = (compute_aggregated_dot_products_with_loader if score_args.aggregate_train_gradients
                             else compute_dot_products_with_loader)
+            mark = _mark("query_s", mark)
             scores = dot_products(model=model, state=state, task=task, train_loader=train_loader, factor_args=factor_args,
                                   score_args=score_args, tracked_module_names=tracked_module_names, loss_scale=scale)
+            mark = _mark("train_s", mark)
             if state.is_main_process:
                 for key, value in scores.items():
                     chunks.setdefault(key, []).append(value)
