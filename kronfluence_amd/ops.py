@@ -696,7 +696,8 @@ class _Timed:
         self.start = None
 
     def __enter__(self):
-        if EVENT_LOG is not None:
+        # (never inside a hipGraph capture: events recorded there cannot be timed -- the eager batches of a pass carry the timing)
+        if EVENT_LOG is not None and not torch.cuda.is_current_stream_capturing():
             self.start, self.end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             self.start.record(torch.cuda.current_stream(self.device))
         return self
