@@ -862,3 +862,27 @@ def test_gpt2_query_passes_give_the_single_pass_scores(preset):
         want = engine.pairwise_scores(chunks(query, 2), chunks(train, 8), bench.lm_loss, bench.lm_loss, cpu_eig, cpu_lam, None)
         print(f"reduced GPT-2, fp32 preset, two query passes vs fp64 oracle end to end: rel_F {rel(two, want):.2e}")
         assert rel(two, want) <= 1e-3, rel(two, want)   # fp32 model + factors against an fp64 run: the reference's own fp32-vs-fp64 gap is 7e-5 on an MLP
+
+
+def test_llama_full_width_block_bench_parity(monkeypatch):
+    """C5 parity, pinned: ONE Llama-3-8B decoder block at FULL width (seven bias-free projections:
+    q / o 4096^2, k / v 1024 x 4096, gate / up 14336 x 4096, down 4096 x 14336), T = 512, the reference's rank-64 low-rank query
+    gradients (module/tracker/precondition.py:19-75), N = Q = 8, through the product's stage functions exactly as ``bench.py`` runs
+    ``llama_block`` -- covariances, eigendecompositions (three of 14336^2), Lambda, preconditioned rank-64 factor pairs, one train
+    pass -- and the scores of that pass against the oracle's fp64 restatement of "qik,qko,b...i,b...o->qb" (module/linear.py:83-99)
+    on the hooked tensors and the very factor pairs the product held, all seven layers summed: ``bench.LOW_RANK_PARITY_BOUND``,
+    the bound the bench line's ``parity`` object is judged by."""
+    import bench
+    from kronfluence_amd.utils.state import State
+
+    monkeypatch.setenv("KF_BENCH_BUSY", "0")
+    monkeypatch.setitem(bench.WORKLOADS["llama_block"], "blocks", 1)
+    result = bench.run_workload("llama_block", State(), 8, 8, steps=1, warmup=0, factor_reps=0, cpu_baseline=False)
+    parity = result["parity"]
+    assert parity is not None and "error" not in parity, parity
+    print(f"one full-width Llama block, 8 x 8, rank 64: scores rel_F {parity['scores_rel_F_vs_fp64_low_rank_contraction']:.2e} "
+          f"(bound {parity['bound']:.0e}); eigen {result['factor_fit']['seconds']['eigendecomposition']:.1f} s")
+    assert parity["queries"] == 8 and parity["train_samples"] == 8 and parity["layer_batches_checked"] == 7
+    assert parity["bound"] == bench.LOW_RANK_PARITY_BOUND == 2e-2
+    assert parity["ok"] and parity["scores_rel_F_vs_fp64_low_rank_contraction"] <= bench.LOW_RANK_PARITY_BOUND
+    assert result["config"]["blocks"] == 1 and result["config"]["tracked_layers"] == 7
