@@ -592,6 +592,7 @@ def _device_busy(step: Callable[[int, int], object], count: int, queries: int) -
             torch.cuda.synchronize()
         ours = model = copies = 0.0
         launches_ours = launches_model = 0
+        by_name: Dict[str, List[float]] = {}
         for e in prof.key_averages():
             if e.device_type != DeviceType.CUDA:
                 continue
@@ -604,7 +605,14 @@ def _device_busy(step: Callable[[int, int], object], count: int, queries: int) -
             else:
                 model += us
                 launches_model += e.count
+                entry = by_name.setdefault(e.key, [0.0, 0])
+                entry[0] += us
+                entry[1] += e.count
         busy = (ours + model + copies) * 1e-6
+        # who the "model" share is: MIOpen / hipBLASLt / ATen kernels by device time; the step runs after the
+        # timed region, so MIOpen's find-mode searches are long over
+        top_model = [{"kernel": k.split("(")[0][:96], "calls": int(v[1]), "seconds": v[0] * 1e-6, "frac_of_wall": v[0] * 1e-6 / wall}
+                     for k, v in sorted(by_name.items(), key=lambda kv: -kv[1][0])[:5]]
         # where the device waits: idle gaps (> 20 us) between consecutive device activities, summed by the activity that PRECEDES the gap
         spans = sorted((e.time_range.start, e.time_range.end, e.name) for e in prof.events() if e.device_type == DeviceType.CUDA)
         gaps: Dict[str, List[float]] = {}
@@ -619,7 +627,7 @@ def _device_busy(step: Callable[[int, int], object], count: int, queries: int) -
         return {"n_train": count, "n_query": queries, "wall_s": wall, "kf_kernel_s": ours * 1e-6, "model_kernel_s": model * 1e-6, "copy_s": copies * 1e-6,
                 "idle_gaps_over_20us_s": gap_total,
                 "largest_idle_after": [{"after": k.replace("(anonymous namespace)::", "").split("(")[0][:70], "gaps": len(v), "seconds": sum(v) * 1e-6} for k, v in top],
-                "kf_kernel_launches": launches_ours, "model_kernel_launches": launches_model,
+                "kf_kernel_launches": launches_ours, "model_kernel_launches": launches_model, "top_model_kernels": top_model,
                 "device_busy_frac": busy / wall, "idle_frac": max(0.0, 1.0 - busy / wall),
                 "kf_kernel_frac": ours * 1e-6 / wall, "model_kernel_frac": model * 1e-6 / wall,
                 "method": "torch profiler (device activity) on one extra step after the timed region; kernel durations / the wall "
@@ -657,6 +665,10 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
     model = prepare_model(raw_model, task).to(dev)
     train = make_data(spec, n_train, 1, dev)
     query = make_data(spec, n_query, 2, dev)
+    if spec.get("channels_last") and spec["kind"] == "image":
+        model = model.to(memory_format=torch.channels_last)
+        train = (train[0].contiguous(memory_format=torch.channels_last),) + tuple(train[1:])
+        query = (query[0].contiguous(memory_format=torch.channels_last),) + tuple(query[1:])
     amp = spec["amp"]
     low = amp == torch.bfloat16
     fargs = factor_arguments(spec)
@@ -934,6 +946,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                        **({"blocks": spec["blocks"]} if "blocks" in spec else {}),
                        "train_batch": spec["train_batch"], "factor_batch": spec["factor_batch"], "query_batch": per_dev_q,
                        "parallelism": f"train-shard-dp{world}",
+                       **({"memory_format": "channels_last"} if spec.get("channels_last") and spec["kind"] == "image" else {}),
                        **({"warmup_n_train": min(warm_n_train, n_train)} if warm_n_train else {}),
                        **({"scaled_from": {"n_train": spec.get("full_n_train"), "n_query": spec.get("full_n_query", spec["n_query"])}}
                           if n_train < spec.get("full_n_train", 0) else {})},
@@ -1151,6 +1164,8 @@ def main() -> None:
     ap.add_argument("--query-passes", type=int, default=None, help="groups the query batches are accumulated in, one train pass each "
                     "(default: as few as fit 62 %% of the device memory)")
     ap.add_argument("--busy-n-train", type=int, default=None, help="train samples of the two extra steps behind ``device_busy`` (default: all)")
+    ap.add_argument("--channels-last", action="store_true", help="image workloads: model and images in torch.channels_last (NHWC) memory "
+                    "format -- MIOpen's bf16 convolution kernels are NHWC kernels; with NCHW tensors it transposes around each of them")
     ap.add_argument("--phase-split", action="store_true", help="also report the step's query-phase / train-pass wall seconds (one more "
                     "device synchronisation per held-query window inside the timed region)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
@@ -1165,6 +1180,8 @@ def main() -> None:
         WORKLOADS[args.workload]["factor_batch"] = args.factor_batch
     if args.blocks:
         WORKLOADS["llama_block"]["blocks"] = args.blocks
+    if args.channels_last:
+        WORKLOADS[args.workload]["channels_last"] = True
     if not args.no_miopen_find:
         torch.backends.cudnn.benchmark = True
 

@@ -49,9 +49,12 @@ def gather_score_blocks(block: torch.Tensor, state: State, dataset_size: int) ->
 # and the allocator), the library never allocates or synchronises, so ONE batch -- forward, backward, every hook launch -- is
 # captured (``torch.cuda.graph``: stream capture into a private pool) writing its scores into a static ``[Q, b]`` block, and replayed
 # for each remaining full batch: inputs copied into the static batch, one ``hipGraphLaunch``, block added into the shard's columns.
-# ``KF_TRAIN_GRAPH`` = auto (default: when the pass has at least ``GRAPH_MIN_BATCHES`` equal batches and nothing stateful is in the
-# way -- shared parameters, per-token scores, host offload, the side stream, micro-batch pairing) | 1 (whenever possible) | 0 (never).
-# A capture that fails falls back to the eager loop for the rest of the pass (logged once).
+# ``KF_TRAIN_GRAPH`` = 0 (default: never) | auto (when the pass has at least ``GRAPH_MIN_BATCHES`` equal batches and nothing stateful
+# is in the way -- shared parameters, per-token scores, host offload, the side stream, micro-batch pairing) | 1 (whenever possible).
+# A capture that fails falls back to the eager loop for the rest of the pass (``GRAPH_LOG``).  OPT-IN because it does not pay on this
+# runtime (profiles/r06_train_graph_ab.log: ResNet-9 idle share 0.103 -> 0.058, step 787.6 -> 782.4 ms, +0.7 %: the idle share is
+# thousands of sub-20-us gaps between dependent kernels, which a graph launch does not remove) and because kernels launched from a
+# graph cannot be event-timed, which ``bench.py``'s per-launch roofline relies on.
 GRAPH_MIN_BATCHES = 6
 GRAPH_LOG: dict = {"captures": 0, "replays": 0, "fallbacks": 0, "last_error": None}
 
@@ -59,7 +62,7 @@ GRAPH_LOG: dict = {"captures": 0, "replays": 0, "fallbacks": 0, "last_error": No
 def _graph_mode() -> str:
     import os
 
-    return os.environ.get("KF_TRAIN_GRAPH", "auto").strip().lower()
+    return os.environ.get("KF_TRAIN_GRAPH", "0").strip().lower()
 
 
 def _tensors_of(batch):

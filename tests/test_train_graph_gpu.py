@@ -32,7 +32,7 @@ def _scores(kind, tmp_path, mode, monkeypatch, n_train, batch, score_kw=None, bf
     fargs = FactorArguments(use_empirical_fisher=True, **low,
                             **(dict(per_sample_gradient_dtype=torch.bfloat16, lambda_dtype=torch.bfloat16) if bf16 else {}))
     analyzer.fit_all_factors("f", train, per_device_batch_size=batch, factor_args=fargs)
-    sargs = ScoreArguments(damping_factor=None, **low,
+    sargs = ScoreArguments(damping_factor=None, query_gradient_accumulation_steps=64, **low,   # all queries held: ONE train pass
                            **(dict(score_dtype=torch.bfloat16, precondition_dtype=torch.bfloat16) if bf16 else {}), **(score_kw or {}))
     out = analyzer.compute_pairwise_scores("s", "f", query, train, per_device_query_batch_size=4, per_device_train_batch_size=batch,
                                            score_args=sargs, dataloader_kwargs=None)
