@@ -114,7 +114,8 @@ int kf_syrk_rows_bf16(float* C, int64_t ldc, const void* X, int64_t b, int64_t T
  * covariance is the sum of six bf16 products with fp32 accumulation (the three dropped products are below 2^-23 of the result).
  * LayerNorm outputs under autocast with fp32 factors (BERT) reach the covariance stage in fp32; the exact-fp32 MFMA instruction
  * behind kf_syrk_accum runs them at 1/16 of the bf16 rate.  mask: nullable [n], KF_I64 / KF_I32 / KF_U8 / KF_F32.  Needs
- * d_in % 8 == 0, 256 <= d_in < 32768; the row counter is the caller's business.
+ * d_in % 8 == 0, 256 <= d_in < 32768, n <= 65535 * 64 (KF_ERR_INVALID_ARGUMENT beyond: callers take kf_syrk_accum); the row
+ * counter is the caller's business.  Rows holding Inf become NaN here (x - bf16(x) = Inf - Inf), on kf_syrk_accum they stay Inf.
  */
 int64_t kf_syrk_rows_f32_workspace_bytes(int64_t n, int64_t d_in);
 int kf_syrk_rows_f32(float* C, int64_t ldc, const void* X, int64_t n, int64_t d_in, const void* mask, int mask_dtype, int append_ones,

@@ -2409,7 +2409,7 @@ int64_t kf_syrk_rows_f32_workspace_bytes(int64_t n, int64_t d_in) {
 int kf_syrk_rows_f32(float* C, int64_t ldc, const void* X, int64_t n, int64_t d_in, const void* mask, int mask_dtype, int append_ones,
                      float alpha, void* workspace, int64_t workspace_bytes, void* stream) {
     if (!C || !X || n < 0 || d_in <= 0) return KF_ERR_INVALID_ARGUMENT;
-    if (d_in % 8 != 0 || d_in < 256 || d_in >= 32768 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || n >= (1LL << 30)) return KF_ERR_INVALID_ARGUMENT;
+    if (d_in % 8 != 0 || d_in < 256 || d_in >= 32768 || (reinterpret_cast<uintptr_t>(X) & 15) != 0 || n > 65535LL * 64) return KF_ERR_INVALID_ARGUMENT;   // (one grid y-block per 64 rows)
     if (mask && mask_dtype != KF_I64 && mask_dtype != KF_I32 && mask_dtype != KF_U8 && mask_dtype != KF_F32) return KF_ERR_UNSUPPORTED_DTYPE;
     if (!workspace || workspace_bytes < kf_syrk_rows_f32_workspace_bytes(n, d_in)) return KF_ERR_WORKSPACE_TOO_SMALL;
     if (n == 0) return KF_OK;

@@ -145,6 +145,16 @@ def perform_eigendecomposition(covariance_factors: FACTOR_TYPE, model: nn.Module
                     break
             else:
                 seen[key].append((diag, index))
+    if world > 1 or (state.use_distributed and dist.is_initialized()):
+        # the decisions above are floating-point threshold tests on all-reduced covariances: equal on every rank in principle, but
+        # the number and order of the broadcasts below follow from them, so rank 0's map is THE map: one int64
+        # broadcast, -1 = solved on its own
+        table = torch.full((len(jobs),), -1, dtype=torch.int64)
+        for index, rep_index in alias.items():
+            table[index] = rep_index
+        table = table.to(state.device)
+        dist.broadcast(table, src=0)
+        alias = {index: int(rep) for index, rep in enumerate(table.tolist()) if rep >= 0}
     solved = [index for index in range(len(jobs)) if index not in alias]   # dealt round-robin over the ranks
     owner_of = {index: position % world for position, index in enumerate(solved)}
     mine = [jobs[index] for index in solved if world == 1 or owner_of[index] == state.process_index]

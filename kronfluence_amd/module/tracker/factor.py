@@ -58,6 +58,7 @@ def _to_covariance_dtype(t: torch.Tensor, dtype: torch.dtype) -> torch.Tensor:
 class _SharedInput:
     """The activation-covariance increment of the tensor the PREVIOUS tracked Linear consumed (see CovarianceTracker)."""
     ref = None          # weakref to that tensor object
+    mask_ref = None     # weakref to the attention mask the increment was formed under (None: no mask)
     version = -1        # its in-place version counter when it was consumed
     key = None          # everything else the increment depends on
     delta = None        # the increment X'^T X' in a buffer of its own (None: its owner accumulated in place)
@@ -83,7 +84,17 @@ class CovarianceTracker(BaseTracker):
         def shared_key(source: torch.Tensor):
             mask = module.attention_mask
             return (tuple(source.shape), source.dtype, module.factor_args.activation_covariance_dtype, module.has_bias,
-                    None if mask is None else (id(mask), mask._version))
+                    None if mask is None else mask._version)
+
+        def same_mask() -> bool:   # identity, through a weak reference: a recycled id() of a freed mask can never match
+            mask, held = module.attention_mask, CovarianceTracker._shared.mask_ref
+            return (mask is None and held is None) or (mask is not None and held is not None and held() is mask)
+
+        def remember(source: torch.Tensor) -> None:
+            shared = CovarianceTracker._shared
+            mask = module.attention_mask
+            shared.ref, shared.version, shared.key = weakref.ref(source), source._version, shared_key(source)
+            shared.mask_ref = None if mask is None else weakref.ref(mask)
 
         @torch.no_grad()
         def forward_hook(mod: nn.Module, inputs: Tuple[torch.Tensor], outputs: torch.Tensor) -> None:
@@ -91,14 +102,19 @@ class CovarianceTracker(BaseTracker):
             source = inputs[0]
             hooked = source.detach()
             shared = CovarianceTracker._shared
-            sharing = (self.SHARE_INPUT_INCREMENTS and type(module).__name__ == "TrackedLinear" and not module.factor_args.has_shared_parameters)
+            # (not beside the pass on a second stream: a leader's increment published from the side stream could be read by a follower
+            # on the main stream before it is complete -- ADVICE r05; the side stream is an opt-in experiment, sharing is the default)
+            sharing = (self.SHARE_INPUT_INCREMENTS and type(module).__name__ == "TrackedLinear" and not module.factor_args.has_shared_parameters
+                       and self._side_stream(hooked.device) is None)
             hit = (sharing and shared.ref is not None and shared.ref() is source and shared.version == source._version
-                   and shared.key == shared_key(source) and shared.owner is not self)
+                   and shared.key == shared_key(source) and same_mask() and shared.owner is not self)
 
             def update() -> None:
-                rows = _to_covariance_dtype(hooked, module.factor_args.activation_covariance_dtype)
                 cov, count = storage[ACTIVATION_COVARIANCE_MATRIX_NAME], storage[NUM_ACTIVATION_COVARIANCE_PROCESSED]
-                if hit and shared.delta is not None:   # follower: the leader's increment is this layer's increment
+                follower = hit and shared.delta is not None
+                # (a follower never touches the rows: no narrowing cast of the activation for nothing)
+                rows = None if follower else _to_covariance_dtype(hooked, module.factor_args.activation_covariance_dtype)
+                if follower:   # the leader's increment is this layer's increment
                     if cov is None:
                         cov, count = torch.zeros_like(shared.delta), torch.zeros_like(shared.count)
                     cov.add_(shared.delta)
@@ -109,14 +125,14 @@ class CovarianceTracker(BaseTracker):
                         cov, count = torch.zeros_like(delta), torch.zeros_like(rows_seen)
                     cov.add_(delta)
                     count.add_(rows_seen)
-                    shared.ref, shared.version, shared.key = weakref.ref(source), source._version, shared_key(source)
+                    remember(source)
                     shared.delta, shared.count, shared.owner = delta, rows_seen, self
                 else:
                     if hit:   # first sighting of the group: from the next batch on the previous layer publishes its increments
                         shared.owner._leads = True
                     cov, count = module.accumulate_activation_covariance(cov, count, rows)
                     if sharing and not hit:
-                        shared.ref, shared.version, shared.key = weakref.ref(source), source._version, shared_key(source)
+                        remember(source)
                         shared.delta, shared.count, shared.owner = None, None, self
                 storage[ACTIVATION_COVARIANCE_MATRIX_NAME] = cov
                 storage[NUM_ACTIVATION_COVARIANCE_PROCESSED] = count
@@ -161,7 +177,7 @@ class CovarianceTracker(BaseTracker):
         self._leads = False
         shared = CovarianceTracker._shared
         if shared.owner is self:
-            shared.ref = shared.delta = shared.count = shared.owner = None
+            shared.ref = shared.mask_ref = shared.delta = shared.count = shared.owner = None
 
 
 class LambdaTracker(BaseTracker):

@@ -126,6 +126,7 @@ def _syrk_rows_bf16(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Ten
 
 # fp32 rows of at least this many rows go through the exact three-term bf16 split (kf_syrk_rows_f32); KF_COV_F32_SPLIT=0: A/B, fallback
 COV_F32_SPLIT_MIN_ROWS = 1024
+COV_F32_SPLIT_MAX_ROWS = 65535 * 64
 
 
 def _syrk_rows_f32(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tensor], has_bias: bool, alpha: float) -> bool:
@@ -134,9 +135,12 @@ def _syrk_rows_f32(cov: torch.Tensor, x: torch.Tensor, mask: Optional[torch.Tens
     ``False`` when the shape / dtype is not eligible -- the exact-fp32 MFMA engine of ``syrk_accum`` takes those."""
     d_in = x.shape[-1]
     n = x.numel() // max(d_in, 1)
-    if not (x.is_cuda and x.dtype == torch.float32 and d_in % 8 == 0 and 256 <= d_in < COV_STAGED_MAX_DIM and n >= COV_F32_SPLIT_MIN_ROWS
+    # n: the split kernel's grid has one y-block per 64 rows (65 535 blocks at most); float masks (fractional weights: the count of
+    # ``kf_syrk_accum`` is a float sum, this path counts integers) stay on the exact-fp32 engine (ADVICE r05)
+    if not (x.is_cuda and x.dtype == torch.float32 and d_in % 8 == 0 and 256 <= d_in < COV_STAGED_MAX_DIM
+            and COV_F32_SPLIT_MIN_ROWS <= n <= COV_F32_SPLIT_MAX_ROWS
             and x.data_ptr() % 16 == 0 and os.environ.get("KF_COV_F32_SPLIT", "1") != "0"
-            and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool, torch.float32))):
+            and (mask is None or mask.dtype in (torch.int64, torch.int32, torch.uint8, torch.bool))):
         return False
     mask = _contig(mask) if mask is not None else None
     ws_bytes = nat.lib().kf_syrk_rows_f32_workspace_bytes(n, d_in)
