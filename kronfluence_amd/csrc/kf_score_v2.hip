@@ -523,6 +523,10 @@ struct RotateV3Args {
     const float* col_add; int col_add_m;
     int64_t c_inner, c_outer;
     int n_major;   // work order: consecutive items share the B (n) tile instead of the A (m) tile
+    // xcd_m = gm in {2, 4, 8} (0: the linear order above): the 8 XCDs form a gm x (8 / gm) grid over (m-tiles, n-tiles) -- an XCD owns
+    // ceil(tiles_m / gm) m-tiles, whose A rows (an eigenvector slab) then stay in ITS 4 MB L2 across all of its n-tiles, at the price
+    // of every B tile being read by gm XCDs.  See rotate_xcd_m().
+    int xcd_m;
     // EPI == 1 ("sum of squares over row groups"): rows are ordered (group, member) with `group_rows` members per group;
     // sumsq[group * ld_sumsq + n] += alpha^2 * sum_member C[(group, member), n]^2 and C itself is never stored.
     float* sumsq; int64_t ld_sumsq; int group_rows;
@@ -537,10 +541,20 @@ __global__ __launch_bounds__(pp::THREADS) void rotate_gemm_v3_kernel(RotateV3Arg
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
     const int64_t items = static_cast<int64_t>(a.tiles_m) * a.tiles_n, per_xcd = (items + 7) / 8;
     const int L = blockIdx.x, xcd = L & 7, j = L >> 3;
-    const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
-    if (j >= per_xcd || item >= items) return;
-    const int tm = v.n_major ? static_cast<int>(item % a.tiles_m) : static_cast<int>(item / a.tiles_n);
-    const int tn = v.n_major ? static_cast<int>(item / a.tiles_m) : static_cast<int>(item % a.tiles_n);
+    int tm, tn;
+    if (v.xcd_m > 0) {
+        const int gm = v.xcd_m, gn = 8 / gm;
+        const int mper = (a.tiles_m + gm - 1) / gm, nper = (a.tiles_n + gn - 1) / gn;
+        if (j >= mper * nper) return;
+        tm = (xcd % gm) * mper + j % mper;   // consecutive workgroups of an XCD: the same B tile against the XCD's few A tiles
+        tn = (xcd / gm) * nper + j / mper;
+        if (tm >= a.tiles_m || tn >= a.tiles_n) return;
+    } else {
+        const int64_t item = static_cast<int64_t>(xcd) * per_xcd + j;
+        if (j >= per_xcd || item >= items) return;
+        tm = v.n_major ? static_cast<int>(item % a.tiles_m) : static_cast<int>(item / a.tiles_n);
+        tn = v.n_major ? static_cast<int>(item / a.tiles_m) : static_cast<int>(item % a.tiles_n);
+    }
     const int m0 = tm * 256, n0 = tn * 256;
 
     pp::Sources src;
@@ -1998,6 +2012,28 @@ __global__ void cast_f32_bf16_kernel(uint16_t* dst, const float* src, int64_t n)
         dst[e] = static_cast<uint16_t>(w & 0xffffu);
     }
 }
+// XCD grid of a blocked rotation (RotateV3Args::xcd_m).  A = the eigenvector matrix (M x K, M = K = O or W: a few 256-row slabs of
+// K * 512 bytes), B = the rows being rotated (N = samples x rows: hundreds of tiles).  In the linear n-major order every XCD
+// streams ALL of A for each of its n-tiles: once A outgrows the 4 MB L2 (O >= 2048) that is tiles_n x |A| of Infinity-Cache
+// traffic per launch (GPT-2 c_fc, 128 sequences: 4.9 GB counted against 0.4 GB of B) -- the "8-10x algorithmic" of VERDICT r05
+// item 4.  With a gm x gn XCD grid an XCD works through ceil(tiles_m / gm) slabs only and B is read by gm XCDs instead.
+// Measured (profiles/r06_rotate_xcd_grid.log, two passes): d = 3072 (12 slabs) gm = 4: 1.27 -> 1.10 ms (GPT-2, 128 x 512 rows;
+// FETCH_SIZE 4.94 -> 3.38 GB), 1.12 -> 1.03 ms (BERT, 512 x 128); d = 14336 gm = 8: 1.40 -> 1.35 ms; d = 4096: 0.115 -> 0.112 ms
+// at any gm; d = 2304 (9 slabs: no gm divides them -- an XCD row would idle) and d = 768 (A fits L2) are fastest in the linear
+// order.  Hence: A beyond ~3 MB -> the largest gm in {8, 4, 2} that divides the m-tiles, else linear.  The kernel stays bound by
+// its MFMA / LDS schedule (0.98 -> 1.13 PFLOP/s), not by this traffic: the gain is the 5-13 % above.
+// KF_ROT_XCD_M = 0 / 2 / 4 / 8 overrides (A/B measurements).
+inline int rotate_xcd_m(int tiles_m, int tiles_n, int64_t K) {
+    if (const char* e = getenv("KF_ROT_XCD_M")) {
+        const int g = atoi(e);
+        return (g == 2 || g == 4 || g == 8) ? g : 0;
+    }
+    const int64_t slab = 256 * K * 2;                                  // bytes of one A tile
+    if (static_cast<int64_t>(tiles_m) * slab <= (3 << 20)) return 0;   // all of A is L2 resident anyway
+    for (int gm : {8, 4, 2})
+        if (tiles_m % gm == 0 && tiles_n >= 2 * (8 / gm)) return gm;
+    return 0;
+}
 // C[m, n] = alpha sum_k A[m, k] B[n, k] (+ col_add[m]) on the 256 x 256 loop, element (m, n) at (n / c_inner) * c_outer + m * c_inner + n % c_inner
 int launch_rotate_blocked(uint16_t* C, const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, int64_t M, int64_t N, int64_t K,
                           float alpha, const float* col_add, int col_add_m, int64_t c_inner, int64_t c_outer, hipStream_t st) {
@@ -2009,7 +2045,9 @@ int launch_rotate_blocked(uint16_t* C, const uint16_t* A, int64_t lda, const uin
     v.r.alpha = alpha; v.r.row_add = nullptr; v.r.row_add_n = 0;
     v.col_add = col_add; v.col_add_m = col_add_m; v.c_inner = c_inner; v.c_outer = c_outer;
     v.n_major = 1;   // the few m-tiles (eigenvectors: L2 resident) of one n-tile run back to back: the big operand is read once
-    const int64_t blocks = 8 * cdiv(static_cast<int64_t>(v.r.tiles_m) * v.r.tiles_n, 8);
+    v.xcd_m = rotate_xcd_m(v.r.tiles_m, v.r.tiles_n, K);
+    int64_t blocks = 8 * cdiv(static_cast<int64_t>(v.r.tiles_m) * v.r.tiles_n, 8);
+    if (v.xcd_m > 0) blocks = 8 * cdiv(v.r.tiles_m, v.xcd_m) * cdiv(v.r.tiles_n, 8 / v.xcd_m);
     with_pp_issue([&](auto iss) { hipLaunchKernelGGL((rotate_gemm_v3_kernel<0, decltype(iss)::value>), dim3(static_cast<unsigned>(blocks)), dim3(pp::THREADS), pp::SMEM_BYTES, st, v); });
     return launch_status();
 }

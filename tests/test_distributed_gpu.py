@@ -60,8 +60,13 @@ def _pipeline(world, rank, out_path):
     eig = perform_eigendecomposition(cov, model, state, fargs, cpu=False)
     _, lam = fit_lambda_matrices_with_loader(model, state, task, ResidentLoader(train, 8, shard(DistributedEvalSampler, N_TRAIN)), fargs, eig,
                                              all_ranks=True, cpu=False)
-    q_idx = list(DistributedSampler(range(N_QUERY), world, rank, shuffle=False, drop_last=False)) if world > 1 else None
-    scores = compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, ResidentLoader(query, 2, q_idx), 2,
+    # the query side (score/query_exchange.py): strided shard + per-layer all-gather, or every rank preconditioning all queries
+    replicate = os.environ.get("KF_QUERY_EXCHANGE") == "replicate"
+    q_idx = (list(DistributedSampler(range(N_QUERY), world, rank, shuffle=False, drop_last=False))
+             if (world > 1 and not replicate) else None)
+    query_loader = ResidentLoader(query, 2, q_idx)
+    query_loader.kf_replicated_queries = replicate and state.use_distributed
+    scores = compute_pairwise_scores_with_loaders({**eig, **lam}, model, state, task, query_loader, 2,
                                                   ResidentLoader(train, 10, shard(DistributedSamplerWithStack, N_TRAIN)),
                                                   sargs, fargs, None)
     cpu = lambda d: {k: {n: v.cpu() for n, v in m.items()} for k, m in d.items()}  # noqa: E731
@@ -75,10 +80,10 @@ def _pipeline(world, rank, out_path):
         torch.save({"cov": cpu(cov), "lam": cpu(lam)}, out_path + f".rank{rank}")
 
 
-def _worker(rank, world, port, out_path, backend="gloo", force=False):
+def _worker(rank, world, port, out_path, backend="gloo", force=False, mode="gather"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
                       LOCAL_RANK=str(rank if backend == "nccl" else 0), KF_DIST_BACKEND=backend,
-                      HSA_ENABLE_IPC_MODE_LEGACY="0", KF_DIST_FORCE="1" if force else "0")
+                      HSA_ENABLE_IPC_MODE_LEGACY="0", KF_DIST_FORCE="1" if force else "0", KF_QUERY_EXCHANGE=mode)
     import torch.distributed as dist
 
     from kronfluence_amd.utils import comm
@@ -95,8 +100,9 @@ def rel(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm())
 
 
+@pytest.mark.parametrize("mode", ["gather", "replicate"])
 @pytest.mark.parametrize("backend", ["gloo", "nccl"])
-def test_two_rank_pipeline_matches_single_process(tmp_path, backend):
+def test_two_rank_pipeline_matches_single_process(tmp_path, backend, mode):
     if backend == "nccl" and torch.cuda.device_count() < 2 and os.environ.get("KF_TEST_RCCL_SHARED_GPU") != "1":
         # (KF_TEST_RCCL_SHARED_GPU=1: try both ranks on the one GPU anyway -- RCCL refuses duplicate devices; kept for the record)
         pytest.skip("RCCL variant needs two visible GPUs (the 1-GPU test box runs the gloo variant)")
@@ -105,8 +111,11 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, backend):
         port = s.getsockname()[1]
     single, double = str(tmp_path / "w1.pt"), str(tmp_path / "w2.pt")
     mp.spawn(_worker, args=(1, port, single, backend), nprocs=1, join=True)
-    mp.spawn(_worker, args=(2, port + 1, double, backend), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, port + 1, double, backend, False, mode), nprocs=2, join=True)
     one, two = torch.load(single), torch.load(double)
+    # replicated query side: every rank ran all query batches itself -- not one query byte was exchanged
+    assert ("query_all_gather" in two["exchanges"]) == (mode == "gather"), two["exchanges"]
+    assert two["exchanges"]["score_gather"]["calls"] > 0
     other = torch.load(double + ".rank1")
     for name, per_module in two["cov"].items():  # rank 1 received the same all-reduced factors as rank 0
         for module, tensor in per_module.items():
@@ -124,7 +133,8 @@ def test_two_rank_pipeline_matches_single_process(tmp_path, backend):
     assert rel(two["scores"], one["scores"]) <= 1e-4, rel(two["scores"], one["scores"])
 
 
-def test_one_rank_over_rccl_runs_every_exchange(tmp_path):
+@pytest.mark.parametrize("mode", ["gather", "replicate"])
+def test_one_rank_over_rccl_runs_every_exchange(tmp_path, mode):
     """The test box has ONE GPU, so the two-rank RCCL variant above never runs there.  This one does: a one-rank process group on
     backend "nccl" (= RCCL) with ``KF_DIST_FORCE=1`` sends the sharded path through every collective a multi-rank job issues --
     bucketed factor all-reduce, eigendecomposition broadcasts, (asynchronous) query all-gather + interleave, score-block gather,
@@ -137,13 +147,16 @@ def test_one_rank_over_rccl_runs_every_exchange(tmp_path):
         port = s.getsockname()[1]
     plain, forced = str(tmp_path / "plain.pt"), str(tmp_path / "forced.pt")
     mp.spawn(_worker, args=(1, port, plain, "nccl", False), nprocs=1, join=True)
-    mp.spawn(_worker, args=(1, port + 1, forced, "nccl", True), nprocs=1, join=True)
+    mp.spawn(_worker, args=(1, port + 1, forced, "nccl", True, mode), nprocs=1, join=True)
     one, two = torch.load(plain), torch.load(forced)
     assert one["backend"] is None and two["backend"] == "nccl"
     assert not one["exchanges"]
     kinds = two["exchanges"]
-    for kind in ("factor_all_reduce", "eigen_broadcast", "query_all_gather", "score_gather"):
+    expected = ("factor_all_reduce", "eigen_broadcast", "score_gather") + (("query_all_gather",) if mode == "gather" else ())
+    for kind in expected:
         assert kinds.get(kind, {}).get("calls", 0) > 0 and kinds[kind]["bytes"] > 0, (kind, kinds)
+    if mode == "replicate":   # (``replicate``: the replicated query side of score/query_exchange.py issues no query collective)
+        assert "query_all_gather" not in kinds
     for name, per_module in one["cov"].items():
         for module, want in per_module.items():
             assert torch.equal(two["cov"][name][module], want), (name, module)
