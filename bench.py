@@ -87,10 +87,25 @@ class _Scale(nn.Module):
         return x * self.weight
 
 
+# The MODEL's batch norm (eval mode: a per-channel affine map) on ATen's own kernel instead of MIOpen's: ``MIOpenBatchNormFwdInferSpatialEst``
+# takes 0.32 ms per call on a [1000, C, H, W] bf16 batch -- 17 % of a ResNet-9 pairwise step (``device_busy.top_model_kernels``, round 6) --
+# about five times the HBM time of its operands.  Same module class, same arithmetic, a different library kernel: the same kind of
+# model-side setting as ``torch.backends.cudnn.benchmark`` below.  ``--miopen-batchnorm`` switches back.
+NATIVE_BATCH_NORM = True
+
+
+class _BatchNorm2d(nn.BatchNorm2d):
+    def forward(self, x):
+        if NATIVE_BATCH_NORM and not self.training and self.running_mean is not None:
+            # what F.batch_norm calls, with its last argument (``cudnn_enabled``: MIOpen on ROCm) off
+            return torch.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, False, 0.0, self.eps, False)
+        return super().forward(x)
+
+
 def resnet9() -> nn.Module:
     """Layer shapes of the CIFAR-10 ResNet-9 the reference's example analyses."""
     def block(cin, cout, k=3, stride=1, padding=1):
-        return nn.Sequential(nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False), nn.BatchNorm2d(cout), nn.ReLU())
+        return nn.Sequential(nn.Conv2d(cin, cout, k, stride=stride, padding=padding, bias=False), _BatchNorm2d(cout), nn.ReLU())
 
     return nn.Sequential(
         block(3, 64), block(64, 128, k=5, stride=2, padding=2),
@@ -947,6 +962,7 @@ def run_workload(name: str, state, n_train: Optional[int], n_query: Optional[int
                        "train_batch": spec["train_batch"], "factor_batch": spec["factor_batch"], "query_batch": per_dev_q,
                        "parallelism": f"train-shard-dp{world}",
                        **({"memory_format": "channels_last"} if spec.get("channels_last") and spec["kind"] == "image" else {}),
+                       **({"model_batch_norm": "aten" if NATIVE_BATCH_NORM else "miopen"} if name == "resnet9" else {}),
                        **({"warmup_n_train": min(warm_n_train, n_train)} if warm_n_train else {}),
                        **({"scaled_from": {"n_train": spec.get("full_n_train"), "n_query": spec.get("full_n_query", spec["n_query"])}}
                           if n_train < spec.get("full_n_train", 0) else {})},
@@ -1166,6 +1182,8 @@ def main() -> None:
     ap.add_argument("--busy-n-train", type=int, default=None, help="train samples of the two extra steps behind ``device_busy`` (default: all)")
     ap.add_argument("--channels-last", action="store_true", help="image workloads: model and images in torch.channels_last (NHWC) memory "
                     "format -- MIOpen's bf16 convolution kernels are NHWC kernels; with NCHW tensors it transposes around each of them")
+    ap.add_argument("--miopen-batchnorm", action="store_true", help="resnet9: the model's eval-mode batch norm on MIOpen's kernel again "
+                    "(default: ATen's; see NATIVE_BATCH_NORM)")
     ap.add_argument("--phase-split", action="store_true", help="also report the step's query-phase / train-pass wall seconds (one more "
                     "device synchronisation per held-query window inside the timed region)")
     ap.add_argument("--no-miopen-find", action="store_true", help="leave torch.backends.cudnn.benchmark off (default: on -- MIOpen "
@@ -1182,6 +1200,9 @@ def main() -> None:
         WORKLOADS["llama_block"]["blocks"] = args.blocks
     if args.channels_last:
         WORKLOADS[args.workload]["channels_last"] = True
+    if args.miopen_batchnorm:
+        global NATIVE_BATCH_NORM
+        NATIVE_BATCH_NORM = False
     if not args.no_miopen_find:
         torch.backends.cudnn.benchmark = True
 
