@@ -13,7 +13,7 @@ The train set is sharded, so every rank needs every query's preconditioned gradi
 Scores are identical (same per-query arithmetic, same held-query windows, same train passes); which is FASTER is a bytes-versus-
 flops question the plan below answers from the layer shapes -- like ``pairwise_score._low_rank_plan`` does for the contraction
 order.  On xGMI (7 links, ~0.54 TB/s inbound per GPU at line rate) moving an element costs ~6 ps while preconditioning it costs
-``4 (O + I')`` flops ~ 20 ps at the rate the query phase achieves, so ``gather`` wins for every BASELINE config; ``replicate`` wins
+``4 (O + I')`` flops ~ 9 ps at the rate the query phase achieves, so ``gather`` wins for every BASELINE config; ``replicate`` wins
 on slow transports (gloo, PCIe-only boxes) and is there to be forced (``KF_QUERY_EXCHANGE=replicate``) when the interconnect
 misbehaves.  DESIGN.md section 6 carries the time model with the predicted 1/2/4/8 curves of both modes.
 """
@@ -36,9 +36,10 @@ MODES = ("auto", "gather", "replicate")
 XGMI_ALLGATHER_GBPS = 350.0
 HOST_TRANSPORT_GBPS = 2.0
 # Rate of the QUERY phase (model forward / backward of the query batch, per-sample gradient, preconditioner), as a fraction of the
-# dense MFMA peak of the precondition dtype: GPT-2-small measures 1.65e12 flop per query in ~5 ms (r05: 2 000 queries, 8 s of
-# preconditioner kernels + the query passes) = 0.13 of 2.5 PF; the exact-fp32 engine sustains about half of its 157 TF.
-QUERY_PHASE_FRACTION = {torch.bfloat16: 0.13, torch.float16: 0.13, torch.float32: 0.5, torch.float64: 0.5}
+# dense MFMA peak of the precondition dtype, measured on one MI355X (round 6, ``bench.py --phase-split``): GPT-2-small 1.52e12
+# algorithmic flop per query in 2.23 ms = 0.27 of 2.5 PF, BERT-base 1.14e12 in 1.10 ms = 0.41; the lower one is used.  The
+# exact-fp32 engine sustains about half of its 157 TF.
+QUERY_PHASE_FRACTION = {torch.bfloat16: 0.27, torch.float16: 0.27, torch.float32: 0.5, torch.float64: 0.5}
 PEAK_TFLOPS = {torch.bfloat16: 2500.0, torch.float16: 2500.0, torch.float32: 157.3, torch.float64: 78.6}
 
 
