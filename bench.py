@@ -89,17 +89,23 @@ class _Scale(nn.Module):
 
 # The MODEL's batch norm (eval mode: a per-channel affine map) on ATen's own kernel instead of MIOpen's: ``MIOpenBatchNormFwdInferSpatialEst``
 # takes 0.32 ms per call on a [1000, C, H, W] bf16 batch -- 17 % of a ResNet-9 pairwise step (``device_busy.top_model_kernels``, round 6) --
-# about five times the HBM time of its operands.  Same module class, same arithmetic, a different library kernel: the same kind of
+# about five times the HBM time of its operands (tools/bn_probe.py: 427 us against 80 us for ATen's kernel at [1000, 64, 32, 32]).  Same module class, same arithmetic, a different library kernel: the same kind of
 # model-side setting as ``torch.backends.cudnn.benchmark`` below.  ``--miopen-batchnorm`` switches back.
 NATIVE_BATCH_NORM = True
 
 
 class _BatchNorm2d(nn.BatchNorm2d):
     def forward(self, x):
-        if NATIVE_BATCH_NORM and not self.training and self.running_mean is not None:
-            # what F.batch_norm calls, with its last argument (``cudnn_enabled``: MIOpen on ROCm) off
-            return torch.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, False, 0.0, self.eps, False)
-        return super().forward(x)
+        if not (NATIVE_BATCH_NORM and not self.training and x.is_cuda):
+            return super().forward(x)
+        # (this build ignores the ``cudnn_enabled`` argument of torch.batch_norm -- tools/bn_probe.py: MIOpen either way, 427 us --
+        # so the global switch is flipped around the call: ``batch_norm_transform_input_kernel``, 80 us on the same tensor)
+        enabled = torch.backends.cudnn.enabled
+        torch.backends.cudnn.enabled = False
+        try:
+            return super().forward(x)
+        finally:
+            torch.backends.cudnn.enabled = enabled
 
 
 def resnet9() -> nn.Module:
