@@ -867,22 +867,26 @@ def test_gpt2_query_passes_give_the_single_pass_scores(preset):
 def test_llama_full_width_block_bench_parity(monkeypatch):
     """C5 parity, pinned: ONE Llama-3-8B decoder block at FULL width (seven bias-free projections:
     q / o 4096^2, k / v 1024 x 4096, gate / up 14336 x 4096, down 4096 x 14336), T = 512, the reference's rank-64 low-rank query
-    gradients (module/tracker/precondition.py:19-75), N = Q = 8, through the product's stage functions exactly as ``bench.py`` runs
+    gradients (module/tracker/precondition.py:19-75), through the product's stage functions exactly as ``bench.py`` runs
     ``llama_block`` -- covariances, eigendecompositions (three of 14336^2), Lambda, preconditioned rank-64 factor pairs, one train
     pass -- and the scores of that pass against the oracle's fp64 restatement of "qik,qko,b...i,b...o->qb" (module/linear.py:83-99)
     on the hooked tensors and the very factor pairs the product held, all seven layers summed: ``bench.LOW_RANK_PARITY_BOUND``,
-    the bound the bench line's ``parity`` object is judged by."""
+    the bound the bench line's ``parity`` object is judged by (bench.py's own sizes: 64 train x 8 query sequences, the first train
+    batch of 8 checked)."""
     import bench
     from kronfluence_amd.utils.state import State
 
     monkeypatch.setenv("KF_BENCH_BUSY", "0")
     monkeypatch.setitem(bench.WORKLOADS["llama_block"], "blocks", 1)
-    result = bench.run_workload("llama_block", State(), 8, 8, steps=1, warmup=0, factor_reps=0, cpu_baseline=False)
+    # factors fitted on 64 sequences (32 768 tokens: every covariance, 14 336 wide at most, has full rank -- on 8 sequences the null space
+    # of the covariances meets the 1e-8 damping and the SAME kernels measure 4.1e-2), scores of 8 queries against the first 8 train sequences
+    result = bench.run_workload("llama_block", State(), 64, 8, steps=1, warmup=0, factor_reps=0, cpu_baseline=False)
     parity = result["parity"]
     assert parity is not None and "error" not in parity, parity
     print(f"one full-width Llama block, 8 x 8, rank 64: scores rel_F {parity['scores_rel_F_vs_fp64_low_rank_contraction']:.2e} "
           f"(bound {parity['bound']:.0e}); eigen {result['factor_fit']['seconds']['eigendecomposition']:.1f} s")
     assert parity["queries"] == 8 and parity["train_samples"] == 8 and parity["layer_batches_checked"] == 7
+    assert result["factor_fit"]["n_fit"] == 64
     assert parity["bound"] == bench.LOW_RANK_PARITY_BOUND == 2e-2
     assert parity["ok"] and parity["scores_rel_F_vs_fp64_low_rank_contraction"] <= bench.LOW_RANK_PARITY_BOUND
     assert result["config"]["blocks"] == 1 and result["config"]["tracked_layers"] == 7
