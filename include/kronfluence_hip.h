@@ -130,6 +130,18 @@ int kf_conv2d_cov_accum(float* Cov, int64_t ldc, const void* x, int64_t b, int64
                         void* stream);
 
 /*
+ * kf_conv2d_cov_small (ABI 13): Cov[I', I'] += alpha * sum_{n,p} patches'[n,p,:]^T patches'[n,p,:] for a convolution whose patch
+ * width I' = C*k1*k2 (+ 1 with append_ones: the bias column of module/conv2d.py:120-127) is AT MOST 32 -- the first layer of an
+ * image model -- straight from x [b, C, H, W] (NCHW contiguous; KF_F32 / KF_BF16 / KF_F16), groups == 1: no patch tensor, one
+ * fp32 MFMA (32x32x2) per two output positions, exact fp32 products and fp32 accumulation as kf_syrk_accum on fp32 rows.
+ * Replaces module/conv2d.py:15-64 (extract_patches, patch order (c, ky, kx)) + :106-128 + tracker/factor.py:58 for such layers
+ * (before: kf_im2col + kf_syrk_accum, a 110 MB fp32 patch matrix per ResNet-9 batch for a 27 x 27 result).  Both triangles are
+ * written.  KF_ERR_INVALID_ARGUMENT when I' > 32; the row counter (b * O1 * O2) is the caller's business.
+ */
+int kf_conv2d_cov_small(float* Cov, int64_t ldc, const void* x, int x_dtype, int64_t b, int64_t C, int64_t H, int64_t W, int k1,
+                        int k2, int s1, int s2, int p1, int p2, int d1, int d2, int append_ones, float alpha, void* stream);
+
+/*
  * out[b, P, I'] = unfold(group_mean(x))  (+ ones column), I' = C/groups*k1*k2 + append_ones,
  * P = O1*O2.  Replaces module/conv2d.py:15-64 (extract_patches: rearrange, reduce "mean",
  * F.unfold, transpose) and :120-127 (ones column).  x is NCHW contiguous.

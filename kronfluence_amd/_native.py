@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libkronfluence_hip.so"
-ABI_VERSION = 12
+ABI_VERSION = 13
 
 KF_F32, KF_BF16, KF_F16, KF_F64, KF_I64, KF_I32, KF_U8 = range(7)
 
@@ -55,6 +55,7 @@ SIGNATURES = {
     "kf_syrk_planes_bf16": (_i, [_p, _i64, _p, _i64, _i64, _i64, _f, _p, _i64, _p]),
     "kf_conv2d_cov_workspace_bytes": (_i64, [_i64] * 4 + [_i] * 8),
     "kf_conv2d_cov_accum": (_i, [_p, _i64, _p] + [_i64] * 4 + [_i] * 8 + [_f, _p, _i64, _p]),
+    "kf_conv2d_cov_small": (_i, [_p, _i64, _p, _i, _i64, _i64, _i64, _i64] + [_i] * 9 + [_f, _p]),
     "kf_im2col": (_i, [_p, _i, _p, _i, _i64, _i64, _i64, _i64] + [_i] * 10 + [_p]),
     "kf_gemm": (_i, [_p, _i64, _i64, ctypes.POINTER(kf_view), ctypes.POINTER(kf_view), _i64, _f, _f, _p, _i64, _p]),
     "kf_gemm_out": (_i, [_p, _i, _i64, _i64, ctypes.POINTER(kf_view), ctypes.POINTER(kf_view), _i64, _f, _p]),

@@ -408,6 +408,97 @@ __global__ void count_kernel(int64_t* count, const void* mask, int mask_dtype, i
 __global__ void add_count_kernel(int64_t* count, int64_t n) { *count += n; }
 
 // ------------------------------------------------------------------------------------------------
+// Activation covariance of a convolution with a SMALL patch width (round 6): d' = C k1 k2 (+ 1) <= 32 -- the first layer of an
+// image model (ResNet-9: 3 x 3 x 3 = 27 columns, 1 024 positions x 1 000 images = a million rows per batch).  The general path
+// materialised the fp32 patch matrix (110 MB per batch; im2col_kernel) and read it back through the 128 x 128 fp32 engine for a
+// 27 x 27 result: 0.8 ms per batch for 0.8 GFLOP.  Here ONE v_mfma_f32_32x32x2_f32 covers the whole result: lane l of a wave
+// holds the patch value P[pos + (l >> 5)][j = l & 31] gathered straight from the NCHW input (a lane's (c, ky, kx) never changes:
+// its input offset is one multiply-add per position; the image is L1 / L2 resident after its first touch), and that ONE register
+// is both MFMA operands -- A[i][k] = P[pos_k][i], B[k][j] = P[pos_k][j] -- so C += P^T P two positions per instruction, exact fp32
+// products, fp32 accumulation (the arithmetic of kf_syrk_accum on fp32 rows).  Reference: module/conv2d.py:15-64 (patch order
+// (c, ky, kx), zero padding), :106-128 (ones column), tracker/factor.py:58.
+// ------------------------------------------------------------------------------------------------
+struct ConvCovSmallArgs {
+    float* C; int64_t ldc;
+    const void* x;
+    int64_t b, Cin, H, W, O1, O2, npos;
+    int k1, k2, s1, s2, p1, p2, d1, d2, D, ones;
+    float alpha;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void conv_cov_small_kernel(ConvCovSmallArgs a) {
+    __shared__ float tile[32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int j = lane & 31, half = lane >> 5;
+    for (int e = tid; e < 32 * 33; e += 256) (&tile[0][0])[e] = 0.0f;
+    __syncthreads();
+    // this lane's patch column: (c, ky, kx) -> input offset relative to the top-left input pixel of a position
+    const int kk = a.k1 * a.k2;
+    const bool real = j < a.D;
+    const int c = real ? j / kk : 0, ky = real ? (j % kk) / a.k2 : 0, kx = real ? j % a.k2 : 0;
+    const int dy = ky * a.d1 - a.p1, dx = kx * a.d2 - a.p2;
+    const int64_t plane = a.H * a.W, coff = static_cast<int64_t>(c) * plane, image = a.Cin * plane;
+    const bool one = a.ones && j == a.D;
+    // waves take contiguous ranges of position PAIRS
+    const int64_t pairs = (a.npos + 1) / 2, waves = static_cast<int64_t>(gridDim.x) * 4, w = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    const int64_t per = (pairs + waves - 1) / waves, first = w * per, last = min(pairs, first + per);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.0f; acc1[r] = 0.0f; }
+    if (first < last) {
+        int64_t pos = 2 * first + half;
+        const int64_t P = a.O1 * a.O2;
+        int64_t n = pos / P;
+        int64_t rem = pos - n * P;
+        int oy = static_cast<int>(rem / a.O2), ox = static_cast<int>(rem - static_cast<int64_t>(oy) * a.O2);
+        auto value = [&]() -> float {
+            float v = 0.0f;
+            if (pos < a.npos) {
+                const int iy = oy * a.s1 + dy, ix = ox * a.s2 + dx;
+                if (real && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = load_t<DT>(a.x, n * image + coff + static_cast<int64_t>(iy) * a.W + ix);
+                else if (one) v = 1.0f;
+            }
+            return v;
+        };
+        auto advance = [&]() {   // two positions further (row-major over (n, oy, ox))
+            pos += 2;
+            ox += 2;
+            while (ox >= a.O2) { ox -= static_cast<int>(a.O2); if (++oy >= a.O1) { oy = 0; ++n; } }
+        };
+        int64_t it = first;
+        for (; it + 8 <= last; it += 8) {   // eight gathers in flight, then eight MFMAs on two accumulator chains
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { v[u] = value(); advance(); }
+#pragma unroll
+            for (int u = 0; u < 8; u += 2) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u], v[u], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(v[u + 1], v[u + 1], acc1, 0, 0, 0);
+            }
+        }
+        for (; it < last; ++it) {
+            const float v = value();
+            advance();
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(v, v, acc0, 0, 0, 0);
+        }
+    }
+    // the four waves' tiles -> one 32 x 32 tile in LDS -> coalesced fp32 atomics (alpha folded in)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * half;
+        atomicAdd(&tile[row][j], acc0[r] + acc1[r]);
+    }
+    __syncthreads();
+    const int dp = a.D + a.ones;
+    for (int e = tid; e < dp * dp; e += 256) {
+        const int row = e / dp, col = e - row * dp;
+        const float v = tile[row][col];
+        if (v != 0.0f) atomicAdd(a.C + static_cast<int64_t>(row) * a.ldc + col, a.alpha * v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // im2col (conv2d.py:15-64): out[b, p, i] with i = (c, ky, kx); group mean folded in
 // ------------------------------------------------------------------------------------------------
 struct Im2colArgs {
@@ -463,12 +554,16 @@ __global__ void im2col_vec8_kernel(Im2colArgs a) {
         // a branch around a load makes the compiler serialise the eight gathers behind one another.
         uint32_t raw[8];
         bool inside[8];
+        // (round 6: the ones column of a biased layer -- element I' - 1 of the LAST octet when C k1 k2 = 7 mod 8 -- used to be gathered
+        // like a patch element, from channel C: one element past the image and not a one; found by kf_conv2d_cov_small's tests)
+        const int real = Ip - a.append_ones;
+        const uint32_t one_bits = a.out_dtype == KF_BF16 ? 0x3F80u : 0x3C00u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int iy = by + ky * a.d1, ix = bx + kx * a.d2;
-            inside[j] = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            inside[j] = iy >= 0 && iy < H && ix >= 0 && ix < W && i0 + j < real;
             const int cy = min(max(iy, 0), H - 1), cx = min(max(ix, 0), W - 1);
-            const int64_t src = img + (static_cast<int64_t>(c) * H + cy) * W + cx;
+            const int64_t src = img + (static_cast<int64_t>(min(c, static_cast<int>(a.C) - 1)) * H + cy) * W + cx;
             if (same_dtype) {
                 raw[j] = reinterpret_cast<const uint16_t*>(a.x)[src];
             } else {
@@ -481,7 +576,7 @@ __global__ void im2col_vec8_kernel(Im2colArgs a) {
         uint32_t w[4];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const uint32_t bits = inside[j] ? raw[j] : 0u;
+            const uint32_t bits = inside[j] ? raw[j] : (i0 + j == real ? one_bits : 0u);   // (i0 + j == real only with append_ones)
             if (j & 1) w[j >> 1] |= bits << 16; else w[j >> 1] = bits;
         }
         typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
@@ -850,7 +945,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 12; }
+int kf_abi_version(void) { return 13; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -923,6 +1018,34 @@ int kf_syrk_accum(float* C, int64_t ldc, const void* X, int in_dtype, int64_t n_
     else KF_SYRK_MASKS(F16);
 #undef KF_SYRK_MASKS
 #undef KF_SYRK_CASE
+    return launch_status();
+}
+
+int kf_conv2d_cov_small(float* Cov, int64_t ldc, const void* x, int x_dtype, int64_t b, int64_t C, int64_t H, int64_t W, int k1, int k2,
+                        int s1, int s2, int p1, int p2, int d1, int d2, int append_ones, float alpha, void* stream) {
+    if (!Cov || !x || b < 0 || C <= 0 || H <= 0 || W <= 0 || k1 <= 0 || k2 <= 0 || s1 <= 0 || s2 <= 0 || d1 <= 0 || d2 <= 0 || p1 < 0 || p2 < 0)
+        return KF_ERR_INVALID_ARGUMENT;
+    if (x_dtype != KF_F32 && x_dtype != KF_BF16 && x_dtype != KF_F16) return KF_ERR_UNSUPPORTED_DTYPE;
+    ConvCovSmallArgs a;
+    a.C = Cov; a.ldc = ldc; a.x = x; a.b = b; a.Cin = C; a.H = H; a.W = W;
+    a.k1 = k1; a.k2 = k2; a.s1 = s1; a.s2 = s2; a.p1 = p1; a.p2 = p2; a.d1 = d1; a.d2 = d2;
+    a.O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1;
+    a.O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
+    if (a.O1 <= 0 || a.O2 <= 0) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t D = C * k1 * k2;
+    a.ones = append_ones ? 1 : 0;
+    if (D + a.ones > 32 || ldc < D + a.ones) return KF_ERR_INVALID_ARGUMENT;   // wider patches: kf_conv2d_cov_accum / kf_im2col + kf_syrk_accum
+    a.D = static_cast<int>(D);
+    a.npos = b * a.O1 * a.O2;
+    if (a.npos >= (1LL << 40)) return KF_ERR_INVALID_ARGUMENT;
+    if (a.npos == 0) return KF_OK;
+    a.alpha = alpha;
+    // one workgroup per CU at most; at least 64 position pairs per wave
+    const unsigned grid = static_cast<unsigned>(std::max<int64_t>(1, std::min<int64_t>(256, cdiv(a.npos, 2 * 64 * 4))));
+    hipStream_t st = as_stream(stream);
+    if (x_dtype == KF_F32) hipLaunchKernelGGL(conv_cov_small_kernel<F32>, dim3(grid), dim3(256), 0, st, a);
+    else if (x_dtype == KF_BF16) hipLaunchKernelGGL(conv_cov_small_kernel<BF16>, dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(conv_cov_small_kernel<F16>, dim3(grid), dim3(256), 0, st, a);
     return launch_status();
 }
 

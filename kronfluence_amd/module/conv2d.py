@@ -68,6 +68,18 @@ class TrackedConv2d(TrackedModule, module_type=nn.Conv2d):
                 count = torch.zeros(1, dtype=torch.int64, device=input_activation.device)
             ops.conv2d_cov_accum(cov, count, input_activation, self.original_module, geometry)
             return cov, count
+        conv = self.original_module
+        d_small = (input_activation.shape[1] * self.kernel_size[0] * self.kernel_size[1] + int(self.has_bias)
+                   if (input_activation.dim() == 4 and conv.groups == 1) else 33)
+        if d_small <= 32:  # a first layer's few patch columns: one fp32 MFMA per two positions, no patch tensor (kf_conv2d_cov_small)
+            fresh = cov is None
+            if fresh:
+                cov = torch.zeros((d_small, d_small), dtype=torch.float32, device=input_activation.device)
+                count = torch.zeros(1, dtype=torch.int64, device=input_activation.device)
+            if ops.conv2d_cov_small(cov, count, input_activation, conv):
+                return cov, count
+            if fresh:
+                cov = count = None
         patches = self._patches(input_activation)
         d = patches.shape[-1]
         if cov is None:

@@ -259,11 +259,41 @@ def conv2d_cov_accum(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, co
     count.add_(n)
 
 
+def conv2d_cov_small(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d) -> bool:
+    """Patch width ``C k1 k2 (+ 1) <= 32`` (the first layer of an image model): covariance straight from the NCHW input of any
+    float dtype on one fp32 MFMA per two positions (kf_conv2d_cov_small); ``False`` when the layer is not eligible."""
+    if not (x.is_cuda and x.dim() == 4 and x.dtype in (torch.float32, torch.bfloat16, torch.float16)) or conv.groups != 1:
+        return False
+    ones = conv.bias is not None
+    b, c, h, w = x.shape
+    k1, k2, s1, s2, p1, p2, d1, d2 = conv_geometry(conv)
+    d = c * k1 * k2
+    if d + int(ones) > 32 or os.environ.get("KF_CONV_COV_SMALL", "1") == "0":
+        return False
+    o1 = (h + 2 * p1 - d1 * (k1 - 1) - 1) // s1 + 1
+    o2 = (w + 2 * p2 - d2 * (k2 - 1) - 1) // s2 + 1
+    if o1 <= 0 or o2 <= 0:
+        return False
+    x = _contig(x, align=False)
+    n = b * o1 * o2
+    with _Timed("syrk_accum_f32" if x.dtype == torch.float32 else "syrk_accum", x.device, float(n) * (d + ones) * (d + ones + 1),
+                float(x.numel()) * x.element_size()):
+        nat.check(
+            nat.lib().kf_conv2d_cov_small(cov.data_ptr(), cov.shape[1], x.data_ptr(), nat.dtype_code(x.dtype), b, c, h, w,
+                                          k1, k2, s1, s2, p1, p2, d1, d2, int(ones), 1.0, nat.stream_ptr(x.device)),
+            "kf_conv2d_cov_small",
+        )
+    count.add_(n)
+    return True
+
+
 def conv_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d) -> None:
     """module/conv2d.py:106-128 + tracker/factor.py:58."""
     geometry = conv2d_cov_geometry(x, conv)
     if geometry is not None:
         conv2d_cov_accum(cov, count, x, conv, geometry)
+        return
+    if conv2d_cov_small(cov, count, x, conv):
         return
     patches = im2col(x, conv, conv.bias is not None, x.dtype if x.dtype != torch.float64 else torch.float32)
     n, d = patches.shape[0] * patches.shape[1], patches.shape[2]

@@ -174,6 +174,10 @@ def conv2d_cov_geometry(x, conv):
     return None  # no implicit-im2col covariance in the stand-in engine
 
 
+def conv2d_cov_small(cov, count, x, conv) -> bool:
+    return False  # nor the small-patch kernel: the patch path
+
+
 def conv2d_score_geometry(x_shape, out_channels, conv):
     return None  # the stand-in engine has no implicit-im2col path: the trackers take the patch path
 
@@ -210,7 +214,7 @@ def cast(src, dtype):
 
 
 LEAVES = ("view", "gemm", "rotate_bf16", "rotate_rows_transposed", "lambda_rows_accum", "eigh_stats", "syrk_accum", "im2col", "eigh", "eigh_small", "lambda_accum", "inv_lambda", "precondition",
-          "pairwise_score", "conv2d_cov_geometry", "conv2d_score_geometry", "pairwise_score_conv2d", "pairwise_score_rows", "rowwise_dot", "mul_bcast", "cast")
+          "pairwise_score", "conv2d_cov_geometry", "conv2d_cov_small", "conv2d_score_geometry", "pairwise_score_conv2d", "pairwise_score_rows", "rowwise_dot", "mul_bcast", "cast")
 
 
 class _Setter:

@@ -120,6 +120,68 @@ def test_conv_covariances(ops, c):
     assert rel(gcov, gwant) <= TOL and int(gcnt) == gcount
 
 
+@pytest.mark.parametrize("c", [
+    dict(b=7, cin=3, k=3, stride=1, padding=1, dilation=1, hw=(32, 32), bias=False),           # ResNet-9's first layer: 27 columns
+    dict(b=3, cin=3, k=3, stride=1, padding=1, dilation=1, hw=(16, 16), bias=True),            # + the bias column: 28
+    dict(b=1, cin=1, k=5, stride=2, padding=0, dilation=1, hw=(13, 13), bias=True),            # 26 columns, 25 positions: an odd count
+    dict(b=5, cin=2, k=(2, 3), stride=(1, 2), padding=(1, 0), dilation=(2, 1), hw=(9, 11), bias=False),
+    dict(b=4, cin=8, k=2, stride=2, padding=0, dilation=1, hw=(8, 8), bias=False),             # exactly 32 columns
+    dict(b=2, cin=31, k=1, stride=1, padding=0, dilation=1, hw=(5, 7), bias=True),             # 1 x 1 kernel, 32 with the bias column
+])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_conv_activation_cov_small_patches(ops, c, dtype, monkeypatch):
+    """kf_conv2d_cov_small: patch width C k1 k2 (+ 1) <= 32 straight from the NCHW input on one fp32 MFMA per two positions, in the
+    reference's (c, ky, kx) order with its zero padding and ones column, against conv2d.py:15-64,106-128 + factor.py:58 in fp64 --
+    and against the materialised path (kf_im2col + kf_syrk_accum) it replaces."""
+    conv = nn.Conv2d(c["cin"], 4, c["k"], stride=c["stride"], padding=c["padding"], dilation=c["dilation"], bias=c["bias"])
+    x = _rand(c["b"], c["cin"], *c["hw"], dtype=dtype)
+    flat, count = ref.conv_flat_activation(x.double(), conv.double())
+    d = flat.shape[1]
+    assert d <= 32
+    want = torch.zeros(d, d, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    xd = x.to(DEV)
+    cov = torch.zeros(d, d, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    if dtype == torch.bfloat16 and ops.conv2d_cov_geometry(xd, conv) is not None:
+        pytest.skip("bf16 layer taken by the LDS-DMA implicit-im2col kernel")
+    assert ops.conv2d_cov_small(cov, cnt, xd, conv)
+    ops.conv_activation_cov(cov, cnt, xd, conv)                      # the dispatcher takes the same kernel: accumulates
+    assert rel(cov, 2 * want) <= TOL, rel(cov, 2 * want)
+    assert int(cnt) == 2 * count and rel(cov, cov.t()) <= 1e-6       # both triangles written (fp32 atomics: equal up to their order)
+    monkeypatch.setenv("KF_CONV_COV_SMALL", "0")
+    old = torch.zeros(d, d, device=DEV)
+    ocnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    assert not ops.conv2d_cov_small(old, ocnt, xd, conv)
+    ops.conv_activation_cov(old, ocnt, xd, conv)
+    assert rel(cov, 2 * old) <= TOL and int(ocnt) == count
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("cin,k", [(31, 1), (7, 3), (5, (3, 1))])
+def test_im2col_ones_column_in_the_last_octet(ops, dtype, cin, k):
+    """A biased layer whose augmented patch width C k1 k2 + 1 is a multiple of 8, 2-byte patches (the 16-byte-store kernel): the
+    ones column is element I' - 1 of the last octet (module/conv2d.py:120-127).  Round 6 found it gathered from channel C -- one
+    element past the image -- instead; exact against the reference's patches now."""
+    conv = nn.Conv2d(cin, 4, k, padding=1, bias=True)
+    x = _rand(3, cin, 6, 9, dtype=dtype)
+    flat, _ = ref.conv_flat_activation(x.double(), conv.double())
+    assert flat.shape[1] % 8 == 0
+    patches = ops.im2col(x.to(DEV), conv, True, dtype)
+    assert torch.equal(patches.reshape(-1, flat.shape[1]).double().cpu(), flat)          # a gather: bit exact
+    assert bool((patches[..., -1] == 1).all())
+
+
+def test_conv_activation_cov_small_declines_wide_patches(ops):
+    conv = nn.Conv2d(4, 4, 3, padding=1, bias=False)                 # 36 columns
+    x = _rand(2, 4, 8, 8).to(DEV)
+    cov = torch.zeros(36, 36, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    assert not ops.conv2d_cov_small(cov, cnt, x, conv) and int(cnt) == 0
+    grouped = nn.Conv2d(4, 4, 3, padding=1, groups=2, bias=False)    # groups: the reference averages them (conv2d.py:55-56)
+    assert not ops.conv2d_cov_small(torch.zeros(18, 18, device=DEV), cnt, x, grouped)
+
+
 # ---- GEMM building block -------------------------------------------------------------------------
 @pytest.mark.parametrize("n,d,m,ones", [(5, 7, 3, False), (300, 129, 130, True), (1000, 1024, 1025, True)])
 def test_matmul_nn_asymmetric(ops, n, d, m, ones):
