@@ -26,20 +26,20 @@ from kronfluence_amd.utils.constants import (
     ACCUMULATED_PRECONDITIONED_GRADIENT_NAME, AGGREGATED_GRADIENT_NAME, ALL_MODULE_NAME, SCORE_TYPE,
 )
 from kronfluence_amd.utils.dataset import find_batch_size, send_to_device
-from kronfluence_amd.utils.state import State, no_sync
+from kronfluence_amd.utils.state import State, no_sync, to_host
 
 
 def gather_score_blocks(block: torch.Tensor, state: State, dataset_size: int) -> torch.Tensor:
     """C5: rank 0 receives every rank's ``[Q, ceil(N/P)]`` block and concatenates them along the
     train axis, dropping the wrap-around padding (reference ``dot_product.py:141-150``)."""
     if not state.use_distributed:
-        return block[:, :dataset_size].cpu()
+        return to_host(block[:, :dataset_size])
     gather_list = [torch.empty_like(block) for _ in range(state.num_processes)] if state.is_main_process else None
     with exchange("score_gather", block.numel() * block.element_size()):
         dist.gather(block, gather_list, dst=0)
     if state.is_main_process:
-        return torch.cat(gather_list, dim=1)[:, :dataset_size].cpu()
-    return block.cpu()
+        return to_host(torch.cat(gather_list, dim=1)[:, :dataset_size])
+    return to_host(block)
 
 
 # ---- the train-side step as a hipGraph ---------------------------------------------------------------------------------------
@@ -235,6 +235,6 @@ def compute_aggregated_dot_products_with_loader(model: nn.Module, task: Task, st
     model.zero_grad(set_to_none=True)
     set_score_sink(model, None, tracked_module_names)
     set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=False)
-    total_scores: SCORE_TYPE = {key: sink.result().to(score_args.score_dtype).cpu() for key, sink in sinks.items()}
+    total_scores: SCORE_TYPE = {key: to_host(sink.result().to(score_args.score_dtype)) for key, sink in sinks.items()}
     state.wait_for_everyone()
     return total_scores

@@ -150,7 +150,8 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
 
     total: SCORE_TYPE = {}
     if state.is_main_process:
-        total = {key: torch.cat(parts, dim=0) for key, parts in chunks.items()}
+        # (one chunk -- all queries held at once -- is handed over as it is: no second host copy)
+        total = {key: parts[0] if len(parts) == 1 else torch.cat(parts, dim=0) for key, parts in chunks.items()}
     model.zero_grad(set_to_none=True)
     set_gradient_scale(model, 1.0)
     set_query_capacity(model, tracked_module_names, None)

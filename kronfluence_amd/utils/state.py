@@ -106,6 +106,27 @@ def paused_gc():
             gc.enable()
 
 
+# Score blocks leave the device through PINNED host memory (torch's caching host allocator: blocks are reused, never unmapped).
+# ``tensor.cpu()`` allocates fresh pageable memory for every result: glibc serves such sizes by mmap / munmap, and on this stack an
+# unmap of memory the GPU driver has pinned for a pageable copy stalls the process for tens of milliseconds -- every third
+# MNIST-MLP pairwise step took 78 ms instead of 10.4 (a 65 ms "Memcpy DtoH" of 400 KB, an 84 ms ``torch.cat`` of one chunk:
+# tools/r06_timeline.py) -- and a pageable copy goes through bounce buffers (200 MB of ResNet-9 scores per step).  Results above
+# ``PINNED_HOST_LIMIT`` bytes stay pageable (pinned memory is not swappable); ``KF_PINNED_SCORES=0`` switches the old path back.
+PINNED_HOST_LIMIT = 4 << 30
+
+
+def to_host(tensor: torch.Tensor) -> torch.Tensor:
+    """The tensor in host memory (as ``tensor.cpu()``), through a pinned buffer when it is a device tensor of moderate size."""
+    if not tensor.is_cuda:
+        return tensor.cpu()
+    nbytes = tensor.numel() * tensor.element_size()
+    if nbytes == 0 or nbytes > PINNED_HOST_LIMIT or os.environ.get("KF_PINNED_SCORES", "1") == "0":
+        return tensor.cpu()
+    out = torch.empty(tensor.shape, dtype=tensor.dtype, pin_memory=True)
+    out.copy_(tensor)   # blocking: the result is complete on return, as with .cpu()
+    return out
+
+
 def release_memory() -> None:
     gc.collect()
     if torch.cuda.is_available():
