@@ -284,6 +284,12 @@ int kf_lambda_rows_accum(float* Lambda, int64_t ld_lambda, const void* GtT, cons
  * Needs groups == 1, no bias, O2 % 8 == 0, O1*O2 % 64 == 0, (C rounded up to 8) * k1 * k2 % 64 == 0, b >= 256;
  * kf_lambda_conv2d_workspace_bytes returns -1 otherwise (use kf_im2col + kf_gemm + kf_lambda_accum).
  */
+/* kf_lambda_conv2d_channels (ABI 13): the channel count Cp (C zero-padded) QaT_perm must be laid out with -- C rounded up to 8, or,
+ * for a layer with very few input channels whose (C rounded up to 8) * k1 * k2 is not a multiple of 64 (a first convolution: 3
+ * channels, 3 x 3 taps), the next multiple of 8 that makes it one (64), accepted while the padded per-sample-gradient GEMM stays
+ * under 2e11 flop per call; -1 when the dense form does not apply (as kf_lambda_conv2d_workspace_bytes). */
+int64_t kf_lambda_conv2d_channels(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2,
+                                  int d1, int d2);
 int64_t kf_lambda_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2,
                                          int p1, int p2, int d1, int d2);
 int kf_lambda_conv2d_accum(float* Lambda, int64_t ld_lambda, const void* Gt_nchw, const void* x, int64_t b, int64_t C, int64_t H,

@@ -66,6 +66,7 @@ SIGNATURES = {
     "kf_lambda_accum": (_i, [_p, _i64, _p, _p, _i64, _i, _i64, _i64, _i64, _i64, _f, _p]),
     "kf_rotate_rows_transposed_bf16": (_i, [_p, _p, _i64, _i64, _i64, _p, _i64, _i64, _p, _i64, _p]),
     "kf_lambda_rows_accum": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i64, _f, _p]),
+    "kf_lambda_conv2d_channels": (_i64, [_i64] * 5 + [_i] * 8),
     "kf_lambda_conv2d_workspace_bytes": (_i64, [_i64] * 5 + [_i] * 8),
     "kf_lambda_conv2d_accum": (_i, [_p, _i64, _p, _p] + [_i64] * 5 + [_i] * 8 + [_p, _i64, _i64, _f, _p, _i64, _p]),
     "kf_inv_lambda": (_i, [_p, _p, _i64, _d, _d, _p, _p]),

@@ -2121,7 +2121,10 @@ struct ConvPlan {
     int64_t copies_bytes, grid_bytes, psg_bytes;
     bool ok;
 };
-ConvPlan conv_plan(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2) {
+// cp_force != 0: that many (zero-padded) channels instead of C rounded up to 8, without the bound on the padding's extra work --
+// the dense Lambda form of a layer with very few input channels (lambda_conv_channels below)
+ConvPlan conv_plan(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2,
+                   int64_t cp_force = 0) {
     ConvPlan c{};
     c.O1 = (H + 2 * p1 - d1 * (k1 - 1) - 1) / s1 + 1;
     c.O2 = (W + 2 * p2 - d2 * (k2 - 1) - 1) / s2 + 1;
@@ -2130,14 +2133,14 @@ ConvPlan conv_plan(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1
     c.O2p = (c.O2 + 7) / 8 * 8;
     c.O1p = c.O1;
     while ((c.O1p * c.O2p) % 64 != 0) ++c.O1p;
-    c.Cp = (C + 7) / 8 * 8;
+    c.Cp = cp_force ? cp_force : (C + 7) / 8 * 8;
     c.Pp = c.O1p * c.O2p;
     c.Ipp = c.Cp * k1 * k2;
     c.D = O * c.Ipp;
     c.Hp = std::max<int64_t>(H + 2 * p1, s1 * (c.O1p - 1) + static_cast<int64_t>(d1) * (k1 - 1) + 1);
     c.Wq = conv_wq(c.O2p, k2, d2, s2);
     // padding the output grid and the channels may at most double the contraction work of the gradient kernel
-    c.ok = c.Pp <= 2 * c.O1 * c.O2 && c.Cp * c.Pp <= 3 * C * c.O1 * c.O2 && c.D % 64 == 0 && O >= 8;
+    c.ok = c.Pp <= 2 * c.O1 * c.O2 && (cp_force != 0 || c.Cp * c.Pp <= 3 * C * c.O1 * c.O2) && c.D % 64 == 0 && O >= 8;
     c.copies_bytes = align256(2 * s2 * b * c.Cp * c.Hp * c.Wq + 64);
     c.grid_bytes = (c.O1p != c.O1 || c.O2p != c.O2) ? align256(2 * b * O * c.Pp) : 0;
     c.psg_bytes = align256(2 * b * c.D);
@@ -2213,9 +2216,35 @@ int kf_pairwise_score_conv2d(float* scores, int64_t ld_scores, const void* P_til
     return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, c.D, scale, st);
 }
 
+namespace {
+// Channels (incl. zero padding) the dense Lambda form carries the patch axis with.  Normally C rounded up to 8; when that does not
+// give whole 64-deep k-steps of the Q_A product (ResNet-9's first layer: 8 * 9 = 72) the next multiple of 8 that does (64 * 9 = 576)
+// is taken -- zero channels cost contraction work only, and such a layer is tiny: accepted up to 2e11 flop of per-sample-gradient
+// GEMM per call (1 000 images of 32 x 32: 7.5e10).  Before round 6 that layer fell back to materialised fp32 patches + three fp32
+// GEMMs: 1.35 ms per batch for 3.9 GFLOP (tools/r06_layer_times.py).  0: the default plan applies.
+int64_t lambda_conv_cp_force(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2, int d1, int d2) {
+    const int64_t cp = (C + 7) / 8 * 8;
+    if ((cp * k1 * k2) % 64 == 0) return 0;
+    const ConvPlan base = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2, cp);
+    if (base.O1 <= 0 || base.O2 <= 0) return 0;
+    for (int64_t wide = cp + 8; wide <= 64; wide += 8)
+        if ((wide * k1 * k2) % 64 == 0)
+            return 2.0 * static_cast<double>(b) * O * wide * k1 * k2 * base.Pp <= 2e11 ? wide : 0;
+    return 0;
+}
+}  // namespace
+
+int64_t kf_lambda_conv2d_channels(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2, int p1, int p2,
+                                  int d1, int d2) {
+    if (kf_lambda_conv2d_workspace_bytes(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2) < 0) return -1;
+    const int64_t force = lambda_conv_cp_force(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    return force ? force : (C + 7) / 8 * 8;
+}
+
 int64_t kf_lambda_conv2d_workspace_bytes(int64_t b, int64_t C, int64_t H, int64_t W, int64_t O, int k1, int k2, int s1, int s2,
                                          int p1, int p2, int d1, int d2) {
-    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2,
+                                 lambda_conv_cp_force(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2));
     // the dense Lambda form contracts over the (padded) patch axis on the 64-deep LDS-DMA engine and folds rows (o, sample)
     // of a 256-row tile into at most two rows of Lambda: whole k-steps, real output grid, >= 256 samples
     if (!c.ok || c.grid_bytes != 0 || c.Ipp % 64 != 0 || b < 256 || O * b >= (1LL << 31) - 256) return -1;
@@ -2228,7 +2257,8 @@ int kf_lambda_conv2d_accum(float* Lambda, int64_t ld_lambda, const void* Gt_nchw
     if (!Lambda || !Gt_nchw || !x || !QaT_perm || b < 0 || C <= 0 || O <= 0 || n_out <= 0) return KF_ERR_INVALID_ARGUMENT;
     const int64_t need = kf_lambda_conv2d_workspace_bytes(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
     if (need < 0) return KF_ERR_INVALID_ARGUMENT;
-    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2);
+    const ConvPlan c = conv_plan(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2,
+                                 lambda_conv_cp_force(b, C, H, W, O, k1, k2, s1, s2, p1, p2, d1, d2));
     if (ldq < c.Ipp || ldq % 8 != 0 || n_out > ld_lambda ||
         ((reinterpret_cast<uintptr_t>(Gt_nchw) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(QaT_perm)) & 15) != 0)
         return KF_ERR_INVALID_ARGUMENT;

@@ -202,6 +202,7 @@ class LambdaTracker(BaseTracker):
     # Q_A whose epilogue squares and sums -- instead of rotating the [b R, I'] patch matrix: fewer flops (SURVEY.md 8d:
     # F_lambda is the cheaper of the two exact forms) and no patch tensor.  ``kf_lambda_conv2d_accum``.
     CONV_DENSE = True
+    CONV_DENSE_FLOP_RATIO = 1.3
     # Linear layers on sequences with whole 64-deep k-tiles (O, I, R multiples of 64: every transformer config): rotations
     # written K-contiguous per sample + ``kf_lambda_rows_accum`` (round 4).  False selects the round-2 kernel (A/B, tests).
     ROWS_ENGINE = True
@@ -226,7 +227,10 @@ class LambdaTracker(BaseTracker):
         taps = conv.kernel_size[0] * conv.kernel_size[1]
         ip = c * taps
         dense = 2.0 * r * o * ip + 2.0 * o * ip * ip + 2.0 * r * o * o   # gradient + Q_A GEMM + channel rotation
-        if dense >= 2.0 * r * (ip * ip + o * o + o * ip) or o % 8 != 0:
+        # the dense form runs on the implicit-im2col kernels (no patch tensor, ~0.8 PFLOP/s), the factored one materialises the
+        # patches and rotates them (~0.5): dense is taken up to ``CONV_DENSE_FLOP_RATIO`` x the factored flops (ResNet-9's
+        # (256, 1152) layer with R = O = 256: equal flops, 1.69 -> 1.0 ms per batch of 1 000; round 6, tools/r06_layer_times.py)
+        if dense >= self.CONV_DENSE_FLOP_RATIO * 2.0 * r * (ip * ip + o * o + o * ip) or o % 8 != 0:
             return False
         geometry = ops.lambda_conv2d_geometry(tuple(activation.shape), o, conv)
         if geometry is None:
@@ -236,9 +240,11 @@ class LambdaTracker(BaseTracker):
             storage[LAMBDA_MATRIX_NAME] = torch.zeros((o, ip), dtype=torch.float32, device=output_gradient.device)
             storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
         storage[NUM_LAMBDA_PROCESSED].add_(b)
-        if self._conv_dense_eigenvectors is None:
-            self._conv_dense_eigenvectors = (ops.conv_patch_order_eigenvectors(q_a, c, taps), q_g.to(torch.bfloat16).contiguous())
-        qa_t_perm, qg16 = self._conv_dense_eigenvectors
+        padded = ops.lambda_conv2d_channels(geometry)   # (may differ between batch sizes: a first layer's wide padding is budgeted by flops)
+        if self._conv_dense_eigenvectors is None or self._conv_dense_eigenvectors[0] != padded:
+            self._conv_dense_eigenvectors = (padded, ops.conv_patch_order_eigenvectors(q_a, c, taps, padded),
+                                             q_g.to(torch.bfloat16).contiguous())
+        _, qa_t_perm, qg16 = self._conv_dense_eigenvectors
         x = activation if activation.dtype == torch.bfloat16 else activation.to(torch.bfloat16)
         gt = ops.rotate_channels(output_gradient, qg16)
         ops.lambda_conv2d_accum(storage[LAMBDA_MATRIX_NAME], gt, x, geometry, qa_t_perm, scale=module.gradient_scale)

@@ -646,12 +646,18 @@ def lambda_conv2d_accum(lam: torch.Tensor, gt_nchw: torch.Tensor, x: torch.Tenso
         )
 
 
-def conv_patch_order_eigenvectors(q_a: torch.Tensor, channels: int, taps: int) -> torch.Tensor:
+def lambda_conv2d_channels(geometry) -> int:
+    """Padded channel count of the dense-form Lambda call for this geometry (kf_lambda_conv2d_channels): what
+    ``conv_patch_order_eigenvectors`` must lay ``Q_A^T`` out with."""
+    return int(nat.lib().kf_lambda_conv2d_channels(*geometry))
+
+
+def conv_patch_order_eigenvectors(q_a: torch.Tensor, channels: int, taps: int, padded_channels: Optional[int] = None) -> torch.Tensor:
     """``Q_A^T`` for the implicit-im2col kernels: bf16 ``[I' rounded up to 8, taps * Cp]`` whose row ``i'`` is column ``i'`` of
     ``q_a`` with its rows re-ordered from the reference's patch order ``(c, ky, kx)`` to the kernels' ``(ky, kx, c)``, ``c``
-    zero-padded to ``Cp`` = a multiple of 8."""
+    zero-padded to ``Cp`` = ``padded_channels`` (default: the next multiple of 8)."""
     ip = q_a.shape[0]
-    cp = channels + (-channels) % 8
+    cp = padded_channels if padded_channels else channels + (-channels) % 8
     q = q_a.reshape(channels, taps, ip).transpose(0, 1)              # [taps, C, I']
     q = torch.nn.functional.pad(q, (0, 0, 0, cp - channels))          # [taps, Cp, I']
     out = q.reshape(taps * cp, ip).t()                               # [I', taps * Cp]

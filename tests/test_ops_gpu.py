@@ -500,6 +500,10 @@ DENSE_LAMBDA_CONVS = [  # b >= 256 (rows (o, sample) of a 256-row tile span at m
     dict(b=333, cin=8, cout=40, k=(2, 4), stride=1, padding=0, dilation=1, hw=(9, 11)),  # I' = 64, O2 = 8, ragged O
     dict(b=260, cin=32, cout=8, k=(1, 2), stride=(1, 2), padding=0, dilation=1, hw=(8, 16)),  # strided columns: two phases
     dict(b=257, cin=20, cout=16, k=(2, 4), stride=1, padding=(1, 2), dilation=1, hw=(7, 15)),  # 20 channels -> 24: Ipp = 192
+    # round 6: very few input channels whose rounding to 8 does not give whole k-steps -- the channel axis is padded wider
+    dict(b=256, cin=3, cout=64, k=3, stride=1, padding=1, dilation=1, hw=(16, 16), wide=64),   # ResNet-9's first layer: 3 -> 64, I' = 27
+    dict(b=300, cin=1, cout=16, k=3, stride=1, padding=1, dilation=1, hw=(8, 8), wide=64),     # 1 channel -> 64
+    dict(b=256, cin=3, cout=8, k=(2, 3), stride=1, padding=0, dilation=1, hw=(9, 10), wide=32),  # 8 * 6 = 48 -> 32 * 6 = 192
 ]
 
 
@@ -520,7 +524,9 @@ def test_lambda_conv2d_dense_form(ops, c):
     q_g = torch.linalg.qr(_rand(o, o, seed=4).double())[0].float()
     geometry = ops.lambda_conv2d_geometry(tuple(x.shape), o, conv)
     assert geometry is not None
-    qa_t_perm = ops.conv_patch_order_eigenvectors(q_a.to(DEV), c["cin"], k1 * k2)
+    padded = ops.lambda_conv2d_channels(geometry)
+    assert padded == c.get("wide", c["cin"] + (-c["cin"]) % 8)
+    qa_t_perm = ops.conv_patch_order_eigenvectors(q_a.to(DEV), c["cin"], k1 * k2, padded)
     assert qa_t_perm.shape[1] % 64 == 0
     lam = torch.zeros(o, ip, device=DEV)
     for scale in (1.0, 0.5):  # "+=" and gradient_scale
