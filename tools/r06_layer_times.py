@@ -35,8 +35,14 @@ def main():
     r = bench.run_workload(workload, state, n_train, None, steps=1, warmup=1, factor_reps=1, cpu_baseline=False)
     print(f"{workload}: {r['value']:.4g} pairs/s, fit {r['factor_fit']['seconds']}; tracked layers (O, I') in forward order: {layers}")
     for tag, calls in SEEN.items():
-        if len(calls) % period:
-            print(f"== {tag}: {len(calls)} calls (not a multiple of {period} layers): mean {sum(c[0] for c in calls) / len(calls):.3f} ms")
+        if len(calls) % period:   # (activation + gradient calls interleave: grouped by their algorithmic flop count instead)
+            print(f"== {tag}: {len(calls)} calls, mean {sum(c[0] for c in calls) / len(calls):.3f} ms; by algorithmic flops / bytes:")
+            groups = {}
+            for ms, fl, nb in calls:
+                groups.setdefault((fl, nb), []).append(ms)
+            for (fl, nb), mss in sorted(groups.items()):
+                ms = sum(mss) / len(mss)
+                print(f"   {len(mss):4d} calls {ms:8.3f} ms  {fl / ms / 1e9 if ms else 0:8.1f} TFLOP/s on {fl:.3g} flop, {nb / 1e6:8.1f} MB in")
             continue
         print(f"== {tag}: {len(calls)} calls = {len(calls) // period} batches x {period} layers (order of the hooks)")
         for pos in range(period):
