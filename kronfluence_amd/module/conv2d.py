@@ -80,6 +80,17 @@ class TrackedConv2d(TrackedModule, module_type=nn.Conv2d):
                 return cov, count
             if fresh:
                 cov = count = None
+        d_rows = (input_activation.shape[1] * self.kernel_size[0] * self.kernel_size[1] + int(self.has_bias)
+                  if (input_activation.dim() == 4 and conv.groups == 1) else 0)
+        if d_rows >= 256 and d_rows % 8 == 0:   # an output grid that is not whole k-steps: patch rows on the K-major covariance kernel
+            fresh = cov is None
+            if fresh:
+                cov = torch.zeros((d_rows, d_rows), dtype=torch.float32, device=input_activation.device)
+                count = torch.zeros(1, dtype=torch.int64, device=input_activation.device)
+            if ops.conv_patch_rows_cov(cov, count, input_activation, conv):
+                return cov, count
+            if fresh:
+                cov = count = None
         patches = self._patches(input_activation)
         d = patches.shape[-1]
         if cov is None:

@@ -212,8 +212,10 @@ def conv_geometry(conv: nn.Conv2d) -> Tuple[int, int, int, int, int, int, int, i
     return k1, k2, s1, s2, p1, p2, d1, d2
 
 
-def im2col(x: torch.Tensor, conv: nn.Conv2d, append_ones: bool, out_dtype: torch.dtype = torch.float32) -> torch.Tensor:
-    """Patches ``[b, P, I']`` of module/conv2d.py:15-64 (+ ones column), via kf_im2col."""
+def im2col(x: torch.Tensor, conv: nn.Conv2d, append_ones: bool, out_dtype: torch.dtype = torch.float32,
+           row_multiple: int = 1) -> torch.Tensor:
+    """Patches ``[b, P, I']`` of module/conv2d.py:15-64 (+ ones column), via kf_im2col.  ``row_multiple > 1``: the patch rows as
+    ONE matrix ``[b P rounded up, I']`` whose trailing rows are zero (whole k-tiles for the K-major covariance kernel)."""
     nat.require_device(x, "x")
     x = _contig(x)
     b, c, h, w = x.shape
@@ -221,13 +223,37 @@ def im2col(x: torch.Tensor, conv: nn.Conv2d, append_ones: bool, out_dtype: torch
     o1 = (h + 2 * p1 - d1 * (k1 - 1) - 1) // s1 + 1
     o2 = (w + 2 * p2 - d2 * (k2 - 1) - 1) // s2 + 1
     ip = (c // conv.groups) * k1 * k2 + int(append_ones)
-    out = torch.empty((b, o1 * o2, ip), dtype=out_dtype, device=x.device)
+    n = b * o1 * o2
+    if row_multiple > 1:
+        out = torch.empty((-(-n // row_multiple) * row_multiple, ip), dtype=out_dtype, device=x.device)
+        out[n:].zero_()
+    else:
+        out = torch.empty((b, o1 * o2, ip), dtype=out_dtype, device=x.device)
     nat.check(
         nat.lib().kf_im2col(out.data_ptr(), nat.dtype_code(out_dtype), x.data_ptr(), nat.dtype_code(x.dtype), b, c, h, w,
                             k1, k2, s1, s2, p1, p2, d1, d2, conv.groups, int(append_ones), nat.stream_ptr(x.device)),
         "kf_im2col",
     )
     return out
+
+
+def conv_patch_rows_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor, conv: nn.Conv2d) -> bool:
+    """A bf16 conv layer the implicit-im2col covariance does not take (an output grid that is not whole k-steps: ResNet-9's
+    unpadded 3 x 3 layer with its 6 x 6 grid) on the K-MAJOR covariance kernel: the materialised patch rows ``[b P, I']`` ARE a
+    K-major operand (kf_syrk_rows_bf16 on one "sample" of ``b P`` rows, zero rows up to a whole k-tile) -- 0.79 -> 0.36 ms per
+    ResNet-9 batch against the generic kf_syrk_accum engine (round 6).  ``False``: not eligible (the caller falls back)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() == 4 and conv.groups == 1):
+        return False
+    ip = x.shape[1] * conv.kernel_size[0] * conv.kernel_size[1] + int(conv.bias is not None)
+    if ip % 8 != 0 or ip < 256 or ip >= COV_STAGED_MAX_DIM:
+        return False
+    rows = im2col(x, conv, conv.bias is not None, torch.bfloat16, row_multiple=64)
+    k1, k2, s1, s2, p1, p2, d1, d2 = conv_geometry(conv)
+    n = x.shape[0] * ((x.shape[2] + 2 * p1 - d1 * (k1 - 1) - 1) // s1 + 1) * ((x.shape[3] + 2 * p2 - d2 * (k2 - 1) - 1) // s2 + 1)
+    if n <= 0 or not _syrk_rows_bf16(cov, rows.unsqueeze(0), None, False, 1.0):
+        return False
+    count.add_(n)
+    return True
 
 
 def conv2d_cov_geometry(x: torch.Tensor, conv: nn.Conv2d):
@@ -293,7 +319,7 @@ def conv_activation_cov(cov: torch.Tensor, count: torch.Tensor, x: torch.Tensor,
     if geometry is not None:
         conv2d_cov_accum(cov, count, x, conv, geometry)
         return
-    if conv2d_cov_small(cov, count, x, conv):
+    if conv2d_cov_small(cov, count, x, conv) or conv_patch_rows_cov(cov, count, x, conv):
         return
     patches = im2col(x, conv, conv.bias is not None, x.dtype if x.dtype != torch.float64 else torch.float32)
     n, d = patches.shape[0] * patches.shape[1], patches.shape[2]

@@ -237,6 +237,33 @@ def test_linear_activation_cov_weighted_integer_mask(ops):
 
 
 @pytest.mark.parametrize("c", [
+    dict(b=7, cin=32, k=3, padding=0, hw=(8, 8), bias=False),     # ResNet-9's unpadded layer in small: a 6 x 6 grid, 252 rows -> 256
+    dict(b=3, cin=64, k=3, padding=0, hw=(7, 9), bias=False),     # 5 x 7 grid, 105 rows -> 128
+    dict(b=2, cin=47, k=(3, 2), padding=0, hw=(6, 6), bias=True), # I' = 282 + 1 is odd: not eligible, the generic engine takes it
+])
+def test_conv_activation_cov_patch_rows_on_the_k_major_kernel(ops, c):
+    """ops.conv_patch_rows_cov: a bf16 conv layer whose output grid is not whole k-steps (the implicit-im2col covariance declines it)
+    accumulates its materialised patch rows as ONE K-major operand, zero rows up to a whole k-tile (kf_syrk_rows_bf16) -- against
+    conv2d.py:106-128 + factor.py:58 in fp64; the count is the number of REAL rows."""
+    conv = nn.Conv2d(c["cin"], 8, c["k"], padding=c["padding"], bias=c["bias"])
+    x = _rand(c["b"], c["cin"], *c["hw"], dtype=torch.bfloat16)
+    flat, count = ref.conv_flat_activation(x.double(), conv)
+    d = flat.shape[1]
+    want = torch.zeros(d, d, dtype=torch.float64)
+    ref.covariance_update(want, flat)
+    assert ops.conv2d_cov_geometry(x.to(DEV), conv) is None
+    cov = torch.zeros(d, d, device=DEV)
+    cnt = torch.zeros(1, dtype=torch.int64, device=DEV)
+    taken = ops.conv_patch_rows_cov(cov, cnt, x.to(DEV), conv)
+    assert taken == (d % 8 == 0 and d >= 256)
+    if taken:
+        assert rel(cov, want) <= TOL and int(cnt) == count
+    ops.conv_activation_cov(cov, cnt, x.to(DEV), conv)   # the public entry takes the same route (or the generic engine)
+    assert rel(cov, (2 if taken else 1) * want) <= TOL, rel(cov, want)
+    assert int(cnt) == (2 if taken else 1) * count and rel(cov, cov.t()) <= 1e-6
+
+
+@pytest.mark.parametrize("c", [
     dict(b=5, cin=16, k=3, stride=1, padding=1, dilation=1, hw=(16, 16)),
     dict(b=3, cin=8, k=5, stride=2, padding=2, dilation=1, hw=(16, 16)),
     dict(b=4, cin=128, k=3, stride=1, padding=1, dilation=1, hw=(8, 8)),

@@ -3,6 +3,8 @@
 #   rot       A/B of the blocked rotation's XCD grids (tools/r06_rot.py), twice, + FETCH_SIZE of the linear order against the grid
 #   dist      the query-exchange modes end to end: 2 and 8 ranks over gloo on the one GPU (KF_QUERY_EXCHANGE=gather | replicate),
 #             scores of both modes compared; the one-rank RCCL test
+#   llama32   configs[4] at FULL DEPTH on the one GPU: 32 Llama-3-8B decoder blocks (224 tracked projections, D = 6.98 G), rank-64
+#             queries, 256 train x 16 query sequences of 512 tokens, one cold factor fit (96 eigenproblems of 14 336^2)
 #   final     the record on the final sources: full GPU suite + smoke, kernel traces, counter passes, the driver-shaped bench line
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -96,6 +98,40 @@ final)
     tail -n 1 gpurun_out/r06_bench_default.out | wc -c
     cp bench_extras.json gpurun_out/r06_bench_default_extras.json
     python tools/bench_digest.py bench_extras.json || tail -c 3000 gpurun_out/r06_bench_default.err
+    ;;
+llama32)
+    # (first attempt, factor batches of 8 sequences: covariance + 352 eigenproblems went through, the Lambda stage ran out of the 288 GiB --
+    #  fp32 eigenvectors 99 GB + their bf16 copies 49 GB + Lambda 28 GB + weights 29 GB + the autograd graph of 8 x 512 tokens through 32
+    #  blocks; hence factor batches of 2, train batches of 4 and expandable allocator segments)
+    ( KF_BENCH_BUSY=0 PYTORCH_ALLOC_CONF=expandable_segments:True PYTORCH_HIP_ALLOC_CONF=expandable_segments:True timeout 2700 \
+        python bench.py --workload llama_block --blocks 32 --n-train 256 --n-query 16 --n-fit 64 --warm-n-train 16 \
+        --factor-batch 2 --train-batch 4 --steps 1 --warmup 1 --no-cpu-baseline --factor-reps 0 --phase-split ) > gpurun_out/r06_bench_llama_32blocks.json 2> gpurun_out/r06_bench_llama_32blocks.log
+    echo "rc $?"
+    cp bench_extras.json gpurun_out/r06_bench_llama_32blocks_extras.json
+    python tools/bench_digest.py bench_extras.json || tail -c 3000 gpurun_out/r06_bench_llama_32blocks.log
+    ;;
+psgdirect)
+    ( timeout 300 python tools/r06_psg_direct.py ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee gpurun_out/r06_psg_direct.log
+    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r06_psgd_trace" -- python "$R/tools/r06_psg_direct.py" ) > gpurun_out/r06_psgd_trace.log 2>&1
+    find gpurun_out/r06_psgd_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r06_psg_direct_kernel_stats.csv \;
+    rm -rf gpurun_out/r06_psgd_trace
+    grep "psg_gemm_v3\|score_gemm_v3\|conv_pad" gpurun_out/r06_psg_direct_kernel_stats.csv | cut -c1-160
+    ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/r06_psgd_pmc" -- python "$R/tools/r06_psg_direct.py" ) > gpurun_out/r06_psgd_pmc.log 2>&1
+    python - <<'PY' | tee -a gpurun_out/r06_psg_direct.log
+import csv, glob
+rows = []
+for path in glob.glob("gpurun_out/r06_psgd_pmc/**/*counter_collection.csv", recursive=True):
+    rows += list(csv.DictReader(open(path)))
+by = {}
+for r in rows:
+    if "psg_gemm_v3" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE":
+        by.setdefault(r["Kernel_Name"].split("(")[0][-40:], []).append(float(r["Counter_Value"]))
+for k, v in sorted(by.items()):
+    print(f"{k}: {len(v)} launches, WRITE_SIZE sum {sum(v):.4g} (raw counter units), mean {sum(v)/len(v):.4g}")
+PY
+    rm -rf gpurun_out/r06_psgd_pmc
+    ( timeout 600 python tools/r06_layer_times.py resnet9 8000 ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tail -60 > gpurun_out/r06_layer_times_resnet9.log
+    tail -45 gpurun_out/r06_layer_times_resnet9.log
     ;;
 suite)
     ( timeout 2700 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r06_pytest_gpu.log 2>&1
