@@ -213,185 +213,5 @@ __device__ __forceinline__ float mainloop(f32x16 (&acc)[4][2], unsigned char* sm
     return cs;
 }
 
-// ------------------------------------------------------------------------------------------------
-// Round 6: the same loop over a STREAM of work items (per-sample-gradient tiles: one item = one sample's 256 x 256 tile = KT
-// k-tiles) without a break in the DMA pipeline, the finished tile leaving STRAIGHT FROM THE ACCUMULATORS.
-//
-// Why: with one workgroup per item (psg_gemm_tn_kernel) an item at T = 128 is two k-tiles between a cold DMA round trip and a
-// 128 KB epilogue that transposes the tile through the very LDS the loop stages in -- load, MFMA, transpose and store run one
-// after the other on a CU, ~12 us for 1.7 us of MFMAs (BERT: 2.6 TB/s of result stream).  The persistent form of round 5 kept
-// the LDS epilogue (four rounds of 32 KB through the spare LDS, two barriers each, half-line stores) and was slower.  Here the
-// epilogue needs NO LDS and NO barrier: the operands are swapped (tile rows = i, the contiguous direction of the result), so a
-// lane holds four consecutive bf16 of a result row per accumulator quad; v_permlane32_swap trades quads between lanes l and l + 32
-// so that a lane owns a whole octet (16 bytes: 8-byte stores were measured 40 % slower on the 128 x 128 kernel,
-// profiles/r06_psg_direct_stores.log).  A wave flushes item j while
-// it sits in the L segments of item j + 1's first k-tile (the other wave of its SIMD is in its M segment): blocks 0, 1 in
-// L(2t), blocks 2, 3 in L(2t + 1), each right before the M segment that restarts those (cleared) accumulators.
-//
-// The stores are VMEM operations and share vmcnt with the LDS-DMA requests (gfx9: one in-order counter for loads and stores), so
-// the counted waits of the tiles around a flush allow for them.  With S = 8 stores per half and the schedule of kf_pingpong.h
-// (ISSUE = 1: M(2t) issues A1(t+1) [2 requests], M(2t+1) issues A0, B0, B1 of t+2 [6]):
-//     end of L(2t)    needs A1(t):              younger = A0 B0 B1(t+1) [6] + the stores of L(2t-1), L(2t)
-//     end of L(2t+1)  needs A0, B0, B1(t+1):    younger = A1(t+1) [2]        + the stores of L(2t), L(2t+1)
-//   flush tile t (first k-tile of an item, not the first item):   vmcnt(6 + S), vmcnt(2 + 2 S)
-//   the tile after it:                                            vmcnt(6 + S), vmcnt(2)
-//   every other tile:                                             vmcnt(6),      vmcnt(2)
-// (the optional extra store of L(2t+1) -- the column sums -- is NOT counted: a wait that allows one request less than are in
-// flight only waits for one more of the OLDEST, a store issued a whole M segment earlier).  KT >= 2, so a flush tile is never
-// the tile after a flush tile.  The last tile of the stream waits vmcnt(0) in L(2t).
-// ------------------------------------------------------------------------------------------------
-// item(j): descriptor of the workgroup's j-th item (wave-uniform; called once per item), any struct with the members
-//     int64_t oa, ob   element offsets of the item's k-tile 0 behind Sources::p
-//     bool colsum      sum the B operand over k for this item (see mainloop)
-// store(descriptor, half, acc, cs): the wave writes blocks i = 2 half, 2 half + 1 of that item's tile from `acc` with EXACTLY 8
-// vector stores (half 1: plus at most one for the column sums `cs`).  nitems >= 1, KT >= 2.
-template <int IMG, class ItemFn, class StoreFn>
-__device__ __forceinline__ void mainloop_stream(unsigned char* sm, const Sources& src, int nitems, int KT, int wave, int lane,
-                                                int64_t step_a, int64_t step_b, ItemFn item, StoreFn store) {
-    constexpr int S = 8;    // vector stores per flushed half and wave
-    const int wm = wave >> 2, wn = wave & 3;
-    auto issue_at = [&](int piece, int t, int64_t off) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-            glds16(src.p[2 * piece + h] + off,
-                   sm + (t & 1) * STAGE_BYTES + piece * PIECE_BYTES + tnmap::request_of(wave, h) * tnmap::REQUEST_BYTES);
-    };
-    const uint32_t sm_lds = lds_address(sm);
-    uint32_t wa[4], wb[2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) wa[i] = sm_lds + tnmap::a_piece(i) * PIECE_BYTES + tnmap::word<IMG>(tnmap::a_row(wm, i), 0, 0, lane);
-#pragma unroll
-    for (int jn = 0; jn < 2; ++jn) wb[jn] = sm_lds + tnmap::b_piece(wn) * PIECE_BYTES + tnmap::word<IMG>(tnmap::b_row(wn, jn), 0, 0, lane);
-
-    bf16x8 a[2][4], b[2][4];
-    auto read_a = [&](int half, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t base = wa[2 * half + i] + buf * STAGE_BYTES;
-            a[i][0] = fragment<IMG, 0>(base); a[i][1] = fragment<IMG, 1>(base); a[i][2] = fragment<IMG, 2>(base); a[i][3] = fragment<IMG, 3>(base);
-        }
-    };
-    auto read_b = [&](int buf) {
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const uint32_t base = wb[jn] + buf * STAGE_BYTES;
-            b[jn][0] = fragment<IMG, 0>(base); b[jn][1] = fragment<IMG, 1>(base); b[jn][2] = fragment<IMG, 2>(base); b[jn][3] = fragment<IMG, 3>(base);
-        }
-    };
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][jn][r] = 0.0f;
-    float cs = 0.0f;
-
-#define KF_TNS_GROUP(HALF, KK)                                                                                         \
-    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                                      \
-        _Pragma("unroll") for (int jn = 0; jn < 2; ++jn)                                                               \
-            acc[(HALF) * 2 + i][jn] =                                                                                  \
-                __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][KK], b[jn][KK], acc[(HALF) * 2 + i][jn], 0, 0, 0)
-    auto ride = [&](bool on, int piece, int t, int64_t off) {
-        if (on) {
-            __builtin_amdgcn_sched_barrier(0);
-            issue_at(piece, t, off);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    // One body for every k-tile; wave-uniform flags: flush = first k-tile of an item after the first (stores item jt - 1 and clears
-    // the accumulators half by half), after = the k-tile behind a flush tile; more1 / more2: k-tile t + 1 / t + 2 exists.  (Three
-    // specialised copies of the body -- the restarted halves on an inline-zero C operand -- made the register allocator spill
-    // the accumulators: scratch loads in the loop, each behind a vmcnt(0).)
-    auto clear_half = [&](int half) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[half * 2 + i][jn][r] = 0.0f;
-    };
-#define KF_TNS_TILE()                                                                                                  \
-    do {                                                                                                               \
-        const int buf_ = t & 1;                                                                                        \
-        if (flush) { store(d_prev, 0, acc, 0.0f); clear_half(0); __builtin_amdgcn_sched_barrier(0); }                  \
-        read_a(0, buf_);                                                                                               \
-        read_b(buf_);                                                                                                  \
-        if (!more1) wait_vmcnt<0>();                                                                                   \
-        else if (flush || after) wait_vmcnt<6 + S>();   /* A1(t) landed; in flight: A0, B0, B1 of t+1 and the stores of L(2t) / L(2t-1) */ \
-        else wait_vmcnt<6>();                                                                                          \
-        wait_lds_reads();                                                                                              \
-        barrier();                                                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
-        KF_TNS_GROUP(0, 0);                                                                                            \
-        ride(more1, 1, t + 1, oa1);                                                                                    \
-        KF_TNS_GROUP(0, 1);                                                                                            \
-        KF_TNS_GROUP(0, 2);                                                                                            \
-        KF_TNS_GROUP(0, 3);                                                                                            \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
-        barrier();                                                                                                     \
-        if (flush) { store(d_prev, 1, acc, cs); cs = 0.0f; clear_half(1); __builtin_amdgcn_sched_barrier(0); }         \
-        read_a(1, buf_);                                                                                               \
-        if (more1) {                                    /* A0, B0, B1 of t+1 landed; in flight: A1(t+1) */             \
-            if (flush) wait_vmcnt<2 + 2 * S>();         /* ... and both halves' stores */                              \
-            else wait_vmcnt<2>();                                                                                      \
-        }                                                                                                              \
-        wait_lds_reads();                                                                                              \
-        barrier();                                                                                                     \
-        __builtin_amdgcn_s_setprio(1);                                                                                 \
-        KF_TNS_GROUP(1, 0);                                                                                            \
-        ride(more2, 0, t + 2, oa2);                                                                                    \
-        KF_TNS_GROUP(1, 1);                                                                                            \
-        ride(more2, 2, t + 2, ob2);                                                                                    \
-        KF_TNS_GROUP(1, 2);                                                                                            \
-        ride(more2, 3, t + 2, ob2);                                                                                    \
-        KF_TNS_GROUP(1, 3);                                                                                            \
-        if (colsum) {   /* the B fragments of this k-tile are still in registers */                                    \
-            if (wm == 0) { cs = sum8(b[0][0], cs); cs = sum8(b[0][1], cs); cs = sum8(b[0][2], cs); cs = sum8(b[0][3], cs); } \
-            else { cs = sum8(b[1][0], cs); cs = sum8(b[1][1], cs); cs = sum8(b[1][2], cs); cs = sum8(b[1][3], cs); }   \
-        }                                                                                                              \
-        __builtin_amdgcn_s_setprio(0);                                                                                 \
-        barrier();                                                                                                     \
-    } while (0)
-
-    const int nt = nitems * KT;
-    // prologue: k-tile 0 complete, A0 / B0 / B1 of k-tile 1 (the same item: KT >= 2) on their way
-    auto d_cur = item(0);            // descriptor of the item k-tile t belongs to (decoded ONCE per item, by the cursor below)
-    auto d_prev = d_cur, d_next = d_cur;
-    issue_at(0, 0, d_cur.oa); issue_at(2, 0, d_cur.ob); issue_at(3, 0, d_cur.ob); issue_at(1, 0, d_cur.oa);
-    issue_at(0, 1, d_cur.oa + step_a); issue_at(2, 1, d_cur.ob + step_b); issue_at(3, 1, d_cur.ob + step_b);
-    wait_vmcnt<8>();   // in flight: A1(0), A0 B0 B1(1)
-    barrier();
-    if (wm == 1) barrier();   // Y runs half a phase behind X from here on (wave-uniform branch)
-
-    int64_t oa1 = d_cur.oa + step_a;  // k-tile t + 1
-    int jc = 0, kc = 2;               // cursor: item and k index of k-tile t + 2
-    if (kc == KT) {
-        jc = 1; kc = 0;
-        if (nitems > 1) d_next = item(1);
-    }
-    int jt = 0, kt = 0;               // item and k index of k-tile t
-    for (int t = 0; t < nt; ++t) {
-        const bool more1 = t + 1 < nt, more2 = t + 2 < nt;
-        const bool flush = kt == 0 && jt > 0, after = kt == 1 && jt > 0;
-        const bool colsum = d_cur.colsum;
-        const int64_t oa2 = (jc == jt ? d_cur.oa : d_next.oa) + kc * step_a, ob2 = (jc == jt ? d_cur.ob : d_next.ob) + kc * step_b;
-        KF_TNS_TILE();
-        oa1 = oa2;
-        // KT >= 2: the cursor already stands in item jt + 1 when k-tile t leaves item jt, and enters item jt + 2 no earlier than that
-        if (++kt == KT) { kt = 0; ++jt; d_prev = d_cur; d_cur = d_next; }
-        if (++kc == KT) {
-            kc = 0; ++jc;
-            if (jc < nitems) d_next = item(jc);
-        }
-    }
-    if (wm == 0) barrier();   // X waits for Y's last segment: barrier counts match, all LDS reads are done
-    store(d_prev, 0, acc, 0.0f);   // (d_prev: the last item -- jt has stepped past it)
-    store(d_prev, 1, acc, cs);
-#undef KF_TNS_TILE
-#undef KF_TNS_GROUP
-}
-
 }  // namespace pptn
 }  // namespace kf

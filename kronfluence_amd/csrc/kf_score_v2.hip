@@ -926,12 +926,11 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 // over the copy-out stores, so that the next item's first k-step stays in flight through the epilogue (no change).  The
 // kernel is bound by memory-system throughput -- its 32 KB result tile per 16-64 MFMAs and the gather-like implicit-im2col
 // requests -- not by the latency of the item boundary.)
-// DIRECT (OUT == 0 only, round 6, A/B): the bf16 tile leaves STRAIGHT FROM THE ACCUMULATORS -- a lane owns four consecutive values of a
-// result row, trades halves with its partner lane (v_permlane32_swap) and stores 16 bytes -- instead of being transposed through
-// LDS: no staging pass, and the two barriers of an item's epilogue are gone.
-template <int OUT, bool DIRECT = false>   // 0: k-tile-major (score GEMM operand), 1: rows ordered (m, sample), 2: plain per sample, times `mul`
+// (Round 6: the tile stored straight from the accumulators instead -- 8-byte quads, or 16-byte octets after a v_permlane32_swap --
+// was measured 41 % / 14 % slower: a store instruction then touches 32 result rows x 16-32 bytes instead of 8 rows x 128,
+// profiles/r06_psg_register_stores_negative.log.)
+template <int OUT>   // 0: k-tile-major (score GEMM operand), 1: rows ordered (m, sample), 2: plain per sample, times `mul`
 __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
-    static_assert(!DIRECT || OUT == 0, "direct stores write the k-tile-major layout");
     constexpr bool ROWS = OUT == 1, PLAIN = OUT == 2;
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 1, wn = wave & 1;
@@ -1024,36 +1023,6 @@ __global__ __launch_bounds__(NTHREADS) void psg_gemm_v3_kernel(PsgV2Args a) {
             __builtin_amdgcn_s_waitcnt(0);
             __syncthreads();
             buf ^= 1;
-        }
-        if constexpr (DIRECT) {
-            // acc[ti][tj][4 q + e] = element (i = n0 + wn 64 + ti 32 + 8 q + 4 hi + e, m = m0 + wm 64 + tj 32 + lr): a lane holds half an
-            // octet of i; v_permlane32_swap trades halves between lanes l and l + 32 so that lane (hi = 0) owns the whole octet q and
-            // lane (hi = 1) the whole octet q + 1 -- 16-byte stores, a full 32-byte sector per result row and instruction
-#pragma unroll
-            for (int tj = 0; tj < 2; ++tj) {
-                const int m = cur.m0 + wm * 64 + tj * 32 + lr;
-                const int64_t drow = static_cast<int64_t>(m) * a.N;
-#pragma unroll
-                for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-                    for (int q = 0; q < 4; q += 2) {
-                        const uint32_t a0 = pack_bf16x2(acc[ti][tj][4 * q], acc[ti][tj][4 * q + 1]);
-                        const uint32_t a1 = pack_bf16x2(acc[ti][tj][4 * q + 2], acc[ti][tj][4 * q + 3]);
-                        const uint32_t b0 = pack_bf16x2(acc[ti][tj][4 * q + 4], acc[ti][tj][4 * q + 5]);
-                        const uint32_t b1 = pack_bf16x2(acc[ti][tj][4 * q + 6], acc[ti][tj][4 * q + 7]);
-                        const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                        const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                        const int n = cur.n0 + wn * 64 + ti * 32 + (q + hi) * 8;
-                        if (m < a.M && n < a.N) {   // N % 8 == 0: an octet is entirely in or out
-                            const int64_t d = drow + n;
-                            uint16_t* dst = a.out + (d >> 6) * a.out_tile_stride + static_cast<int64_t>(cur.z) * 64 + (d & 63);
-                            *reinterpret_cast<u32x4*>(dst) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                        }
-                    }
-            }
-            cur = nxt;
-            have = have_next;
-            continue;
         }
         // `buf` now holds the next item's first k-step (landed); `buf ^ 1` was consumed last and stages the bf16 tile:
         // row m (256 B), 16-byte chunk c of it at chunk position c ^ (m & 15)
@@ -1187,7 +1156,9 @@ __global__ __launch_bounds__(pp::THREADS) void psg_gemm_pp_kernel(PsgPpArgs a) {
 // of A', i.e. sum_t G[n][t][o]) is summed from the G fragments the waves of the tiles tn == 0 hold anyway (v_dot2c_f32_bf16 beside
 // the MFMAs) -- no second pass over G -- and written with the 7 zeros that pad the axis to Ip = I + 8.  Work items, operand roles
 // (tile rows = i, tile columns = o) and the epilogue are those of psg_gemm_pp_kernel.  (A persistent, item-pipelined form was
-// measured and removed: profiles/r05_psg_persistent_negative.log.)
+// measured and removed: profiles/r05_psg_persistent_negative.log; so was, in round 6, a stream of items per persistent workgroup
+// with the tile stored straight from the accumulators -- no LDS pass, no barrier, correct, slower: the stores share the in-order
+// vmcnt queue with the LDS-DMA requests, profiles/r06_psg_register_stores_negative.log.)
 // ------------------------------------------------------------------------------------------------
 struct PsgTnArgs {
     uint16_t* out; int64_t out_tile_stride;
@@ -1262,103 +1233,6 @@ __global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_kernel(PsgTnArgs a)
                 u32x4{pack_bf16x2(total, 0.0f), 0u, 0u, 0u};
         }
     }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Round 6: the K-major per-sample gradients as a STREAM of items per workgroup (pptn::mainloop_stream): 256 persistent
-// workgroups, each walking a strided list of its XCD's (sample, tile) items without a break in the DMA pipeline; a finished
-// tile leaves straight from the accumulators -- v_permlane32_swap completes a lane's octet of the result row, 16-byte stores
-// into the k-tile-major buffer, no LDS pass, no barrier.  Same arguments, work decomposition and result layout as
-// psg_gemm_tn_kernel.  KT >= 2.
-// ------------------------------------------------------------------------------------------------
-struct PsgTnStreamArgs {
-    PsgTnArgs g;
-    int64_t dA, dG;   // element offsets of segment 1's operands behind segment 0's (A[1] - A[0], G[1] - G[0])
-    int debug;        // measurements only: 1 = no stores at all, 2 = every store into the first 2 MB of the buffer (L2 resident)
-};
-
-template <int IMG>
-__global__ __launch_bounds__(pptn::THREADS) void psg_gemm_tn_stream_kernel(PsgTnStreamArgs sa) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
-    const PsgTnArgs& a = sa.g;
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wm = wave >> 2, wn = wave & 3;
-    const int tiles = a.tiles_m * a.tiles_n;
-    const int64_t items = static_cast<int64_t>(a.batch) * tiles, per_xcd = (items + 7) / 8;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
-    // this workgroup's items: first, first + slots, ... inside its XCD's contiguous range (the workgroups of an XCD work on
-    // neighbouring items -- a sample's tiles -- at the same time: its two operands stay in that L2)
-    const int64_t first = static_cast<int64_t>(xcd) * per_xcd + slot, end = min(items, static_cast<int64_t>(xcd + 1) * per_xcd);
-    if (first >= end) return;
-    const int nitems = static_cast<int>((end - first + slots - 1) / slots);
-    const int64_t T = static_cast<int64_t>(a.KT) * 64;
-
-    struct Item { int64_t oa, ob; bool colsum; int z, m0, i0; };   // (wave-uniform; items < 2^31: 32-bit divisions)
-    const unsigned first32 = static_cast<unsigned>(first), utiles = static_cast<unsigned>(tiles), utm = static_cast<unsigned>(a.tiles_m);
-    auto item_of = [&](int j) __attribute__((always_inline)) {
-        const unsigned item = __builtin_amdgcn_readfirstlane(first32 + static_cast<unsigned>(j) * static_cast<unsigned>(slots));
-        Item w;
-        w.z = static_cast<int>(item / utiles);
-        const unsigned tile = item - static_cast<unsigned>(w.z) * utiles;
-        const unsigned tn = tile / utm, tm = tile - tn * utm;
-        w.i0 = static_cast<int>(tn) * 256; w.m0 = static_cast<int>(tm) * 256;
-        w.colsum = a.ones && tn == 0;
-        const int seg = w.z >= a.b0, zs = w.z - (seg ? a.b0 : 0);
-        w.oa = (seg ? sa.dA : 0) + zs * T * a.I + w.i0;
-        w.ob = (seg ? sa.dG : 0) + zs * T * a.O + w.m0;
-        return w;
-    };
-
-    pptn::Sources src;
-    pptn::make_sources<IMG>(src, wave, lane, [&](int f) { return a.A[0] + f; }, static_cast<int64_t>(a.I),
-                            [&](int f) { return a.G[0] + f; }, static_cast<int64_t>(a.O));
-
-    // Result addressing.  acc[i][jn][4 q + e] = (tile row n = wm 128 + i 32 + 8 q + 4 hi + e, tile column m = wn 64 + jn 32 + lr); after
-    // the swap lane (hi) owns the octet q + hi (q = 0, 2).  d = m Ip + n with Ip = I (+ 8 with the bias column), I % 256 == 0:
-    //     d >> 6 = m (I >> 6) [+ m >> 3] + n >> 6 + (r + n & 63) >> 6,   d & 63 = (r + n & 63) & 63,   r = (8 m) & 63 = 8 (lane & 7) [or 0]
-    const int lr = lane & 31, hi = lane >> 5;
-    const int r8 = a.ones ? (lane & 7) * 8 : 0;
-    const int64_t ts = a.out_tile_stride;
-    auto store = [&](const Item& w, int half, f32x16 (&acc)[4][2], float cs) __attribute__((always_inline)) {
-#pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int m = w.m0 + wn * 64 + jn * 32 + lr;
-            const int row64 = m * (a.I >> 6) + (a.ones ? m >> 3 : 0) + (w.i0 >> 6) + wm * 2;
-            uint16_t* base = a.out + static_cast<int64_t>(row64) * ts + static_cast<int64_t>(w.z) * 64;
-#pragma unroll
-            for (int ii = 0; ii < 2; ++ii) {
-                const int i = 2 * half + ii;
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq) {
-                    const int q = 2 * qq;
-                    const uint32_t a0 = pack_bf16x2(acc[i][jn][4 * q], acc[i][jn][4 * q + 1]);
-                    const uint32_t a1 = pack_bf16x2(acc[i][jn][4 * q + 2], acc[i][jn][4 * q + 3]);
-                    const uint32_t b0 = pack_bf16x2(acc[i][jn][4 * q + 4], acc[i][jn][4 * q + 5]);
-                    const uint32_t b1 = pack_bf16x2(acc[i][jn][4 * q + 6], acc[i][jn][4 * q + 7]);
-                    const auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-                    const auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-                    const int e = r8 + (i & 1) * 32 + (q + hi) * 8;
-                    uint16_t* dst = base + (((e >> 6) + (i >> 1)) * ts + (e & 63));
-                    if (sa.debug == 2) dst = a.out + ((dst - a.out) & 0xffff8);
-                    if (sa.debug == 3) {   // the SHAPE of full-line stores (8 rows x 128 bytes per instruction), wrong data: timing only
-                        const int s4 = ii * 2 + qq, mm = w.m0 + wn * 64 + jn * 32 + s4 * 8 + (lane >> 3);
-                        const int64_t dd = static_cast<int64_t>(mm) * a.Ip + w.i0 + wm * 128 + half * 64 + (lane & 7) * 8;
-                        dst = a.out + (dd >> 6) * ts + static_cast<int64_t>(w.z) * 64 + (dd & 63 & ~7);
-                    }
-                    if (sa.debug != 1) *reinterpret_cast<u32x4*>(dst) = u32x4{s0[0], s1[0], s0[1], s1[1]};
-                    __builtin_amdgcn_sched_barrier(0);   // one store's temporaries at a time: beside 128 accumulators there is no room for the packed tile
-                }
-            }
-        }
-        if (half == 1 && w.colsum) {   // column I: wave (wm, wn) summed G over t for output columns m0 + wn 64 + wm 32 + lr; k-octets in lanes l, l ^ 32
-            const float total = cs + __shfl_xor(cs, 32);
-            if (hi == 0) {
-                const int64_t db = static_cast<int64_t>(w.m0 + wn * 64 + wm * 32 + lr) * a.Ip + a.I;
-                *reinterpret_cast<u32x4*>(a.out + (db >> 6) * ts + static_cast<int64_t>(w.z) * 64 + (db & 63)) =
-                    u32x4{pack_bf16x2(total, 0.0f), 0u, 0u, 0u};
-            }
-        }
-    };
-    pptn::mainloop_stream<IMG>(sm, src, nitems, a.KT, wave, lane, static_cast<int64_t>(a.I) * 64, static_cast<int64_t>(a.O) * 64, item_of, store);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1954,7 +1828,6 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_pp_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pp::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>((psg_gemm_v3_kernel<0, true>)), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_v3_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, PV3_SMEM_MAX) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_v2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, PV2_SMEM) == hipSuccess &&
@@ -1964,9 +1837,6 @@ int configure_once() {
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_stream_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
-            hipFuncSetAttribute(reinterpret_cast<const void*>(psg_gemm_tn_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess &&
             hipFuncSetAttribute(reinterpret_cast<const void*>(cov_gemm_tn_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, pptn::SMEM_BYTES) == hipSuccess;
@@ -2043,9 +1913,6 @@ int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t
     return launch_status();
 }
 
-// KF_PSG_DIRECT=1: the k-tile-major per-sample gradients of the 128 x 128 kernel leave straight from the accumulators (A/B, read per call)
-inline bool psg_direct_stores() { const char* e = getenv("KF_PSG_DIRECT"); return e && e[0] == '1' && e[1] == 0; }
-
 int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
     p.n_begin = 0;
     if (engine_generation() == 3 && !p.conv && !p.out_rows && p.K >= 256 && p.M % 256 == 0 && p.N >= 256 && !getenv("KF_PSG_PP_OFF")) {
@@ -2078,7 +1945,6 @@ int launch_psg_v2(PsgV2Args& p, hipStream_t st) {
         const size_t smem = PV2_SMEM + ((p.conv && p.N <= PV2_ROWTAB_MAX) ? static_cast<size_t>((p.N + 3) / 4 * 16) : 0);
         if (p.out_rows == 2) hipLaunchKernelGGL(psg_gemm_v3_kernel<2>, dim3(grid), dim3(NTHREADS), smem, st, p);
         else if (p.out_rows) hipLaunchKernelGGL(psg_gemm_v3_kernel<1>, dim3(grid), dim3(NTHREADS), smem, st, p);
-        else if (psg_direct_stores()) hipLaunchKernelGGL((psg_gemm_v3_kernel<0, true>), dim3(grid), dim3(NTHREADS), smem, st, p);
         else hipLaunchKernelGGL(psg_gemm_v3_kernel<0>, dim3(grid), dim3(NTHREADS), smem, st, p);
         return launch_status();
     }
@@ -2479,21 +2345,9 @@ int kf_pairwise_score_rows2(float* scores, int64_t ld_scores, const void* P_tile
         g.tiles_m = static_cast<int>(O / 256); g.tiles_n = static_cast<int>(I / 256); g.ones = append_ones ? 1 : 0;
         const int64_t items = b * g.tiles_m * g.tiles_n;
         if (items >= (1LL << 31)) return KF_ERR_INVALID_ARGUMENT;
-        const char* stream_env = getenv("KF_PSG_STREAM");   // 1: persistent workgroups, items streamed, register stores (round 6; A/B)
-        if (stream_env && stream_env[0] == '1' && stream_env[1] == 0 && g.KT >= 2 && b * 64 * 3 < (1LL << 31)) {
-            PsgTnStreamArgs sargs{};
-            sargs.g = g;
-            sargs.dA = g.A[1] ? g.A[1] - g.A[0] : 0;
-            sargs.dG = g.G[1] ? g.G[1] - g.G[0] : 0;
-            if (const char* e = getenv("KF_PSG_STREAM_DEBUG")) sargs.debug = atoi(e);
-            with_tn_image([&](auto img) {
-                hipLaunchKernelGGL((psg_gemm_tn_stream_kernel<decltype(img)::value>), dim3(256), dim3(pptn::THREADS), pptn::SMEM_BYTES, st, sargs);
-            });
-        } else {
-            with_tn_image([&](auto img) {
-                hipLaunchKernelGGL((psg_gemm_tn_kernel<decltype(img)::value>), dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pptn::THREADS), pptn::SMEM_BYTES, st, g);
-            });
-        }
+        with_tn_image([&](auto img) {
+            hipLaunchKernelGGL((psg_gemm_tn_kernel<decltype(img)::value>), dim3(static_cast<unsigned>(8 * cdiv(items, 8))), dim3(pptn::THREADS), pptn::SMEM_BYTES, st, g);
+        });
         if (launch_status() != KF_OK) return KF_ERR_LAUNCH_FAILED;
         return launch_score_v2(scores, ld_scores, reinterpret_cast<const uint16_t*>(P_tiled), psg, Q, b, O * Ip, scale, st);
     }

@@ -110,26 +110,9 @@ llama32)
     cp bench_extras.json gpurun_out/r06_bench_llama_32blocks_extras.json
     python tools/bench_digest.py bench_extras.json || tail -c 3000 gpurun_out/r06_bench_llama_32blocks.log
     ;;
-psgdirect)
-    ( timeout 300 python tools/r06_psg_direct.py ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tee gpurun_out/r06_psg_direct.log
-    ( cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r06_psgd_trace" -- python "$R/tools/r06_psg_direct.py" ) > gpurun_out/r06_psgd_trace.log 2>&1
-    find gpurun_out/r06_psgd_trace -name "*kernel_stats.csv" -exec cp {} gpurun_out/r06_psg_direct_kernel_stats.csv \;
-    rm -rf gpurun_out/r06_psgd_trace
-    grep "psg_gemm_v3\|score_gemm_v3\|conv_pad" gpurun_out/r06_psg_direct_kernel_stats.csv | cut -c1-160
-    ( cd /tmp && timeout 300 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$R/gpurun_out/r06_psgd_pmc" -- python "$R/tools/r06_psg_direct.py" ) > gpurun_out/r06_psgd_pmc.log 2>&1
-    python - <<'PY' | tee -a gpurun_out/r06_psg_direct.log
-import csv, glob
-rows = []
-for path in glob.glob("gpurun_out/r06_psgd_pmc/**/*counter_collection.csv", recursive=True):
-    rows += list(csv.DictReader(open(path)))
-by = {}
-for r in rows:
-    if "psg_gemm_v3" in r["Kernel_Name"] and r["Counter_Name"] == "WRITE_SIZE":
-        by.setdefault(r["Kernel_Name"].split("(")[0][-40:], []).append(float(r["Counter_Value"]))
-for k, v in sorted(by.items()):
-    print(f"{k}: {len(v)} launches, WRITE_SIZE sum {sum(v):.4g} (raw counter units), mean {sum(v)/len(v):.4g}")
-PY
-    rm -rf gpurun_out/r06_psgd_pmc
+layers)
+    # per-layer times of the event-timed entry points (the psgdirect / psgstream steps that ran beside it measured two removed
+    # experiments: profiles/r06_psg_register_stores_negative.log, commit 95a01bd)
     ( timeout 600 python tools/r06_layer_times.py resnet9 8000 ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tail -60 > gpurun_out/r06_layer_times_resnet9.log
     tail -45 gpurun_out/r06_layer_times_resnet9.log
     ;;
