@@ -21,6 +21,7 @@ from kronfluence_amd.arguments import FactorArguments
 from kronfluence_amd.factor.covariance import _loss_scale
 from kronfluence_amd.module.tracked_module import ModuleMode
 from kronfluence_amd.module.utils import (
+    READ_ONLY_FACTORS,
     finalize_iteration, get_tracked_module_names, load_factors, set_factors, set_gradient_scale, set_mode, set_side_stream,
     synchronize_factors, update_factor_args,
 )
@@ -245,7 +246,7 @@ def _fit_lambda_matrices_with_loader_impl(model: nn.Module, state: State, task: 
     set_mode(model, ModuleMode.LAMBDA, tracked_module_names, release_memory=True)
     if eigen_factors is not None:
         for name in eigen_factors:
-            set_factors(model, name, eigen_factors[name], clone=True)
+            set_factors(model, name, eigen_factors[name], clone=True, share=READ_ONLY_FACTORS)
     num_data_processed = torch.zeros((1,), dtype=torch.int64)
     enable_amp = factor_args.amp_dtype is not None
     scale = _loss_scale(factor_args)

@@ -132,10 +132,24 @@ def load_factors(model: nn.Module, factor_name: str, tracked_module_names: Optio
     return out
 
 
-def set_factors(model: nn.Module, factor_name: str, factors: Dict[str, torch.Tensor], clone: bool = False) -> None:
+# Factors a stage only ever READS once they are set -- the rotations read the eigenvector matrices, ``FactorConfig.prepare`` replaces
+# the Lambda matrix by a new tensor (1 / (Lambda / n + damping)) -- are SHARED with the caller's dictionary when they already live on
+# the accelerator instead of cloned (reference module/utils.py:158-177 clones everything): at Llama-3-8B's full depth the clones are
+# 99 GB of eigenvectors + 28 GB of Lambda on top of the caller's own 127 GB, the difference between fitting one MI355X and not.
+# Everything else (counters, accumulators a stage adds to in place) is cloned as before.
+READ_ONLY_FACTORS = ("activation_eigenvectors", "gradient_eigenvectors")
+READ_ONLY_FACTORS_WHEN_SCORING = READ_ONLY_FACTORS + ("lambda_matrix",)
+
+
+def set_factors(model: nn.Module, factor_name: str, factors: Dict[str, torch.Tensor], clone: bool = False,
+                share: Iterable[str] = ()) -> None:
+    """``share``: factor names whose accelerator-resident tensors are handed over as they are even with ``clone``."""
+    shared = factor_name in tuple(share)
     for m in _tracked(model):
         if m.name in factors:
-            m.set_factor(factor_name, factors[m.name].clone() if clone else factors[m.name])
+            factor = factors[m.name]
+            keep = not clone or (shared and factor.is_cuda)
+            m.set_factor(factor_name, factor if keep else factor.clone())
 
 
 def factors_exist(model: nn.Module, tracked_module_names: Optional[List[str]] = None) -> bool:

@@ -15,6 +15,7 @@ from kronfluence_amd.arguments import FactorArguments, ScoreArguments, unsupport
 from kronfluence_amd.factor.covariance import _loss_scale
 from kronfluence_amd.module.tracked_module import ModuleMode
 from kronfluence_amd.module.utils import (
+    READ_ONLY_FACTORS_WHEN_SCORING,
     accumulate_iterations, finalize_all_iterations, finalize_iteration, get_tracked_module_names, prepare_modules,
     set_async_query_gather, set_factors, set_gradient_scale, set_mode, set_query_capacity, synchronize_modules, truncate,
     update_factor_args,
@@ -83,7 +84,7 @@ def _compute_pairwise_scores_with_loaders_impl(loaded_factors: FACTOR_TYPE, mode
         tracked_module_names = get_tracked_module_names(model)
     set_mode(model, ModuleMode.PRECONDITION_GRADIENT, tracked_module_names, release_memory=True)
     for name in loaded_factors:
-        set_factors(model, name, loaded_factors[name], clone=True)
+        set_factors(model, name, loaded_factors[name], clone=True, share=READ_ONLY_FACTORS_WHEN_SCORING)
     prepare_modules(model, tracked_module_names, state.device)
 
     chunks: Dict[str, List[torch.Tensor]] = {}
@@ -180,7 +181,7 @@ def _compute_pairwise_query_aggregated_scores_impl(loaded_factors: FACTOR_TYPE, 
         tracked_module_names = get_tracked_module_names(model)
     set_mode(model, ModuleMode.GRADIENT_AGGREGATION, tracked_module_names, release_memory=True)
     for name in loaded_factors:
-        set_factors(model, name, loaded_factors[name], clone=True)
+        set_factors(model, name, loaded_factors[name], clone=True, share=READ_ONLY_FACTORS_WHEN_SCORING)
     prepare_modules(model, tracked_module_names, state.device)
     enable_amp = score_args.amp_dtype is not None
     scale = _loss_scale(factor_args) if (enable_amp and factor_args.amp_dtype == torch.float16) else 1.0

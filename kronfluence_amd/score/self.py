@@ -20,6 +20,7 @@ from kronfluence_amd.arguments import FactorArguments, ScoreArguments
 from kronfluence_amd.factor.covariance import _loss_scale
 from kronfluence_amd.module.tracked_module import ModuleMode, TrackedModule
 from kronfluence_amd.module.utils import (
+    READ_ONLY_FACTORS_WHEN_SCORING,
     finalize_all_iterations, finalize_iteration, get_tracked_module_names, prepare_modules, set_factors,
     set_gradient_scale, set_mode, set_score_sink, update_factor_args, update_score_args,
 )
@@ -59,7 +60,7 @@ def _self_scores_impl(loaded_factors: FACTOR_TYPE, model: nn.Module, state: Stat
     score_mode = ModuleMode.SELF_MEASUREMENT_SCORE if with_measurement else ModuleMode.SELF_SCORE
     set_mode(model, score_mode, tracked_module_names, release_memory=True)
     for name in loaded_factors:
-        set_factors(model, name, loaded_factors[name], clone=True)
+        set_factors(model, name, loaded_factors[name], clone=True, share=READ_ONLY_FACTORS_WHEN_SCORING)
     prepare_modules(model, tracked_module_names, state.device)
 
     modules = [m for m in model.modules() if isinstance(m, TrackedModule) and m.name in tracked_module_names]
