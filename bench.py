@@ -392,7 +392,9 @@ WORKLOADS = {
                       factor_batch=1000, train_batch=1000, query_batch=100,
                       cpu_sample=dict(n_train=1000, n_query=100, n_fit=250)),
     "resnet9": dict(model=resnet9, kind="image", shape=(3, 32, 32), classes=10, n_train=50_000, n_query=1000,
-                    amp=torch.bfloat16, factor_batch=1000, train_batch=1000, query_batch=250,
+                    # (round 6: factor batches of 2 000 and train batches of 2 048 images -- whole 256-column tiles of the score GEMM, half the
+                    #  launches: 83.3 -> 86.8 M pairs/s, covariance 0.447 -> 0.410 s, Lambda 0.573 -> 0.553 s; 4 096: 84.8 M)
+                    amp=torch.bfloat16, factor_batch=2000, train_batch=2048, query_batch=250,
                     cpu_sample=dict(n_train=192, n_query=32, n_fit=64)),
     "bert_base": dict(model=bert_base, kind="glue", vocab=28996, tokens=128, n_train=8192, n_query=872, full_n_train=67_349,
                       amp=torch.bfloat16, fp32_factors=True, factor_batch=512, train_batch=512, query_batch=109,

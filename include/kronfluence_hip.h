@@ -332,6 +332,23 @@ int kf_precondition(void* P, int out_dtype, int64_t ldp, const void* G, const vo
                     int64_t ldq, void* workspace, int64_t workspace_bytes, void* stream);
 
 /*
+ * kf_precondition_bf16 (ABI 14): the bf16 form of kf_precondition WITHOUT the fp32 eigenvector matrices -- same result, same
+ * call chain (module/tracker/precondition.py:102-123 + factor/config.py:341-353 with precondition_dtype = score_dtype = bf16,
+ * factor/config.py:323-328: the reference casts the eigenvectors to that dtype in `prepare`).  kf_precondition reads Qg (for the
+ * back rotation) and row I of Qa (the bias row) in fp32; a model whose eigenvectors are STORED in bf16 (the reference's
+ * all-low-precision factors) would have to keep fp32 copies alive only for that: 99 GB at Llama-3-8B's full depth.
+ * G: [q,R,O], A: [q,R,I] bf16; Qg_bf16, QgT_bf16 = Qg^T: [O,O]; Qa_bf16, QaT_bf16 = Qa^T: [ldq,ldq] zero-padded from [I',I'],
+ * ldq = I' rounded up to a multiple of 8; bias_row: fp32, I' entries = Qa[I, :] (append_ones) or null; inv_lambda [O,I'] fp32.
+ * P: [q,O,ldq] bf16 (ldp == ldq; ldq - I' zero columns per row).  KF_ERR_INVALID_ARGUMENT when the shape is not one the bf16
+ * form takes (R == 1, O or I not multiples of 8 or below 64): the caller uses kf_precondition with fp32 eigenvectors then.
+ * workspace (device): kf_precondition_workspace_bytes(q,R,O,I') bytes.
+ */
+int kf_precondition_bf16(void* P, int64_t ldp, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I,
+                         int append_ones, const void* Qg_bf16, const void* QgT_bf16, const void* Qa_bf16, const void* QaT_bf16,
+                         int64_t ldq, const float* bias_row, const float* inv_lambda, float scale, void* workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/*
  * scores[q, n] += scale * sum_{o,i} P[q,o,i] * ( sum_r G[n,r,o] * A'[n,r,i] )   for n < b
  * Replaces module/linear.py:112-122 and module/conv2d.py:199-209 (three-operand einsum),
  * module/tracker/pairwise_score.py:41-45 and the per-layer add_ of score/dot_product.py:105-117:

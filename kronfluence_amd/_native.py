@@ -15,7 +15,7 @@ from typing import Optional
 import torch  # noqa: F401  (must precede the dlopen below)
 
 LIB_NAME = "libkronfluence_hip.so"
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 KF_F32, KF_BF16, KF_F16, KF_F64, KF_I64, KF_I32, KF_U8 = range(7)
 
@@ -72,6 +72,7 @@ SIGNATURES = {
     "kf_inv_lambda": (_i, [_p, _p, _i64, _d, _d, _p, _p]),
     "kf_precondition_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "kf_precondition": (_i, [_p, _i, _i64, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _f, _p, _p, _p, _i64, _p, _i64, _p]),
+    "kf_precondition_bf16": (_i, [_p, _i64, _p, _p, _i64, _i64, _i64, _i64, _i, _p, _p, _p, _p, _i64, _p, _p, _f, _p, _i64, _p]),
     "kf_pairwise_workspace_bytes": (_i64, [_i64, _i64, _i64, _i64]),
     "kf_pairwise_score": (_i, [_p, _i64, _p, _i, _i64, _i64, _p, _p, _i, _i64, _i64, _i64, _i64, _i, _f, _p, _i64, _p]),
     "kf_pairwise_conv2d_workspace_bytes": (_i64, [_i64] * 5 + [_i] * 8),

@@ -24,8 +24,8 @@ int rotate_gemm_v2(void* C, int64_t ldc, const void* A, int64_t lda, const void*
 int64_t precondition_v3_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t W);
 bool precondition_v3_eligible(int64_t q, int64_t R, int64_t O, int64_t I, int64_t W);
 int precondition_v3(void* Pout, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg,
-                    const float* Qa, int64_t Ip, const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16,
-                    const void* QaT_bf16, int64_t W, void* workspace, void* stream);
+                    const void* Qg_bf16, const float* bias_row, int64_t Ip, const float* inv_lambda, float scale, const void* Qa_bf16,
+                    const void* QgT_bf16, const void* QaT_bf16, int64_t W, void* workspace, void* stream);
 }
 
 namespace {
@@ -945,7 +945,7 @@ kf_view make_view(const void* p, int dtype, int64_t bs, int64_t rs, int64_t ks, 
 // ================================================================================================
 extern "C" {
 
-int kf_abi_version(void) { return 13; }
+int kf_abi_version(void) { return 14; }
 
 const char* kf_status_string(int s) {
     switch (s) {
@@ -1192,6 +1192,62 @@ int kf_inv_lambda(float* out, const float* Lambda, int64_t numel, double n_lambd
     return launch_status();
 }
 
+namespace {
+// The bf16 form of the preconditioner (ScoreArguments.precondition_dtype = bf16): the augmented axis is carried at width
+// ldq = I' rounded up to a multiple of 8 -- the copies Qa_bf16 / QaT_bf16 are [ldq, ldq] with zero padding, P has row stride
+// ldp == ldq and zero padding columns -- so layers with an odd I' (every Linear with bias on sequences: BERT, GPT-2) stay on the
+// bf16 engine; the bias column "[A, 1] Qa = A Qa[:I] + Qa[I]" is a row (bias_row, fp32) added in the epilogue.
+bool precondition_low_eligible(const void* Pout, const void* G, const void* A, int out_dtype, int in_dtype, int64_t R, int64_t O, int64_t I,
+                               int64_t Ip, int64_t ldp, const void* Qa_bf16, const void* QgT_bf16, const void* QaT_bf16, int64_t ldq) {
+    return Qa_bf16 && QgT_bf16 && QaT_bf16 && out_dtype == KF_BF16 && in_dtype == KF_BF16 && R > 1 && O % 8 == 0 && I % 8 == 0 &&
+           I >= HBK && O >= HBK && ldq % 8 == 0 && ldq >= Ip && ldp == ldq &&
+           ((reinterpret_cast<uintptr_t>(Qa_bf16) | reinterpret_cast<uintptr_t>(QgT_bf16) | reinterpret_cast<uintptr_t>(QaT_bf16) |
+             reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Pout)) & 15) == 0;
+}
+
+// Qg (fp32) or Qg_bf16 (the same matrix in bf16; preferred when given): the back rotation of the round-3 form needs Qg itself
+int precondition_low(void* Pout, int64_t ldp, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I, int append_ones,
+                     const float* Qg, const void* Qg_bf16, const float* bias_row, const float* inv_lambda, float scale, const void* Qa_bf16,
+                     const void* QgT_bf16, const void* QaT_bf16, int64_t ldq, void* workspace, void* stream) {
+    hipStream_t st = as_stream(stream);
+    const int64_t Ip = I + (append_ones ? 1 : 0);
+    int rc;
+    if (ldq == (Ip + 7) / 8 * 8 && precondition_v3_eligible(q, R, O, I, ldq))
+        return precondition_v3(Pout, G, A, q, R, O, I, append_ones, Qg, Qg_bf16, bias_row, Ip, inv_lambda, scale, Qa_bf16, QgT_bf16, QaT_bf16, ldq,
+                               workspace, stream);
+    {
+        const int64_t W = ldq;
+        uint16_t* Gt16 = reinterpret_cast<uint16_t*>(workspace);   // [q R, O]
+        uint16_t* At16 = Gt16 + ((q * R * O + 127) & ~127LL);        // [q R, W]
+        uint16_t* rot16 = At16 + ((q * R * W + 127) & ~127LL);       // [q, O, W]
+        uint16_t* T16 = rot16 + ((q * O * W + 127) & ~127LL);        // [q, O, W]
+        // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']                (NT: B[n, k] = QgT[n, k])
+        rc = launch_gemm_bf16(1, Gt16, KF_BF16, O, 0, make_view(G, KF_BF16, 0, O, 1, q * R, O), make_view(QgT_bf16, KF_BF16, 0, O, 1, O, O), 1,
+                              1.0f, 0.0f, st, 0);
+        if (rc != KF_OK) return rc;
+        // At[(q r), i'] = sum_i A[(q r), i] Qa[i, i'] (+ Qa[I, i'])  (NT over the I real columns; pad columns come out zero)
+        HalfExtras bias;
+        if (append_ones) { bias.row_add = bias_row; bias.row_add_n = static_cast<int>(Ip); }
+        rc = launch_gemm_bf16(1, At16, KF_BF16, W, 0, make_view(A, KF_BF16, 0, I, 1, q * R, I), make_view(QaT_bf16, KF_BF16, 0, W, 1, W, I), 1,
+                              1.0f, 0.0f, st, 0, false, &bias);
+        if (rc != KF_OK) return rc;
+        // rot[q][o, i] = (sum_r Gt[q, r, o] At[q, r, i]) * inv_lambda[o, i]   (TN, batched over q; zero in the pad columns)
+        HalfExtras lam;
+        lam.mul = inv_lambda; lam.ld_mul = Ip; lam.mul_n = static_cast<int>(Ip);
+        rc = launch_gemm_bf16(2, rot16, KF_BF16, W, O * W, make_view(Gt16, KF_BF16, R * O, 1, O, O, R), make_view(At16, KF_BF16, R * W, 1, W, W, R), q,
+                              1.0f, 0.0f, st, 0, false, &lam);
+        if (rc != KF_OK) return rc;
+        // T[(q o), j] = sum_i rot[(q o), i] Qa[j, i]                 (NT)
+        rc = launch_gemm_bf16(1, T16, KF_BF16, W, 0, make_view(rot16, KF_BF16, 0, W, 1, q * O, W), make_view(Qa_bf16, KF_BF16, 0, W, 1, W, W), 1,
+                              1.0f, 0.0f, st, 0);
+        if (rc != KF_OK) return rc;
+        // P[q][m, n] = scale * sum_o QgT[o, m] T[q][o, n]            (TN, batched over q)
+        return launch_gemm_bf16(2, Pout, KF_BF16, ldp, O * ldp, make_view(QgT_bf16, KF_BF16, 0, 1, O, O, O), make_view(T16, KF_BF16, O * W, 1, W, W, O), q,
+                                scale, 0.0f, st, 0);
+    }
+}
+}  // namespace
+
 int64_t kf_precondition_workspace_bytes(int64_t q, int64_t R, int64_t O, int64_t Ip) {
     // Gt, At, T and (for low-precision outputs) the fp32 staging copy of the rotated gradient; I' rounded up to the
     // padded width the bf16 path may use
@@ -1212,47 +1268,11 @@ int kf_precondition(void* Pout, int out_dtype, int64_t ldp, const void* G, const
     if (q == 0) return KF_OK;
     hipStream_t st = as_stream(stream);
     // precondition_dtype = bf16 (reference low-precision preset): every O(q ..) contraction runs on the bf16 MFMA engine
-    // from bf16 copies of the eigenvectors (fp32 accumulation).  The augmented axis is carried at width ldq = I' rounded
-    // up to a multiple of 8 -- the copies Qa_bf16 / QaT_bf16 are [ldq, ldq] with zero padding, P has row stride ldp ==
-    // ldq and zero padding columns -- so layers with an odd I' (every Linear with bias on sequences: BERT, GPT-2) stay
-    // on the bf16 engine; the bias column "[A, 1] Qa = A Qa[:I] + Qa[I]" is a row added in the epilogue.
-    const bool low = Qa_bf16 && QgT_bf16 && QaT_bf16 && out_dtype == KF_BF16 && in_dtype == KF_BF16 && R > 1 && O % 8 == 0 && I % 8 == 0 &&
-                     I >= HBK && O >= HBK && ldq % 8 == 0 && ldq >= Ip && ldp == ldq &&
-                     ((reinterpret_cast<uintptr_t>(Qa_bf16) | reinterpret_cast<uintptr_t>(QgT_bf16) | reinterpret_cast<uintptr_t>(QaT_bf16) |
-                       reinterpret_cast<uintptr_t>(A) | reinterpret_cast<uintptr_t>(G) | reinterpret_cast<uintptr_t>(Pout)) & 15) == 0;
+    // from bf16 copies of the eigenvectors (fp32 accumulation): precondition_low below.
+    if (precondition_low_eligible(Pout, G, A, out_dtype, in_dtype, R, O, I, Ip, ldp, Qa_bf16, QgT_bf16, QaT_bf16, ldq))
+        return precondition_low(Pout, ldp, G, A, q, R, O, I, append_ones, Qg, nullptr, append_ones ? Qa + I * Ip : nullptr, inv_lambda, scale,
+                                Qa_bf16, QgT_bf16, QaT_bf16, ldq, workspace, stream);
     int rc;
-    if (low && ldq == (Ip + 7) / 8 * 8 && precondition_v3_eligible(q, R, O, I, ldq))
-        return precondition_v3(Pout, G, A, q, R, O, I, append_ones, Qg, Qa, Ip, inv_lambda, scale, Qa_bf16, QgT_bf16, QaT_bf16, ldq, workspace, stream);
-    if (low) {
-        const int64_t W = ldq;
-        uint16_t* Gt16 = reinterpret_cast<uint16_t*>(workspace);   // [q R, O]
-        uint16_t* At16 = Gt16 + ((q * R * O + 127) & ~127LL);        // [q R, W]
-        uint16_t* rot16 = At16 + ((q * R * W + 127) & ~127LL);       // [q, O, W]
-        uint16_t* T16 = rot16 + ((q * O * W + 127) & ~127LL);        // [q, O, W]
-        // Gt[(q r), o'] = sum_o G[(q r), o] Qg[o, o']                (NT: B[n, k] = QgT[n, k])
-        rc = launch_gemm_bf16(1, Gt16, KF_BF16, O, 0, make_view(G, KF_BF16, 0, O, 1, q * R, O), make_view(QgT_bf16, KF_BF16, 0, O, 1, O, O), 1,
-                              1.0f, 0.0f, st, 0);
-        if (rc != KF_OK) return rc;
-        // At[(q r), i'] = sum_i A[(q r), i] Qa[i, i'] (+ Qa[I, i'])  (NT over the I real columns; pad columns come out zero)
-        HalfExtras bias;
-        if (append_ones) { bias.row_add = Qa + I * Ip; bias.row_add_n = static_cast<int>(Ip); }
-        rc = launch_gemm_bf16(1, At16, KF_BF16, W, 0, make_view(A, KF_BF16, 0, I, 1, q * R, I), make_view(QaT_bf16, KF_BF16, 0, W, 1, W, I), 1,
-                              1.0f, 0.0f, st, 0, false, &bias);
-        if (rc != KF_OK) return rc;
-        // rot[q][o, i] = (sum_r Gt[q, r, o] At[q, r, i]) * inv_lambda[o, i]   (TN, batched over q; zero in the pad columns)
-        HalfExtras lam;
-        lam.mul = inv_lambda; lam.ld_mul = Ip; lam.mul_n = static_cast<int>(Ip);
-        rc = launch_gemm_bf16(2, rot16, KF_BF16, W, O * W, make_view(Gt16, KF_BF16, R * O, 1, O, O, R), make_view(At16, KF_BF16, R * W, 1, W, W, R), q,
-                              1.0f, 0.0f, st, 0, false, &lam);
-        if (rc != KF_OK) return rc;
-        // T[(q o), j] = sum_i rot[(q o), i] Qa[j, i]                 (NT)
-        rc = launch_gemm_bf16(1, T16, KF_BF16, W, 0, make_view(rot16, KF_BF16, 0, W, 1, q * O, W), make_view(Qa_bf16, KF_BF16, 0, W, 1, W, W), 1,
-                              1.0f, 0.0f, st, 0);
-        if (rc != KF_OK) return rc;
-        // P[q][m, n] = scale * sum_o QgT[o, m] T[q][o, n]            (TN, batched over q)
-        return launch_gemm_bf16(2, Pout, KF_BF16, ldp, O * ldp, make_view(QgT_bf16, KF_BF16, 0, 1, O, O, O), make_view(T16, KF_BF16, O * W, 1, W, W, O), q,
-                                scale, 0.0f, st, 0);
-    }
     if (ldp != Ip) return KF_ERR_INVALID_ARGUMENT;  // the fp32 path writes compact rows
     float* Gt = reinterpret_cast<float*>(workspace);
     float* At = Gt + q * R * O;
@@ -1276,6 +1296,20 @@ int kf_precondition(void* Pout, int out_dtype, int64_t ldp, const void* G, const
     rc = launch_gemm(Pout, Ip, O * Ip, make_view(Qg, KF_F32, 0, O, 1, O, O), make_view(T, KF_F32, O * Ip, 1, Ip, Ip, O), q, scale, 0.0f,
                      nullptr, 0, st, out_dtype);
     return rc;
+}
+
+int kf_precondition_bf16(void* Pout, int64_t ldp, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I, int append_ones,
+                         const void* Qg_bf16, const void* QgT_bf16, const void* Qa_bf16, const void* QaT_bf16, int64_t ldq,
+                         const float* bias_row, const float* inv_lambda, float scale, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!Pout || !G || !A || !Qg_bf16 || !inv_lambda || q < 0 || R <= 0 || O <= 0 || I <= 0 || (append_ones && !bias_row)) return KF_ERR_INVALID_ARGUMENT;
+    const int64_t Ip = I + (append_ones ? 1 : 0);
+    if ((reinterpret_cast<uintptr_t>(Qg_bf16) & 15) != 0 ||
+        !precondition_low_eligible(Pout, G, A, KF_BF16, KF_BF16, R, O, I, Ip, ldp, Qa_bf16, QgT_bf16, QaT_bf16, ldq))
+        return KF_ERR_INVALID_ARGUMENT;
+    if (!workspace || workspace_bytes < kf_precondition_workspace_bytes(q, R, O, Ip)) return KF_ERR_WORKSPACE_TOO_SMALL;
+    if (q == 0) return KF_OK;
+    return precondition_low(Pout, ldp, G, A, q, R, O, I, append_ones, nullptr, Qg_bf16, bias_row, inv_lambda, scale, Qa_bf16, QgT_bf16,
+                            QaT_bf16, ldq, workspace, stream);
 }
 
 int64_t kf_pairwise_workspace_bytes(int64_t b, int64_t R, int64_t O, int64_t Ip) {

@@ -1893,20 +1893,28 @@ void launch_score_rows(float* scores, int64_t ld, const uint16_t* P, const uint1
     else hipLaunchKernelGGL((score_gemm_v2_kernel<128, 256, 2>), grid, dim3(SV2_THREADS), 2 * 384 * 128, st, s);
 }
 
+// whether the mixed row tiling below is taken without being asked for (round 6: opt-in until measured)
+constexpr bool MIXED_ROWS_DEFAULT = false;
+inline bool mixed_rows_default() { return MIXED_ROWS_DEFAULT; }
+
 int launch_score_v2(float* scores, int64_t ld, const uint16_t* P, const uint16_t* psg, int64_t Q, int64_t b, int64_t D,
                     float scale, hipStream_t st) {
     // Mixed row tiling: Q = 256 a + r with 0 < r <= 128 and a wide train side (BERT: 872 queries against 512 sequences) would pad
-    // its last 256-row tile more than half -- `a` row tiles on the 256 x 256 loop and ONE launch of 128 x 256 tiles (64 x 64
-    // waves, kf_pingpong64.h) for the last r rows instead: 896 instead of 1 024 padded rows.  OPT-IN (KF_SCORE_MIXED=1): measured on
-    // BERT (872 x 512) the 128 x 256 launch costs 253 us for an eighth of the work -- 740 + 253 us against 970 us for one launch over
-    // 1 024 padded rows: no gain.
+    // its last 256-row tile more than half -- `a` row tiles on the 256 x 256 loop and ONE more launch for the last r rows: 896
+    // instead of 1 024 padded rows.  Round 5 ran that remainder on 128 x 256 tiles (64 x 64 waves, kf_pingpong64.h): 253 us for an
+    // eighth of the work -- 740 + 253 us against 970 us for one launch over 1 024 padded rows, no gain.  Round 6: when the train
+    // side is whole 512-column tiles the remainder takes the 128 x 512 wave grid (score_gemm_v5_kernel<1, 8>: waves of 128 x 64
+    // like the main loop, one tile across the whole batch, split over k on all CUs); KF_SCORE_MIXED = 0 / 1 forces it off / on
+    // (1 without 512-column tiles: the 128 x 256 shape).
     const int64_t rest = Q % 256;
     const char* mixed_env = getenv("KF_SCORE_MIXED");
-    const bool mixed = Q > 256 && rest > 0 && rest <= 128 && b > 128 && engine_generation() == 3 && half_tile_engine() == 4 &&
-                       !getenv("KF_SCORE_SHAPE") && mixed_env && atoi(mixed_env) == 1;
+    const bool wide_rest = cdiv(b, 512) * 512 == cdiv(b, 256) * 256;
+    const bool eligible = Q > 256 && rest > 0 && rest <= 128 && b > 128 && engine_generation() == 3 && half_tile_engine() == 4 &&
+                          !getenv("KF_SCORE_SHAPE");
+    const bool mixed = eligible && (mixed_env ? atoi(mixed_env) == 1 : (wide_rest && mixed_rows_default()));
     if (mixed) {
         launch_score_rows(scores, ld, P, psg, Q, 0, Q - rest, b, D, scale, 0, st);
-        launch_score_rows(scores, ld, P, psg, Q, Q - rest, rest, b, D, scale, 2, st);
+        launch_score_rows(scores, ld, P, psg, Q, Q - rest, rest, b, D, scale, wide_rest ? 4 : 2, st);
     } else {
         launch_score_rows(scores, ld, P, psg, Q, 0, Q, b, D, scale, -1, st);
     }
@@ -2079,9 +2087,11 @@ bool precondition_v3_eligible(int64_t q, int64_t R, int64_t O, int64_t I, int64_
            ((W + 63) / 64 * 64) * R + 64 < (1LL << 31) && q <= 65535;
 }
 
+// Qg: fp32 [O, O], cast to bf16 per call -- or Qg_bf16: the same matrix already in bf16 (then Qg is not read);
+// bias_row: row I of Qa (fp32, Ip entries) when the ones column is appended, else null
 int precondition_v3(void* Pout, const void* G, const void* A, int64_t q, int64_t R, int64_t O, int64_t I, int append_ones, const float* Qg,
-                    const float* Qa, int64_t Ip, const float* inv_lambda, float scale, const void* Qa_bf16, const void* QgT_bf16,
-                    const void* QaT_bf16, int64_t W, void* workspace, void* stream) {
+                    const void* Qg_bf16, const float* bias_row, int64_t Ip, const float* inv_lambda, float scale, const void* Qa_bf16,
+                    const void* QgT_bf16, const void* QaT_bf16, int64_t W, void* workspace, void* stream) {
     if (configure_once() != KF_OK) return KF_ERR_LAUNCH_FAILED;
     hipStream_t st = as_stream(stream);
     const PrecondPlan p = precond_plan(q, R, O, W);
@@ -2097,12 +2107,16 @@ int precondition_v3(void* Pout, const void* G, const void* A, int64_t q, int64_t
     if (hipMemsetAsync(at, 0, static_cast<size_t>(2 * q * W64 * R), st) != hipSuccess) return KF_ERR_LAUNCH_FAILED;
     hipLaunchKernelGGL(pad_rows_bf16_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(W * W64, 256), 2048))), dim3(256), 0, st, qa,
                        reinterpret_cast<const uint16_t*>(Qa_bf16), static_cast<int>(W), static_cast<int>(W), static_cast<int>(W64));
-    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(O * O, 256), 2048))), dim3(256), 0, st, qg, Qg, O * O);
+    const uint16_t* qg_used = reinterpret_cast<const uint16_t*>(Qg_bf16);
+    if (!qg_used) {
+        hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(static_cast<unsigned>(std::min<int64_t>(cdiv(O * O, 256), 2048))), dim3(256), 0, st, qg, Qg, O * O);
+        qg_used = qg;
+    }
     int rc = launch_rotate_blocked(gt, reinterpret_cast<const uint16_t*>(QgT_bf16), O, reinterpret_cast<const uint16_t*>(G), O, O, q * R, O, 1.0f,
                                    nullptr, 0, R, O * R, st);
     if (rc != KF_OK) return rc;
     rc = launch_rotate_blocked(at, reinterpret_cast<const uint16_t*>(QaT_bf16), W, reinterpret_cast<const uint16_t*>(A), I, W, q * R, I, 1.0f,
-                               append_ones ? Qa + I * Ip : nullptr, append_ones ? static_cast<int>(Ip) : 0, R, W64 * R, st);
+                               append_ones ? bias_row : nullptr, append_ones ? static_cast<int>(Ip) : 0, R, W64 * R, st);
     if (rc != KF_OK) return rc;
     PsgV2Args g{};
     g.out = rot; g.out_tile_stride = 0; g.out_rows = 2;
@@ -2114,7 +2128,7 @@ int precondition_v3(void* Pout, const void* G, const void* A, int64_t q, int64_t
     if (rc != KF_OK) return rc;
     rc = launch_rotate_blocked(tt, qa, W64, rot, W64, W, q * O, W64, 1.0f, nullptr, 0, O, W * O, st);
     if (rc != KF_OK) return rc;
-    return launch_rotate_blocked(reinterpret_cast<uint16_t*>(Pout), qg, O, tt, O, O, q * W, O, scale, nullptr, 0, W, O * W, st);
+    return launch_rotate_blocked(reinterpret_cast<uint16_t*>(Pout), qg_used, O, tt, O, O, q * W, O, scale, nullptr, 0, W, O * W, st);
 }
 }  // namespace kf
 

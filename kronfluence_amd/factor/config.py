@@ -203,8 +203,14 @@ class Ekfac(FactorConfig, factor_strategy=FactorStrategy.EKFAC):
         replaced by ``1 / (Lambda / n + damping)`` (fp64 arithmetic, kf_inv_lambda).  Everything
         stays RESIDENT in HBM -- the reference parks the result on the CPU and re-uploads it on
         every query batch (config.py:347-349)."""
+        # (bf16 preconditioner + bf16-stored eigenvectors: the bf16 call chain, kf_precondition_bf16, reads no fp32 copy; the paths
+        #  that do convert on first use, ``BaseTracker._eigenvectors32`` -- at Llama-3-8B's depth the fp32 copies are 99 GB)
+        lazy = (getattr(score_args, "precondition_dtype", None) == torch.bfloat16 and getattr(score_args, "score_dtype", None) == torch.bfloat16)
         for name in (ACTIVATION_EIGENVECTORS_NAME, GRADIENT_EIGENVECTORS_NAME):
-            storage[name] = storage[name].to(device=device, dtype=torch.float32).contiguous()
+            if lazy and storage[name].dtype == torch.bfloat16:
+                storage[name] = storage[name].to(device=device).contiguous()
+            else:
+                storage[name] = storage[name].to(device=device, dtype=torch.float32).contiguous()
         storage[ACTIVATION_EIGENVALUES_NAME] = None
         storage[GRADIENT_EIGENVALUES_NAME] = None
         n_lambda = float(storage[NUM_LAMBDA_PROCESSED].item())

@@ -99,6 +99,16 @@ class BaseTracker:
         self.cached_activations: Optional[Union[List[torch.Tensor], torch.Tensor]] = None
         self.cached_per_sample_gradient: Optional[torch.Tensor] = None
 
+    def _eigenvectors32(self, name: str) -> torch.Tensor:
+        """The stored eigenvector matrix ``name`` in fp32, converted (and kept in ``storage``) on first use: ``Ekfac.prepare`` leaves
+        accelerator-resident low-precision eigenvectors as they are when the preconditioner runs in bf16 -- the bf16 call chain
+        never reads fp32 copies -- so the paths that do (one row per sample, fp32 stages, self-influence) ask here."""
+        q = self.module.storage[name]
+        if q.dtype != torch.float32 or not q.is_contiguous():
+            q = q.to(dtype=torch.float32).contiguous()
+            self.module.storage[name] = q
+        return q
+
     # -- protocol, overridden per mode ---------------------------------------------------------------------
     def register_hooks(self) -> None:
         """Install the mode's forward hook(s) on the wrapped module."""

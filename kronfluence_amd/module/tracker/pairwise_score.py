@@ -470,8 +470,8 @@ class PairwiseScoreTracker(BaseTracker):
                     # rotated row by row, keeping the R axis: the held queries had one row per sample, the train
                     # batch may have several (single-token queries against sequence batches)
                     n, r = g.shape[0], g.shape[1]
-                    g = ops.matmul_nn(g.reshape(n * r, -1), storage[GRADIENT_EIGENVECTORS_NAME]).reshape(n, r, -1)
-                    a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
+                    g = ops.matmul_nn(g.reshape(n * r, -1), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME)).reshape(n, r, -1)
+                    a = ops.matmul_nn(a.reshape(n * r, -1), self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME),
                                       append_ones=ones).reshape(n, r, -1)
                     ones = False
                 if isinstance(preconditioned, list) and self._low_rank_plan(preconditioned[0], preconditioned[1], g, a, ones) == "factored":
@@ -537,7 +537,7 @@ class PairwiseScoreTracker(BaseTracker):
             summed = summed.to(torch.float32).contiguous()
             _, o, ip = summed.shape
             if module.queries_in_eigenbasis:  # queries are held as M_q: rotate the summed gradient instead
-                q_a, q_g = storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
+                q_a, q_g = self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME)
                 t1 = torch.empty((o, ip), dtype=torch.float32, device=summed.device)
                 ops.gemm(t1, ip, 0, ops.view(summed, 0, ip, 1, o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
                 rotated = torch.empty((1, o, ip), dtype=torch.float32, device=summed.device)

@@ -55,21 +55,27 @@ class PreconditionTracker(BaseTracker):
     _bf16_q = None
 
     def _bf16_eigenvectors(self):
-        """bf16 copies ``(Q_A, Q_G^T, Q_A^T)`` for ``precondition_dtype == bf16`` (the reference casts the eigenvectors to
-        that dtype in ``Ekfac.prepare``, factor/config.py:323-328), ``Q_A`` and ``Q_A^T`` zero-padded to ``[W, W]`` with
-        ``W = I'`` rounded up to a multiple of 8 (see ``ops.precondition``); ``(None, None, None)`` otherwise."""
+        """bf16 operands ``(Q_A, Q_G^T, Q_A^T, Q_G, bias row)`` for ``precondition_dtype == bf16`` (the reference casts the eigenvectors
+        to that dtype in ``Ekfac.prepare``, factor/config.py:323-328): ``Q_A`` and ``Q_A^T`` zero-padded to ``[W, W]`` with ``W = I'``
+        rounded up to a multiple of 8 (see ``ops.precondition``), ``Q_G`` as stored when it is stored in bf16, the bias row
+        ``Q_A[I]`` in fp32 for layers with a bias; five ``None`` otherwise.  Stored matrices that already have the layout asked for
+        (bf16, ``I' % 8 == 0``) are used as they are -- no copy."""
         args = self.module.score_args
         if args.precondition_dtype != torch.bfloat16 or args.score_dtype != torch.bfloat16:
-            return None, None, None
+            return None, None, None, None, None
         storage = self.module.storage
-        source = storage[ACTIVATION_EIGENVECTORS_NAME]
+        source, source_g = storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
         if self._bf16_q is None or self._bf16_q[0] is not source:
             pad = (-source.shape[0]) % 8
-            padded = torch.nn.functional.pad(source, (0, pad, 0, pad))
-            self._bf16_q = (source, padded.to(torch.bfloat16).contiguous(),
-                            storage[GRADIENT_EIGENVECTORS_NAME].t().contiguous().to(torch.bfloat16),
-                            padded.t().contiguous().to(torch.bfloat16))
-        return self._bf16_q[1], self._bf16_q[2], self._bf16_q[3]
+            if pad == 0 and source.dtype == torch.bfloat16 and source.is_contiguous():
+                q_a = source
+            else:
+                q_a = torch.nn.functional.pad(source, (0, pad, 0, pad)).to(torch.bfloat16).contiguous()
+            q_a_t = torch.nn.functional.pad(source.t(), (0, pad, 0, pad)).to(torch.bfloat16).contiguous()
+            q_g = source_g if (source_g.dtype == torch.bfloat16 and source_g.is_contiguous()) else source_g.to(torch.bfloat16).contiguous()
+            bias_row = source[-1].to(torch.float32).contiguous() if self.module.has_bias else None
+            self._bf16_q = (source, q_a, source_g.t().contiguous().to(torch.bfloat16), q_a_t, q_g, bias_row)
+        return self._bf16_q[1:]
 
     def _store(self, preconditioned: torch.Tensor, from_hook: bool = False) -> None:
         """Keeps the ``[q, O, I']`` block, or -- with ``query_gradient_low_rank = k < min(O, I')`` -- its rank-k factors
@@ -119,8 +125,8 @@ class PreconditionTracker(BaseTracker):
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 if self.EIGENBASIS_QUERIES and g.shape[1] == 1 and not module.factor_args.has_shared_parameters:
                     q = g.shape[0]
-                    gt = ops.matmul_nn(g.reshape(q, -1), storage[GRADIENT_EIGENVECTORS_NAME])
-                    at = ops.matmul_nn(a.reshape(q, -1), storage[ACTIVATION_EIGENVECTORS_NAME], append_ones=ones)
+                    gt = ops.matmul_nn(g.reshape(q, -1), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME))
+                    at = ops.matmul_nn(a.reshape(q, -1), self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME), append_ones=ones)
                     o, ip = gt.shape[1], at.shape[1]
                     rotated = torch.empty((q, o, ip), dtype=torch.float32, device=g.device)
                     ops.gemm(rotated, ip, o * ip, ops.view(gt, o, 1, o, o, 1), ops.view(at, ip, 1, ip, ip, 1), batch=q,
@@ -130,11 +136,16 @@ class PreconditionTracker(BaseTracker):
                     self._store(rotated, from_hook=True)
                     return
                 module.queries_in_eigenbasis = False
-                qa16, qgt16, qat16 = self._bf16_eigenvectors()
-                out = ops.precondition(g, a, ones, storage[GRADIENT_EIGENVECTORS_NAME],
-                                       storage[ACTIVATION_EIGENVECTORS_NAME], storage[LAMBDA_MATRIX_NAME],
-                                       scale=module.gradient_scale, out_dtype=self._out_dtype(),
-                                       q_a_bf16=qa16, q_g_t_bf16=qgt16, q_a_t_bf16=qat16)
+                qa16, qgt16, qat16, qg16, bias_row = self._bf16_eigenvectors()
+                if qa16 is not None and ops.precondition_bf16_eligible(g, a) and (not ones or bias_row is not None):
+                    # bf16 eigenvectors only (kf_precondition_bf16): no fp32 copies of Q_G / Q_A are made for this layer
+                    out = ops.precondition_bf16(g, a, ones, qg16, qgt16, qa16, qat16, bias_row, storage[LAMBDA_MATRIX_NAME],
+                                                scale=module.gradient_scale)
+                else:
+                    out = ops.precondition(g, a, ones, self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME),
+                                           self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME), storage[LAMBDA_MATRIX_NAME],
+                                           scale=module.gradient_scale, out_dtype=self._out_dtype(),
+                                           q_a_bf16=qa16, q_g_t_bf16=qgt16, q_a_t_bf16=qat16)
                 # the bf16 engine hands back rows zero-padded to a multiple of 8 (odd I'); the score trackers consume that
                 # width as it is, every other reader strips it (``unpadded_queries``)
                 module.query_padding = out.shape[-1] - (a.shape[-1] + int(ones))

@@ -89,8 +89,8 @@ class SelfScoreTracker(_SelfScoreBase):
             if module.per_sample_gradient_process_fnc is None and module.factor_args.strategy in ("ekfac", "kfac"):
                 g, a, ones = module.gradient_factors(activation, output_gradient.detach())
                 b, r, o = g.shape
-                gt = ops.matmul_nn(g.reshape(b * r, o), storage[GRADIENT_EIGENVECTORS_NAME])
-                at = ops.matmul_nn(a.reshape(b * r, a.shape[-1]), storage[ACTIVATION_EIGENVECTORS_NAME], append_ones=ones)
+                gt = ops.matmul_nn(g.reshape(b * r, o), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME))
+                at = ops.matmul_nn(a.reshape(b * r, a.shape[-1]), self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME), append_ones=ones)
                 ip = at.shape[1]
                 rotated = torch.empty((b, o, ip), dtype=torch.float32, device=g.device)
                 ops.gemm(rotated, ip, o * ip, ops.view(gt, r * o, 1, o, o, r), ops.view(at, r * ip, 1, ip, ip, r), batch=b,
@@ -142,8 +142,8 @@ class SelfScoreWithMeasurementTracker(_SelfScoreBase):
                     # rotated row by row, keeping the R axis: the held queries had one row per sample, the train
                     # batch may have several (single-token queries against sequence batches)
                     n, r = g.shape[0], g.shape[1]
-                    g = ops.matmul_nn(g.reshape(n * r, -1), storage[GRADIENT_EIGENVECTORS_NAME]).reshape(n, r, -1)
-                    a = ops.matmul_nn(a.reshape(n * r, -1), storage[ACTIVATION_EIGENVECTORS_NAME],
+                    g = ops.matmul_nn(g.reshape(n * r, -1), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME)).reshape(n, r, -1)
+                    a = ops.matmul_nn(a.reshape(n * r, -1), self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME),
                                       append_ones=ones).reshape(n, r, -1)
                     ones = False
                 psg = ops.per_sample_gradient(g, a, ones)

@@ -749,6 +749,48 @@ def precondition(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g: torch
     return out
 
 
+def precondition_bf16_eligible(g: torch.Tensor, a: torch.Tensor) -> bool:
+    """Shapes / dtypes the bf16 form of the preconditioner takes (``precondition_bf16``; the library decides the same way)."""
+    return (g.is_cuda and g.dtype == a.dtype == torch.bfloat16 and g.dim() == 3 and g.shape[1] > 1 and g.shape[2] % 8 == 0
+            and a.shape[2] % 8 == 0 and g.shape[2] >= 64 and a.shape[2] >= 64)
+
+
+def precondition_bf16(g: torch.Tensor, a: torch.Tensor, append_ones: bool, q_g_bf16: torch.Tensor, q_g_t_bf16: torch.Tensor,
+                      q_a_bf16: torch.Tensor, q_a_t_bf16: torch.Tensor, bias_row: Optional[torch.Tensor], lam_inv: torch.Tensor,
+                      scale: float = 1.0) -> torch.Tensor:
+    """``precondition`` for ``precondition_dtype == score_dtype == bf16`` from bf16 eigenvectors ONLY (kf_precondition_bf16): no
+    fp32 copies of ``Q_G`` / ``Q_A`` have to exist.  ``q_a_bf16`` / ``q_a_t_bf16``: ``[W, W]``, ``W = I'`` rounded up to a multiple of
+    8, zero-padded; ``bias_row``: fp32 ``Q_A[I]`` (``append_ones``).  -> bf16 ``[q, O, W]``."""
+    nat.require_device(g, "g")
+    g, a = _contig(g), _contig(a)
+    q, r, o = g.shape
+    i = a.shape[2]
+    ip = i + int(append_ones)
+    w = q_a_bf16.shape[0]
+    _require(precondition_bf16_eligible(g, a), "precondition_bf16: bf16 [q, R > 1, .] factors with O, I multiples of 8 and >= 64")
+    _require(q_g_bf16.shape == q_g_t_bf16.shape == (o, o) and q_a_bf16.shape == q_a_t_bf16.shape == (w, w) and w % 8 == 0
+             and ip <= w < ip + 8 and lam_inv.shape == (o, ip), "precondition_bf16: operand shapes")
+    _require(q_g_bf16.dtype == q_g_t_bf16.dtype == q_a_bf16.dtype == q_a_t_bf16.dtype == torch.bfloat16
+             and lam_inv.dtype == torch.float32 and all(t.is_contiguous() for t in (q_g_bf16, q_g_t_bf16, q_a_bf16, q_a_t_bf16, lam_inv)),
+             "precondition_bf16: contiguous bf16 eigenvector copies, fp32 inverse Lambda")
+    if append_ones:
+        _require(bias_row is not None and bias_row.dtype == torch.float32 and bias_row.is_contiguous() and bias_row.numel() == ip,
+                 "precondition_bf16: fp32 bias row of I' entries")
+    out = torch.empty((q, o, w), dtype=torch.bfloat16, device=g.device)
+    ws_bytes = nat.lib().kf_precondition_workspace_bytes(q, r, o, ip)
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=g.device)
+    flops = 2.0 * q * r * (o * o + i * ip) + 2.0 * q * r * o * ip + 2.0 * q * o * ip * (ip + o)
+    with _Timed("precondition", g.device, flops, float(q) * (r * (o + i) * 2 + o * w * 2)):
+        nat.check(
+            nat.lib().kf_precondition_bf16(out.data_ptr(), w, g.data_ptr(), a.data_ptr(), q, r, o, i, int(append_ones),
+                                           q_g_bf16.data_ptr(), q_g_t_bf16.data_ptr(), q_a_bf16.data_ptr(), q_a_t_bf16.data_ptr(), w,
+                                           _ptr(bias_row) if append_ones else None, lam_inv.data_ptr(), scale, ws.data_ptr(), ws_bytes,
+                                           nat.stream_ptr(g.device)),
+            "kf_precondition_bf16",
+        )
+    return out
+
+
 # When set to a dict, the instrumented entry points append ``(start_event, end_event, algorithmic_flops,
 # algorithmic_bytes)`` under their name: bench.py times the hot kernels with HIP events on the launch stream.
 EVENT_LOG: Optional[dict] = None

@@ -921,6 +921,53 @@ def test_precondition_bf16_odd_augmented_axis(ops, q, r, o, i):
     assert rel(got[..., :ip], want) <= 1.5e-2, rel(got[..., :ip], want)
 
 
+@pytest.mark.parametrize("q,r,o,i,bias", [(3, 64, 64, 128, True), (2, 128, 768, 768, True), (4, 6, 72, 136, False), (2, 128, 128, 256, False),
+                                          (3, 50, 128, 72, True)])
+def test_precondition_bf16_eigenvectors_only(ops, q, r, o, i, bias):
+    """kf_precondition_bf16 (ABI 14): the bf16 preconditioner from bf16 eigenvector matrices ALONE -- ``Q_G`` itself in bf16 for the
+    back rotation, the bias row ``Q_A[I]`` in fp32 -- gives what ``kf_precondition`` gives when it is handed the fp32 matrices
+    those were rounded from (it casts ``Q_G`` per call and reads row ``I`` of ``Q_A``): bit for bit, on the round-3 call chain
+    (whole 64-deep tiles) and on the round-1 one (ragged shapes); and against the fp64 oracle (K7 + K11)."""
+    ip = i + int(bias)
+    w = ip + (-ip) % 8
+    g, a = _rand(q, r, o, dtype=torch.bfloat16), _rand(q, r, i, dtype=torch.bfloat16, seed=1)
+    q_g = torch.linalg.qr(_rand(o, o, seed=2).double())[0].to(torch.bfloat16)      # the factors as STORED: bf16
+    q_a = torch.linalg.qr(_rand(ip, ip, seed=3).double())[0].to(torch.bfloat16)
+    lam_inv = _rand(o, ip, seed=4).abs().double() + 0.1
+    want = ref.ekfac_precondition(ref.linear_per_sample_gradient(a.double(), g.double(), bias), q_a.double(), q_g.double(), lam_inv) * 0.5
+    qa_d, qg_d = q_a.to(DEV), q_g.to(DEV)
+    padded = torch.nn.functional.pad(qa_d, (0, w - ip, 0, w - ip)).contiguous()
+    padded_t = torch.nn.functional.pad(qa_d.t(), (0, w - ip, 0, w - ip)).contiguous()
+    bias_row = qa_d[-1].float().contiguous() if bias else None
+    assert ops.precondition_bf16_eligible(g.to(DEV), a.to(DEV))
+    got = ops.precondition_bf16(g.to(DEV), a.to(DEV), bias, qg_d.contiguous(), qg_d.t().contiguous(), padded, padded_t, bias_row,
+                                lam_inv.float().to(DEV), scale=0.5)
+    same = ops.precondition(g.to(DEV), a.to(DEV), bias, qg_d.float(), qa_d.float().contiguous(), lam_inv.float().to(DEV), scale=0.5,
+                            out_dtype=torch.bfloat16, q_a_bf16=padded, q_g_t_bf16=qg_d.t().contiguous(), q_a_t_bf16=padded_t)
+    assert got.shape == same.shape == (q, o, w) and got.dtype == torch.bfloat16
+    assert torch.equal(got, same)
+    assert float(got[..., ip:].float().abs().max()) == 0.0 if w > ip else True
+    assert rel(got[..., :ip], want) <= 1.5e-2, rel(got[..., :ip], want)
+
+
+def test_precondition_bf16_declines_what_the_bf16_engine_does_not_take(ops):
+    """One row per sample (R == 1) or narrow factors are not the bf16 call chain's: ``precondition_bf16_eligible`` says so and the
+    entry point answers KF_ERR_INVALID_ARGUMENT -- the tracker then converts the eigenvectors to fp32 on first use."""
+    from kronfluence_amd import _native
+
+    g, a = _rand(3, 1, 64, dtype=torch.bfloat16).to(DEV), _rand(3, 1, 64, dtype=torch.bfloat16, seed=1).to(DEV)
+    assert not ops.precondition_bf16_eligible(g, a)
+    eye = torch.eye(64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_native.KfError):
+        ops.precondition_bf16(g, a, False, eye, eye, eye, eye, None, torch.ones(64, 64, device=DEV))
+    out = torch.empty(3, 64, 64, dtype=torch.bfloat16, device=DEV)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=DEV)
+    rc = _native.lib().kf_precondition_bf16(out.data_ptr(), 64, g.data_ptr(), a.data_ptr(), 3, 1, 64, 64, 0, eye.data_ptr(), eye.data_ptr(),
+                                            eye.data_ptr(), eye.data_ptr(), 64, None, torch.ones(64, 64, device=DEV).data_ptr(), 1.0,
+                                            ws.data_ptr(), ws.numel(), None)
+    assert rc != 0
+
+
 @pytest.mark.parametrize("b,r,o,i,bias", [(4, 64, 64, 128, True), (2, 128, 768, 768, True), (3, 128, 64, 3072, True), (3, 64, 72, 136, False)])
 def test_lambda_bf16_odd_augmented_axis(ops, b, r, o, i, bias):
     """bf16 Lambda rotations with the bias row added in the epilogue and the augmented axis zero-padded to a multiple of 8
