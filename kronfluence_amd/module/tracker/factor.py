@@ -188,10 +188,14 @@ class LambdaTracker(BaseTracker):
                 f"The strategy {self.module.factor_args.strategy} requires eigendecomposition "
                 f"results for Lambda computations, but they are not found."
             )
+        # bf16 lambda_dtype + bf16-stored eigenvectors: the bf16 rotations below build their operands from the stored matrices, no
+        # fp32 copy is made (Llama-3-8B at full depth: 99 GB); the fp32 engine converts on first use (``_eigenvectors32``)
+        keep = self.module.factor_args.lambda_dtype == torch.bfloat16
         for name in (ACTIVATION_EIGENVECTORS_NAME, GRADIENT_EIGENVECTORS_NAME):
             q = storage[name]
-            if q.device != device or q.dtype != torch.float32 or not q.is_contiguous():
-                storage[name] = q.to(device=device, dtype=torch.float32).contiguous()  # once (factor.py:191-201)
+            want = q.dtype if (keep and q.dtype == torch.bfloat16) else torch.float32
+            if q.device != device or q.dtype != want or not q.is_contiguous():
+                storage[name] = q.to(device=device, dtype=want).contiguous()  # once (factor.py:191-201)
         return storage[ACTIVATION_EIGENVECTORS_NAME], storage[GRADIENT_EIGENVECTORS_NAME]
 
     _bf16_eigenvectors = None  # (Q_A^T, Q_G^T) in bf16, for lambda_dtype == bf16
@@ -287,7 +291,7 @@ class LambdaTracker(BaseTracker):
                 pad = (-ip) % 8
                 qa_t = torch.nn.functional.pad(q_a.t(), (0, pad, 0, pad)).to(torch.bfloat16).contiguous()
                 self._bf16_eigenvectors = (qa_t, q_g.t().contiguous().to(torch.bfloat16),
-                                           q_a[i].contiguous() if append_ones else None)
+                                           q_a[i].to(torch.float32).contiguous() if append_ones else None)
             qa_t, qg_t, bias_row = self._bf16_eigenvectors
             if self.ROWS_ENGINE and ops.lambda_rows_eligible(o, i, r):
                 # round 4: both rotations written K-contiguous per sample, the per-sample product + square + sum over
@@ -300,6 +304,7 @@ class LambdaTracker(BaseTracker):
             at = ops.rotate_bf16(a.reshape(b * r, i), qa_t, bias_row)
             ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
             return
+        q_a, q_g = self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME)
         gt = ops.matmul_nn(g.reshape(b * r, o), q_g)
         at = ops.matmul_nn(a.reshape(b * r, a.shape[-1]), q_a, append_ones=append_ones)
         ops.lambda_accum(storage[LAMBDA_MATRIX_NAME], gt, at, b, r, scale=module.gradient_scale)
@@ -321,7 +326,8 @@ class LambdaTracker(BaseTracker):
             storage[NUM_LAMBDA_PROCESSED] = torch.zeros(1, dtype=torch.int64)
         storage[NUM_LAMBDA_PROCESSED].add_(b)
         if self._rotates():
-            q_a, q_g = self._eigenvectors(g.device)
+            self._eigenvectors(g.device)
+            q_a, q_g = self._eigenvectors32(ACTIVATION_EIGENVECTORS_NAME), self._eigenvectors32(GRADIENT_EIGENVECTORS_NAME)
             t1 = torch.empty((b * o, ip), dtype=torch.float32, device=g.device)
             ops.gemm(t1, ip, 0, ops.view(g, 0, ip, 1, b * o, ip), ops.view(q_a, 0, 1, ip, ip, ip))
             rotated = torch.empty((b, o, ip), dtype=torch.float32, device=g.device)
