@@ -3,6 +3,7 @@
 #   rot       A/B of the blocked rotation's XCD grids (tools/r06_rot.py), twice, + FETCH_SIZE of the linear order against the grid
 #   dist      the query-exchange modes end to end: 2 and 8 ranks over gloo on the one GPU (KF_QUERY_EXCHANGE=gather | replicate),
 #             scores of both modes compared; the one-rank RCCL test
+#   layers    per-layer times of the event-timed entry points of the ResNet-9 workload (tools/r06_layer_times.py)
 #   llama32   configs[4] at FULL DEPTH on the one GPU: 32 Llama-3-8B decoder blocks (224 tracked projections, D = 6.98 G), rank-64
 #             queries, 256 train x 16 query sequences of 512 tokens, one cold factor fit (96 eigenproblems of 14 336^2)
 #   final     the record on the final sources: full GPU suite + smoke, kernel traces, counter passes, the driver-shaped bench line
