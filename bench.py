@@ -397,8 +397,7 @@ WORKLOADS = {
                     amp=torch.bfloat16, factor_batch=2000, train_batch=2048, query_batch=250,
                     cpu_sample=dict(n_train=192, n_query=32, n_fit=64)),
     "bert_base": dict(model=bert_base, kind="glue", vocab=28996, tokens=128, n_train=8192, n_query=872, full_n_train=67_349,
-                      # (round 6: batches of 1 024 sequences, 8 192 x 872: 4 060 -> 3 957 ms per step, covariance 1.86 -> 1.71 s)
-                      amp=torch.bfloat16, fp32_factors=True, factor_batch=1024, train_batch=1024, query_batch=109,
+                      amp=torch.bfloat16, fp32_factors=True, factor_batch=512, train_batch=512, query_batch=109,
                       cpu_sample=dict(n_train=16, n_query=4, n_fit=8)),
     "gpt2_small": dict(model=gpt2_small, kind="lm", vocab=50257, tokens=512, n_train=2048, n_query=1024,
                        full_n_train=100_000, full_n_query=2000, amp=torch.bfloat16, low_cov=True, factor_batch=128, train_batch=128,

@@ -6,7 +6,6 @@
 #   layers    per-layer times of the event-timed entry points of the ResNet-9 workload (tools/r06_layer_times.py)
 #   llama32   configs[4] at FULL DEPTH on the one GPU: 32 Llama-3-8B decoder blocks (224 tracked projections, D = 6.98 G), rank-64
 #             queries, 256 train x 16 query sequences of 512 tokens, one cold factor fit (96 eigenproblems of 14 336^2)
-#   bertrec   BERT-base re-recorded at batches of 1 024 sequences (counter replays, trace) + the default bench line again
 #   final     the record on the final sources: full GPU suite + smoke, kernel traces, counter passes, the driver-shaped bench line
 # Everything is written under gpurun_out/ (scratch; what is kept is copied to profiles/ by hand).
 set -u
@@ -117,23 +116,6 @@ layers)
     # experiments: profiles/r06_psg_register_stores_negative.log, commit 95a01bd)
     ( timeout 600 python tools/r06_layer_times.py resnet9 8000 ) 2>&1 | grep -v "^W0\|amdgpu.ids" | tail -60 > gpurun_out/r06_layer_times_resnet9.log
     tail -45 gpurun_out/r06_layer_times_resnet9.log
-    ;;
-bertrec)
-    # BERT-base re-recorded at its round-6 batch sizes (1 024 sequences): counter replays, trace, then the driver-shaped default line
-    rm -rf gpurun_out/r06_pmc
-    for e in score cov lambda; do replay_pmc gpurun_out/r06_pmc bert_base $e; done
-    ( python tools/pmc_entry_summary.py bert_base profiles/pmc_bert_base.json gpurun_out/r06_pmc ) > gpurun_out/r06_pmc_bert_base_summary.log 2>&1
-    cp profiles/pmc_bert_base.json gpurun_out/r06_pmc_bert_base.json
-    grep "^==" gpurun_out/r06_pmc_bert_base_summary.log
-    find gpurun_out/r06_pmc -name "*.csv" -size +2M -delete
-    ( cd /tmp && KF_EIGH_STREAMS=1 KF_BENCH_BUSY=0 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d "$R/gpurun_out/r06_trace_bert_base" -- \
-        python "$R/bench.py" --workload bert_base --n-train 2048 --steps 1 --warmup 1 --no-extras --no-cpu-baseline --factor-reps 0 ) > gpurun_out/r06_trace_bert_base.log 2>&1
-    find gpurun_out/r06_trace_bert_base -name "*kernel_stats.csv" -exec cp {} gpurun_out/r06_bert_base_n2048_kernel_stats.csv \;
-    rm -rf gpurun_out/r06_trace_bert_base
-    ( timeout 1800 python bench.py --gpus 1 --steps 20 --warmup 5 ) > gpurun_out/r06_bench_default.out 2> gpurun_out/r06_bench_default.err
-    tail -n 1 gpurun_out/r06_bench_default.out | wc -c
-    cp bench_extras.json gpurun_out/r06_bench_default_extras.json
-    python tools/bench_digest.py bench_extras.json | grep -v "idle 0" | cut -c1-250 || tail -c 3000 gpurun_out/r06_bench_default.err
     ;;
 suite)
     ( timeout 2700 python -m pytest tests -m gpu -q --durations=12 ) > gpurun_out/r06_pytest_gpu.log 2>&1

@@ -32,7 +32,7 @@ DEV = "cuda:0"
 LAYERS = {
     "gpt2_small": dict(T=512, q=1024, train_batch=128, pair=True, factor_batch=128,
                        shapes=[(2304, 768, True, 1), (768, 768, True, 1), (3072, 768, True, 1), (768, 3072, True, 1)]),
-    "bert_base": dict(T=128, q=872, train_batch=1024, pair=False, factor_batch=1024,   # (round 6: bench.py's batches of 1 024)
+    "bert_base": dict(T=128, q=872, train_batch=512, pair=False, factor_batch=512,
                       shapes=[(768, 768, True, 4), (3072, 768, True, 1), (768, 3072, True, 1)]),
     "llama_block": dict(T=512, q=8, train_batch=8, pair=True, factor_batch=8,
                         shapes=[(4096, 4096, False, 2), (1024, 4096, False, 2), (14336, 4096, False, 2), (4096, 14336, False, 1)]),
