@@ -256,17 +256,23 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict
     f64x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
-    for (int64_t i0 = i_begin; i0 < i_end; i0 += GK) {
-        double v[8];
+    // (round 6: the next k-tile's global loads are issued before the MFMAs of the current one -- the workgroup always has a tile in
+    //  flight instead of alternating between waiting for one and consuming it; profiles/r06_eigh_prefetch.log)
+    double v[8];
+    auto fetch = [&](int64_t i0) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int64_t i = i0 + lseg * 8 + e;
             v[e] = (grow >= 0 && i < i_end) ? Wt[grow * d + i] : 0.0;
         }
+    };
+    if (i_begin < i_end) fetch(i_begin);
+    for (int64_t i0 = i_begin; i0 < i_end; i0 += GK) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
         for (int e = 0; e < 8; ++e) tile[lrow * GPITCH + lseg * 8 + e] = v[e];
         __syncthreads();
+        if (i0 + GK < i_end) fetch(i0 + GK);
 #pragma unroll
         for (int ks = 0; ks < GK / 4; ++ks) {
             const int k = ks * 4 + (lane >> 4);
@@ -434,17 +440,21 @@ __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ W
 #pragma unroll 1
     for (int which = 0; which < 1 + with_v; ++which) {   // with_v == 0: the factor-first solver carries no V
         double* Mx = which == 0 ? Wt : Vt;
-        for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
-            double v[16];
+        double v[16];
+        auto fetch = [&](int64_t i0) {   // (round 6: the next tile's loads fly under this tile's MFMAs and stores, see eigh_gram_kernel)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int64_t i = i0 + lseg * 16 + e;
                 v[e] = (grow >= 0 && i < i_end) ? Mx[grow * d + i] : 0.0;
             }
+        };
+        if (i_begin < i_end) fetch(i_begin);
+        for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
             __syncthreads();  // previous tile consumed (and U staged, first time round)
 #pragma unroll
             for (int e = 0; e < 16; ++e) Tl[lrow * UPITCH + lseg * 16 + e] = v[e];
             __syncthreads();
+            if (i0 + UT < i_end) fetch(i0 + UT);
             f64x4 acc[4];
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -871,7 +881,8 @@ BlockPlan block_plan(int64_t d) {
     p.players = p.nblocks + (p.nblocks & 1);
     p.pairs = p.players / 2;
     // ~2 workgroups per CU per kernel: the pairs of a round alone (d / 64) would leave most of the 256 CUs idle
-    const int64_t want = std::max<int64_t>(1, (512 + p.pairs - 1) / p.pairs);
+    static const int64_t target = [] { const char* e = getenv("KF_EIGH_WGS"); return e ? std::max<int64_t>(64, atoll(e)) : 512; }();   // (measurements)
+    const int64_t want = std::max<int64_t>(1, (target + p.pairs - 1) / p.pairs);
     int64_t gs = std::max<int64_t>(1, std::min<int64_t>(want, (d + 255) / 256));
     p.gchunk = ((d + gs - 1) / gs + GK - 1) / GK * GK;
     p.gsplit = static_cast<int>((d + p.gchunk - 1) / p.gchunk);
