@@ -1182,6 +1182,7 @@ def main() -> None:
     ap.add_argument("--factor-reps", type=int, default=1)
     ap.add_argument("--train-batch", type=int, default=None, help="override the workload's train batch size")
     ap.add_argument("--factor-batch", type=int, default=None, help="override the workload's factor-fit batch size")
+    ap.add_argument("--query-batch", type=int, default=None, help="override the workload's per-device query batch size")
     ap.add_argument("--n-fit", type=int, default=None, help="fit the factors on the first N train samples only (default: all)")
     ap.add_argument("--warm-n-train", type=int, default=None, help="warm-up steps score against the first N train samples only")
     ap.add_argument("--blocks", type=int, default=None, help="llama_block: decoder blocks of the slice (default 1; other_configs uses 2)")
@@ -1204,6 +1205,8 @@ def main() -> None:
         WORKLOADS[args.workload]["train_batch"] = args.train_batch
     if args.factor_batch:
         WORKLOADS[args.workload]["factor_batch"] = args.factor_batch
+    if args.query_batch:
+        WORKLOADS[args.workload]["query_batch"] = args.query_batch
     if args.blocks:
         WORKLOADS["llama_block"]["blocks"] = args.blocks
     if args.channels_last:
