@@ -485,3 +485,48 @@ def test_side_stream_join_finds_every_tensor_a_layer_keeps():
     storage = {"covariance": a, "count": 3, "host": torch.zeros(2), "none": None, "list": [b, torch.zeros(1)], "queries": holder}
     found = list(base._device_tensors(storage))
     assert [t.shape[0] for t in found] == [2, 3, 4, 5]   # two levels of holder objects, not a third
+
+
+def test_set_factors_shares_only_read_only_accelerator_factors():
+    """``set_factors(share=...)`` (round 6): with ``clone=True`` a factor is handed to the module as it is ONLY when it is named
+    read-only for the stage AND already lives on the accelerator; host tensors and every other factor (counters, accumulators a
+    stage adds to in place) are cloned as the reference does (module/utils.py:158-177).  ``Ekfac.prepare`` with a bf16
+    preconditioner leaves bf16-stored eigenvectors bf16 (converted on first use by the fp32 paths), fp32 ones fp32."""
+    from kronfluence_amd.factor.config import FactorConfig
+    from kronfluence_amd.module.utils import READ_ONLY_FACTORS, READ_ONLY_FACTORS_WHEN_SCORING, set_factors
+
+    assert READ_ONLY_FACTORS == (C.ACTIVATION_EIGENVECTORS_NAME, C.GRADIENT_EIGENVECTORS_NAME)
+    assert READ_ONLY_FACTORS_WHEN_SCORING == READ_ONLY_FACTORS + (C.LAMBDA_MATRIX_NAME,)
+    model = prepare_model(fx.make_model("mlp"), _Task())
+    module = next(m for m in model.modules() if isinstance(m, TrackedModule))
+    host = torch.eye(3)
+    set_factors(model, C.ACTIVATION_EIGENVECTORS_NAME, {module.name: host}, clone=True, share=READ_ONLY_FACTORS)
+    stored = module.storage[C.ACTIVATION_EIGENVECTORS_NAME]
+    assert stored is not host and torch.equal(stored, host)            # a host tensor is cloned whatever its name
+    set_factors(model, C.ACTIVATION_EIGENVECTORS_NAME, {module.name: host}, clone=False)
+    assert module.storage[C.ACTIVATION_EIGENVECTORS_NAME] is host
+
+    class _Resident(torch.Tensor):   # stands in for an accelerator tensor on a box without one
+        is_cuda = True
+
+    resident = torch.eye(3).as_subclass(_Resident)
+    set_factors(model, C.GRADIENT_EIGENVECTORS_NAME, {module.name: resident}, clone=True, share=READ_ONLY_FACTORS)
+    assert module.storage[C.GRADIENT_EIGENVECTORS_NAME] is resident    # read-only + resident: shared
+    set_factors(model, C.LAMBDA_MATRIX_NAME, {module.name: resident}, clone=True, share=READ_ONLY_FACTORS)
+    assert module.storage[C.LAMBDA_MATRIX_NAME] is not resident        # the Lambda stage accumulates into Lambda: cloned
+    set_factors(model, C.LAMBDA_MATRIX_NAME, {module.name: resident}, clone=True, share=READ_ONLY_FACTORS_WHEN_SCORING)
+    assert module.storage[C.LAMBDA_MATRIX_NAME] is resident            # scoring replaces it by its damped inverse: shared
+    set_factors(model, C.NUM_LAMBDA_PROCESSED, {module.name: resident}, clone=True, share=READ_ONLY_FACTORS_WHEN_SCORING)
+    assert module.storage[C.NUM_LAMBDA_PROCESSED] is not resident      # counters are never shared
+
+
+def test_base_tracker_converts_eigenvectors_to_fp32_on_first_use_only():
+    """``BaseTracker._eigenvectors32``: what the fp32 paths call once ``Ekfac.prepare`` leaves bf16-stored eigenvectors alone."""
+    model = prepare_model(fx.make_model("mlp"), _Task())
+    module = next(m for m in model.modules() if isinstance(m, TrackedModule))
+    tracker = next(iter(module._trackers.values()))
+    low = torch.eye(4, dtype=torch.bfloat16)
+    module.storage[C.ACTIVATION_EIGENVECTORS_NAME] = low
+    first = tracker._eigenvectors32(C.ACTIVATION_EIGENVECTORS_NAME)
+    assert first.dtype == torch.float32 and module.storage[C.ACTIVATION_EIGENVECTORS_NAME] is first
+    assert tracker._eigenvectors32(C.ACTIVATION_EIGENVECTORS_NAME) is first   # converted once, kept
