@@ -250,27 +250,29 @@ __global__ __launch_bounds__(256) void eigh_gram_kernel(const double* __restrict
     int P, Q;
     pair_of_round(pair, round, players, P, Q);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int lrow = tid >> 2, lseg = tid & 3;  // loader: row of the pair, 8-double segment of the k-tile
-    const int64_t grow = pair_row(lrow, P, Q, nblocks, d);
+    // loader (round 6): 32 lanes along a row -- a wave instruction reads 2 rows x 256 contiguous bytes (it used to read one
+    // double from each of 64 rows) -- thread (lr0, lcol) fetches column lcol of rows lr0 + 8 p
+    const int lcol = tid & 31, lr0 = tid >> 5;
+    int64_t grow[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp) grow[pp] = pair_row(lr0 + 8 * pp, P, Q, nblocks, d);
     const int64_t i_begin = split * chunk, i_end = min(d, i_begin + chunk);
     f64x4 acc[4];
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[b] = f64x4{0.0, 0.0, 0.0, 0.0};
     // (round 6: the next k-tile's global loads are issued before the MFMAs of the current one -- the workgroup always has a tile in
-    //  flight instead of alternating between waiting for one and consuming it; profiles/r06_eigh_prefetch.log)
+    //  flight instead of alternating between waiting for one and consuming it; profiles/r06_eigh_prefetch_coalesced.log)
     double v[8];
     auto fetch = [&](int64_t i0) {
+        const int64_t i = i0 + lcol;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int64_t i = i0 + lseg * 8 + e;
-            v[e] = (grow >= 0 && i < i_end) ? Wt[grow * d + i] : 0.0;
-        }
+        for (int pp = 0; pp < 8; ++pp) v[pp] = (grow[pp] >= 0 && i < i_end) ? Wt[grow[pp] * d + i] : 0.0;
     };
     if (i_begin < i_end) fetch(i_begin);
     for (int64_t i0 = i_begin; i0 < i_end; i0 += GK) {
         __syncthreads();  // previous tile fully consumed
 #pragma unroll
-        for (int e = 0; e < 8; ++e) tile[lrow * GPITCH + lseg * 8 + e] = v[e];
+        for (int pp = 0; pp < 8; ++pp) tile[(lr0 + 8 * pp) * GPITCH + lcol] = v[pp];
         __syncthreads();
         if (i0 + GK < i_end) fetch(i0 + GK);
 #pragma unroll
@@ -430,8 +432,12 @@ __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ W
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const double* usrc = Ubuf + static_cast<int64_t>(pair) * (KP * KP);
     for (int e = tid; e < KP * KP; e += 256) Ul[(e / KP) * UPITCH + (e % KP)] = usrc[e];
-    const int lrow = tid >> 2, lseg = tid & 3;  // loader: row c of the pair, 16-double segment of the tile
-    const int64_t grow = pair_row(lrow, P, Q, nblocks, d);
+    // loader (round 6): 16 lanes along a row -- a wave instruction reads 4 rows x 128 contiguous bytes -- thread (lr0, lcol) fetches
+    // columns lcol + 16 c of rows lr0 + 16 p
+    const int lcol = tid & 15, lr0 = tid >> 4;
+    int64_t grow[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) grow[pp] = pair_row(lr0 + 16 * pp, P, Q, nblocks, d);
     // output rows of this wave: j = wave * 16 + (lane >> 4) + 4 r
     int64_t orow[4];
 #pragma unroll
@@ -443,16 +449,20 @@ __global__ __launch_bounds__(256) void eigh_update_kernel(double* __restrict__ W
         double v[16];
         auto fetch = [&](int64_t i0) {   // (round 6: the next tile's loads fly under this tile's MFMAs and stores, see eigh_gram_kernel)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int64_t i = i0 + lseg * 16 + e;
-                v[e] = (grow >= 0 && i < i_end) ? Mx[grow * d + i] : 0.0;
-            }
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int64_t i = i0 + lcol + 16 * c;
+                    v[pp * 4 + c] = (grow[pp] >= 0 && i < i_end) ? Mx[grow[pp] * d + i] : 0.0;
+                }
         };
         if (i_begin < i_end) fetch(i_begin);
         for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
             __syncthreads();  // previous tile consumed (and U staged, first time round)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) Tl[lrow * UPITCH + lseg * 16 + e] = v[e];
+            for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) Tl[(lr0 + 16 * pp) * UPITCH + lcol + 16 * c] = v[pp * 4 + c];
             __syncthreads();
             if (i0 + UT < i_end) fetch(i0 + UT);
             f64x4 acc[4];
@@ -663,18 +673,23 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Wt
     const int64_t r0 = static_cast<int64_t>(k) * CB, i_lo = r0 + CB;
     const int n = static_cast<int>(min<int64_t>(CB, d - r0));
     for (int e = tid; e < CB * CB; e += 256) Ul[(e / CB) * UPITCH + (e % CB)] = U[e];
-    const int lrow = tid >> 2, lseg = tid & 3;   // loader: row c of the step, 16-double segment of the tile
+    const int lcol = tid & 15, lr0 = tid >> 4;   // loader as eigh_update_kernel's: 16 lanes along a row, rows lr0 + 16 p, columns lcol + 16 c
     const int64_t i_begin = i_lo + blockIdx.x * chunk, i_end = min(d, i_begin + chunk);
     for (int64_t i0 = i_begin; i0 < i_end; i0 += UT) {
         double v[16];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int64_t i = i0 + lseg * 16 + e;
-            v[e] = (lrow < n && i < i_end) ? Wt[(r0 + lrow) * d + i] : 0.0;
-        }
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int64_t i = i0 + lcol + 16 * c;
+                const int row = lr0 + 16 * pp;
+                v[pp * 4 + c] = (row < n && i < i_end) ? Wt[(r0 + row) * d + i] : 0.0;
+            }
         __syncthreads();  // previous tile consumed (and U staged, first time round)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) Tl[lrow * UPITCH + lseg * 16 + e] = v[e];
+        for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) Tl[(lr0 + 16 * pp) * UPITCH + lcol + 16 * c] = v[pp * 4 + c];
         __syncthreads();
         f64x4 acc[4];
 #pragma unroll
@@ -713,13 +728,16 @@ __global__ __launch_bounds__(256) void chol_trailing_kernel(double* __restrict__
     const int64_t r0 = static_cast<int64_t>(k) * CB, c0 = r0 + CB;
     const int n = static_cast<int>(min<int64_t>(CB, d - r0));
     const int64_t i0 = c0 + static_cast<int64_t>(blockIdx.x) * CB, j0 = c0 + static_cast<int64_t>(blockIdx.y) * CB;
-    const int lrow = tid >> 2, lseg = tid & 3;
+    const int lcol = tid & 15, lr0 = tid >> 4;   // 16 lanes along a row (coalesced: 4 rows x 128 bytes per wave instruction)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int64_t i = i0 + lseg * 16 + e, j = j0 + lseg * 16 + e;
-        Al[lrow * UPITCH + lseg * 16 + e] = (lrow < n && i < d) ? Wt[(r0 + lrow) * d + i] : 0.0;
-        Bl[lrow * UPITCH + lseg * 16 + e] = (lrow < n && j < d) ? Wt[(r0 + lrow) * d + j] : 0.0;
-    }
+    for (int pp = 0; pp < 4; ++pp)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = lr0 + 16 * pp, col = lcol + 16 * c;
+            const int64_t i = i0 + col, j = j0 + col;
+            Al[row * UPITCH + col] = (row < n && i < d) ? Wt[(r0 + row) * d + i] : 0.0;
+            Bl[row * UPITCH + col] = (row < n && j < d) ? Wt[(r0 + row) * d + j] : 0.0;
+        }
     __syncthreads();
     f64x4 acc[4];
 #pragma unroll
